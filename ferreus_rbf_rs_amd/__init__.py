@@ -1,0 +1,12 @@
+"""MI355X-native BBFMM matvec for ferreus_rbf_rs's RBF solve hot path.
+
+`FmmTree` mirrors ferreus_rbf_utils::FmmTree / py_ferreus_bbfmm.FmmTree; all passes run
+as HIP kernels behind the C ABI in include/ferreus_bbfmm_hip.h.
+"""
+from .fmm_tree import (FmmError, FmmKernelType, FmmParams, FmmTree, KernelDoesNotSupportGradients,
+                       KernelParams, KernelType, M2LCompressionType, PointOutsideTree,
+                       SpheroidalOrder, mfma_f64_selftest)
+
+__all__ = ["FmmTree", "FmmParams", "KernelParams", "KernelType", "FmmKernelType",
+           "SpheroidalOrder", "M2LCompressionType", "FmmError", "PointOutsideTree",
+           "KernelDoesNotSupportGradients", "mfma_f64_selftest"]

@@ -1,0 +1,105 @@
+"""ctypes binding of libferreus_bbfmm_hip.so (the C ABI in include/ferreus_bbfmm_hip.h).
+
+The product path fails loudly when the HIP library is missing: there is no Python or
+CPU fallback for any compute entry point.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libferreus_bbfmm_hip.so")
+
+# bbfmm_status
+OK, POINT_OUTSIDE_TREE, KERNEL_NO_GRADIENTS, BAD_ARGUMENT, DEVICE_ERROR, UNSUPPORTED = range(6)
+FLAG_HOST_ONLY = 1
+N_PHASES = 11
+PHASE_NAMES = ["gather", "P2M", "M2M", "M2L_stage1", "M2L_stage2", "P2L", "L2L", "P2P", "M2P",
+               "L2P", "scatter"]
+
+c_i32, c_i64, c_f64, c_u32 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double, ctypes.c_uint32
+c_p = ctypes.c_void_p
+
+
+class Params(ctypes.Structure):
+    """bbfmm_params <-> FmmParams (ferreus_bbfmm/src/bbfmm.rs:77-104)."""
+    _fields_ = [("max_points_per_cell", c_i64), ("compression_type", c_i32),
+                ("epsilon", c_f64), ("eval_chunk_size", c_i64)]
+
+
+class TreeStats(ctypes.Structure):
+    _fields_ = [("d", c_i32), ("order", c_i32), ("n_nodes", c_i32), ("depth", c_i32),
+                ("n_points", c_i64), ("n_cells", c_i64), ("n_leaves", c_i64),
+                ("n_u", c_i64), ("n_v", c_i64), ("n_w", c_i64), ("n_x", c_i64),
+                ("p2p_pairs", c_i64), ("p2p_tile_bytes_k1", c_i64), ("m2l_flops_k1", c_f64),
+                ("center", c_f64 * 3), ("radius", c_f64)]
+
+
+# every symbol include/ferreus_bbfmm_hip.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "bbfmm_params_defaults": (None, [c_i32, c_p]),
+    "bbfmm_create": (ctypes.c_int, [c_p, c_i64, c_i32, c_i64, c_i32, c_i32, c_f64, c_f64, c_i32,
+                                    c_i32, c_p, c_p, c_u32, c_p]),
+    "bbfmm_destroy": (None, [c_p]),
+    "bbfmm_last_error": (ctypes.c_char_p, [c_p]),
+    "bbfmm_set_weights": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64]),
+    "bbfmm_set_local_coefficients": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64]),
+    "bbfmm_evaluate": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64, c_p, c_i64, c_i64, c_p, c_i64,
+                                      c_p]),
+    "bbfmm_evaluate_with_gradients": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64, c_p, c_i64,
+                                                     c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+    "bbfmm_evaluate_leaves": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64, c_p, c_i64, c_i64, c_p,
+                                             c_i64, c_p]),
+    "bbfmm_evaluate_leaves_with_gradients": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64, c_p,
+                                                            c_i64, c_i64, c_p, c_i64, c_p, c_i64,
+                                                            c_p]),
+    "bbfmm_source_points": (ctypes.c_int, [c_p, c_p, c_i64]),
+    "bbfmm_fast_matrix_vector_product": (ctypes.c_int, [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p,
+                                                        c_i64, c_f64, c_p]),
+    "bbfmm_matvec_device": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_i64, c_i32]),
+    "bbfmm_stream": (c_p, [c_p]),
+    "bbfmm_set_partition": (ctypes.c_int, [c_p, c_i32, c_i32]),
+    "bbfmm_partition_row_count": (c_i64, [c_p]),
+    "bbfmm_partition_rows": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_get_tree_stats": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_get_cells": (ctypes.c_int, [c_p, c_p, c_p]),
+    "bbfmm_get_leaf_sources": (ctypes.c_int, [c_p, c_p, c_p]),
+    "bbfmm_get_list": (ctypes.c_int, [c_p, ctypes.c_char, c_p, c_p, c_p]),
+    "bbfmm_get_m2l_ranks": (ctypes.c_int, [c_p, c_p, c_p]),
+    "bbfmm_get_m2l_operator": (ctypes.c_int, [c_p, c_i32, c_i32, c_p]),
+    "bbfmm_get_m2l_factors": (ctypes.c_int, [c_p, c_i32, c_i32, c_p, c_p]),
+    "bbfmm_get_permutation_tables": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
+    "bbfmm_points_to_leaves": (ctypes.c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p]),
+    "bbfmm_set_profiling": (ctypes.c_int, [c_p, c_i32]),
+    "bbfmm_get_phase_ms": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_reset_phase_ms": (ctypes.c_int, [c_p]),
+    "bbfmm_mfma_f64_selftest": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_debug_dense_m2m": (ctypes.c_int, [c_p, c_i32, c_p]),
+    "bbfmm_debug_apply_m2l_tables_host": (ctypes.c_int, [c_p, c_p, c_p]),
+    "bbfmm_debug_get_coefficients": (ctypes.c_int, [c_p, ctypes.c_char, c_i32, c_p]),
+}
+
+_lib = None
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (built by ferreus_rbf_rs_amd/build.py).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -m ferreus_rbf_rs_amd.build` "
+            "(hipcc, gfx950).  There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,322 @@
+// extern "C" boundary: include/ferreus_bbfmm_hip.h over bbfmm::FmmTree.
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ferreus_bbfmm_hip.h"
+#include "fmm_tree.hpp"
+
+struct bbfmm_handle {
+    bbfmm::FmmTree tree;
+    std::string err;
+};
+
+using bbfmm::FmmTree;
+
+#define GUARD(h)                              \
+    if (!(h)) return BBFMM_BAD_ARGUMENT;      \
+    try {
+#define END_GUARD(h)                                   \
+    }                                                  \
+    catch (const std::bad_alloc &) {                   \
+        (h)->err = "out of host memory";               \
+        return BBFMM_BAD_ARGUMENT;                     \
+    }                                                  \
+    catch (const std::exception &e) {                  \
+        (h)->err = std::string("exception: ") + e.what(); \
+        return BBFMM_BAD_ARGUMENT;                     \
+    }                                                  \
+    catch (...) {                                      \
+        (h)->err = "unknown exception";                \
+        return BBFMM_BAD_ARGUMENT;                     \
+    }
+
+extern "C" {
+
+void bbfmm_params_defaults(int32_t interpolation_order, bbfmm_params *out) {
+    if (!out) return;
+    out->max_points_per_cell = 256;
+    out->compression_type = BBFMM_COMPRESSION_ACA;
+    double eps = 1.0; // 10f64.powi(-order), bbfmm.rs:100
+    for (int i = 0; i < interpolation_order; ++i) eps *= 10.0;
+    out->epsilon = 1.0 / eps;
+    out->eval_chunk_size = 1024;
+}
+
+int bbfmm_create(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t interpolation_order,
+                 int32_t kernel_type, double base_range, double total_sill, int32_t adaptive_tree, int32_t sparse,
+                 const double *extents, const bbfmm_params *params, uint32_t flags, bbfmm_handle **out) {
+    if (!out) return BBFMM_BAD_ARGUMENT;
+    *out = nullptr;
+    bbfmm_handle *h = nullptr;
+    try {
+        h = new bbfmm_handle();
+        const int rc = h->tree.create(pts, n, d, ld, interpolation_order, kernel_type, base_range, total_sill,
+                                      adaptive_tree != 0, sparse != 0, extents, params, flags);
+        // The handle is returned even on failure so that bbfmm_last_error can be read;
+        // the caller destroys it either way.
+        *out = h;
+        return rc;
+    } catch (const std::exception &e) {
+        if (h) {
+            h->err = std::string("exception: ") + e.what();
+            *out = h;
+        }
+        return BBFMM_BAD_ARGUMENT;
+    } catch (...) {
+        delete h;
+        return BBFMM_BAD_ARGUMENT;
+    }
+}
+
+void bbfmm_destroy(bbfmm_handle *h) { delete h; }
+
+const char *bbfmm_last_error(const bbfmm_handle *h) {
+    if (!h) return "null handle";
+    if (!h->err.empty()) return h->err.c_str();
+    return h->tree.last_error();
+}
+
+int bbfmm_set_weights(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw) {
+    GUARD(h) return h->tree.set_weights(w, rows, k, ldw);
+    END_GUARD(h)
+}
+
+int bbfmm_set_local_coefficients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw) {
+    GUARD(h) return h->tree.set_local_coefficients(w, rows, k, ldw);
+    END_GUARD(h)
+}
+
+int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw, const double *x, int64_t m,
+                   int64_t ldx, double *out, int64_t ldo, int64_t *bad_point_index) {
+    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, false, bad_point_index);
+    END_GUARD(h)
+}
+
+int bbfmm_evaluate_with_gradients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
+                                  const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo, double *grad,
+                                  int64_t ldg, int64_t *bad_point_index) {
+    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, false, bad_point_index);
+    END_GUARD(h)
+}
+
+int bbfmm_evaluate_leaves(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw, const double *x,
+                          int64_t m, int64_t ldx, double *out, int64_t ldo, int64_t *bad_point_index) {
+    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, true, bad_point_index);
+    END_GUARD(h)
+}
+
+int bbfmm_evaluate_leaves_with_gradients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
+                                         const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo,
+                                         double *grad, int64_t ldg, int64_t *bad_point_index) {
+    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, true, bad_point_index);
+    END_GUARD(h)
+}
+
+int bbfmm_source_points(const bbfmm_handle *h, double *out, int64_t ld) {
+    if (!h || !out) return BBFMM_BAD_ARGUMENT;
+    const auto &p = h->tree.source_points();
+    const int64_t n = h->tree.tree().n_points;
+    const int d = h->tree.tree().d;
+    if (ld < n) return BBFMM_BAD_ARGUMENT;
+    for (int a = 0; a < d; ++a) std::memcpy(out + a * ld, p.data() + static_cast<size_t>(a) * n, n * sizeof(double));
+    return BBFMM_OK;
+}
+
+int bbfmm_fast_matrix_vector_product(bbfmm_handle *h, const double *w, int64_t rows, int64_t basis_size,
+                                     const int64_t *target_indices, int64_t n_target_indices, const double *poly,
+                                     int64_t ldp, double nugget, double *result) {
+    GUARD(h)
+    return h->tree.fast_matrix_vector_product(w, rows, basis_size, target_indices, n_target_indices, poly, ldp, nugget,
+                                              result);
+    END_GUARD(h)
+}
+
+int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_out, int64_t ldo,
+                        int32_t sync) {
+    GUARD(h) return h->tree.matvec_device(d_w, ldw, k, d_out, ldo, sync != 0);
+    END_GUARD(h)
+}
+
+void *bbfmm_stream(bbfmm_handle *h) { return h ? static_cast<void *>(h->tree.stream()) : nullptr; }
+
+int bbfmm_set_partition(bbfmm_handle *h, int32_t rank, int32_t world) {
+    GUARD(h) return h->tree.set_partition(rank, world);
+    END_GUARD(h)
+}
+
+int64_t bbfmm_partition_row_count(const bbfmm_handle *h) {
+    if (!h) return -1;
+    const auto &r = h->tree.partition_rows();
+    return r.empty() ? h->tree.tree().n_points : static_cast<int64_t>(r.size());
+}
+
+int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out) {
+    if (!h || !rows_out) return BBFMM_BAD_ARGUMENT;
+    const auto &r = h->tree.partition_rows();
+    if (r.empty()) {
+        for (int64_t i = 0; i < h->tree.tree().n_points; ++i) rows_out[i] = i;
+    } else {
+        std::memcpy(rows_out, r.data(), r.size() * sizeof(int64_t));
+    }
+    return BBFMM_OK;
+}
+
+int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out) {
+    if (!h || !out) return BBFMM_BAD_ARGUMENT;
+    h->tree.stats(out);
+    return BBFMM_OK;
+}
+
+int bbfmm_get_cells(const bbfmm_handle *h, uint64_t *keys, uint8_t *is_leaf) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    const auto &t = h->tree.tree();
+    if (keys) std::memcpy(keys, t.key.data(), t.key.size() * sizeof(uint64_t));
+    if (is_leaf) std::memcpy(is_leaf, t.is_leaf.data(), t.is_leaf.size());
+    return BBFMM_OK;
+}
+
+int bbfmm_get_leaf_sources(const bbfmm_handle *h, int64_t *ptr, int64_t *idx) {
+    if (!h || !ptr || !idx) return BBFMM_BAD_ARGUMENT;
+    const auto &t = h->tree.tree();
+    const int64_t C = t.n_cells();
+    int64_t cur = 0;
+    for (int64_t c = 0; c < C; ++c) {
+        ptr[c] = cur;
+        if (t.is_leaf[c])
+            for (int64_t q = t.pt_begin[c]; q < t.pt_end[c]; ++q) idx[cur++] = t.order[q];
+    }
+    ptr[C] = cur;
+    return BBFMM_OK;
+}
+
+int bbfmm_get_list(const bbfmm_handle *h, char which, int64_t *ptr, int32_t *idx, int64_t *n_entries) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    const auto &t = h->tree.tree();
+    const bbfmm::Csr *l = nullptr;
+    switch (which) {
+    case 'U': case 'u': l = &t.u; break;
+    case 'V': case 'v': l = &t.v; break;
+    case 'W': case 'w': l = &t.w; break;
+    case 'X': case 'x': l = &t.x; break;
+    default: return BBFMM_BAD_ARGUMENT;
+    }
+    if (n_entries) *n_entries = static_cast<int64_t>(l->idx.size());
+    if (ptr) std::memcpy(ptr, l->ptr.data(), l->ptr.size() * sizeof(int64_t));
+    if (idx && !l->idx.empty()) std::memcpy(idx, l->idx.data(), l->idx.size() * sizeof(int32_t));
+    return BBFMM_OK;
+}
+
+int bbfmm_get_m2l_ranks(const bbfmm_handle *h, int32_t *ranks, int32_t *n_ref_out) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    const auto &o = h->tree.ops();
+    if (n_ref_out) *n_ref_out = o.n_ref;
+    if (ranks)
+        for (size_t level = 0; level < o.m2l.size(); ++level)
+            for (int r = 0; r < o.n_ref; ++r)
+                ranks[level * o.n_ref + r] = o.m2l[level].empty() ? 0 : o.m2l[level][r].rank;
+    return BBFMM_OK;
+}
+
+int bbfmm_get_m2l_operator(const bbfmm_handle *h, int32_t level, int32_t ref, double *out) {
+    if (!h || !out) return BBFMM_BAD_ARGUMENT;
+    const auto &o = h->tree.ops();
+    if (level < 2 || level >= static_cast<int>(o.m2l.size()) || ref < 0 || ref >= o.n_ref) return BBFMM_BAD_ARGUMENT;
+    const auto &op = o.m2l[level][ref];
+    const int n = o.n;
+    if (op.vt.empty()) {
+        std::memcpy(out, op.u.data(), sizeof(double) * n * n);
+        return BBFMM_OK;
+    }
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < op.rank; ++k) s += op.u[static_cast<size_t>(k) * n + i] * op.vt[static_cast<size_t>(j) * op.rank + k];
+            out[static_cast<size_t>(j) * n + i] = s;
+        }
+    return BBFMM_OK;
+}
+
+int bbfmm_get_m2l_factors(const bbfmm_handle *h, int32_t level, int32_t ref, double *u, double *vt) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    const auto &o = h->tree.ops();
+    if (level < 2 || level >= static_cast<int>(o.m2l.size()) || ref < 0 || ref >= o.n_ref) return BBFMM_BAD_ARGUMENT;
+    const auto &op = o.m2l[level][ref];
+    if (u) std::memcpy(u, op.u.data(), op.u.size() * sizeof(double));
+    if (vt && !op.vt.empty()) std::memcpy(vt, op.vt.data(), op.vt.size() * sizeof(double));
+    return BBFMM_OK;
+}
+
+int bbfmm_get_permutation_tables(const bbfmm_handle *h, int32_t *n_perm, int32_t *perm, int32_t *invperm,
+                                 int32_t *perm_lookup, int32_t *ref_lookup) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    const auto &o = h->tree.ops();
+    if (n_perm) *n_perm = o.n_perm;
+    if (perm) std::memcpy(perm, o.perm.data(), o.perm.size() * sizeof(int32_t));
+    if (invperm) std::memcpy(invperm, o.invperm.data(), o.invperm.size() * sizeof(int32_t));
+    if (perm_lookup) std::memcpy(perm_lookup, o.perm_lookup.data(), o.perm_lookup.size() * sizeof(int32_t));
+    if (ref_lookup) std::memcpy(ref_lookup, o.ref_lookup.data(), o.ref_lookup.size() * sizeof(int32_t));
+    return BBFMM_OK;
+}
+
+int bbfmm_points_to_leaves(const bbfmm_handle *h, const double *x, int64_t m, int64_t ldx, int32_t *cell_out,
+                           int64_t *bad_point_index) {
+    if (!h || (m > 0 && (!x || !cell_out)) || ldx < m) return BBFMM_BAD_ARGUMENT;
+    const int64_t bad = bbfmm::points_to_leaves(h->tree.tree(), x, m, ldx, cell_out);
+    if (bad >= 0) {
+        if (bad_point_index) *bad_point_index = bad;
+        return BBFMM_POINT_OUTSIDE_TREE;
+    }
+    return BBFMM_OK;
+}
+
+int bbfmm_set_profiling(bbfmm_handle *h, int32_t enable) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    h->tree.set_profiling(enable != 0);
+    return BBFMM_OK;
+}
+
+int bbfmm_get_phase_ms(const bbfmm_handle *h, double *ms_out) {
+    if (!h || !ms_out) return BBFMM_BAD_ARGUMENT;
+    std::memcpy(ms_out, h->tree.phase_ms(), sizeof(double) * BBFMM_N_PHASES);
+    return BBFMM_OK;
+}
+
+int bbfmm_reset_phase_ms(bbfmm_handle *h) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    h->tree.reset_phase_ms();
+    return BBFMM_OK;
+}
+
+int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors) {
+    double tf = 0;
+    int errs = -1;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BBFMM_DEVICE_ERROR;
+    const int rc = bbfmm::mfma_f64_selftest(&tf, &errs);
+    if (tflops) *tflops = tf;
+    if (layout_errors) *layout_errors = errs;
+    return rc == 0 ? BBFMM_OK : BBFMM_DEVICE_ERROR;
+}
+
+// Test hooks (host only): dense M2M matrix of the reference and the stacked-table M2L.
+int bbfmm_debug_dense_m2m(const bbfmm_handle *h, int32_t child_index, double *out) {
+    if (!h || !out) return BBFMM_BAD_ARGUMENT;
+    std::vector<double> m;
+    bbfmm::dense_m2m_matrix(h->tree.ops(), child_index, &m);
+    std::memcpy(out, m.data(), m.size() * sizeof(double));
+    return BBFMM_OK;
+}
+
+int bbfmm_debug_apply_m2l_tables_host(const bbfmm_handle *h, const double *M, double *L) {
+    if (!h || !M || !L) return BBFMM_BAD_ARGUMENT;
+    return h->tree.debug_apply_m2l_tables_host(M, L);
+}
+
+int bbfmm_debug_get_coefficients(bbfmm_handle *h, char which, int32_t k, double *out) {
+    GUARD(h) return h->tree.debug_get_coefficients(which, k, out);
+    END_GUARD(h)
+}
+
+} // extern "C"

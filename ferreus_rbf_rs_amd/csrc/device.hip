@@ -1,0 +1,1054 @@
+// Hand-written CDNA4 (gfx950) kernels for the BBFMM matvec.  See device.hpp for the
+// HBM layout.  Wavefront = 64 everywhere; FP64 throughout (the reference is f64 end
+// to end, ferreus_bbfmm/src/traits.rs:20).
+//
+//   gather/scatter  HBM streaming
+//   P2M / L2P       Chebyshev anterpolation / interpolation (chebyshev.rs:831-927),
+//                   tensor factors staged in LDS
+//   M2M / L2L       sum-factorised 1-D transfers (the reference multiplies by the
+//                   dense Kronecker matrix, bbfmm.rs:742-772,1051-1086; same operator)
+//   M2L             two batched small-GEMM stages on v_mfma_f64_16x16x4_f64
+//   P2P/M2P/P2L     direct kernel evaluation, LDS-tiled sources, lanes = target x slice
+#include "device.hpp"
+
+#include <cstdio>
+#include <vector>
+
+namespace bbfmm {
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+struct Xyz {
+    const double *x, *y, *z;
+};
+
+// ------------------------------------------------------------------ gather/scatter
+__global__ void gather_weights_kernel(const double *__restrict__ w, int64_t ldw, const int32_t *__restrict__ order,
+                                      int64_t N, double *__restrict__ ws) {
+    const int k = blockIdx.y;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x)
+        ws[k * N + i] = w[k * ldw + order[i]];
+}
+
+__global__ void scatter_output_kernel(const double *__restrict__ os, int64_t n, const int32_t *__restrict__ perm,
+                                      double *__restrict__ out, int64_t ldo, int accumulate) {
+    const int k = blockIdx.y;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t dst = k * ldo + perm[i];
+        if (accumulate)
+            out[dst] += os[k * n + i];
+        else
+            out[dst] = os[k * n + i];
+    }
+}
+
+__global__ void gather_rows_kernel(const double *__restrict__ src, int64_t ld_src, const int32_t *__restrict__ idx,
+                                   int64_t n, double *__restrict__ dst, int64_t ld_dst) {
+    const int c = blockIdx.y;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[c * ld_dst + i] = src[c * ld_src + idx[i]];
+}
+
+static inline int grid_for(int64_t n, int block) {
+    int64_t g = (n + block - 1) / block;
+    if (g > 2048) g = 2048; // 256 CUs x 8 blocks, grid-stride the rest
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+void launch_gather_weights(const double *w, int64_t ldw, int K, const int32_t *order, int64_t N, double *w_sorted,
+                           hipStream_t s) {
+    if (N == 0) return;
+    hipLaunchKernelGGL(gather_weights_kernel, dim3(grid_for(N, 256), K), dim3(256), 0, s, w, ldw, order, N, w_sorted);
+}
+void launch_scatter_output(const double *out_sorted, int64_t n, int K, const int32_t *perm, double *out, int64_t ldo,
+                           int accumulate, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(scatter_output_kernel, dim3(grid_for(n, 256), K), dim3(256), 0, s, out_sorted, n, perm, out,
+                       ldo, accumulate);
+}
+void launch_gather_rows(const double *src, int64_t ld_src, int ncols, const int32_t *idx, int64_t n, double *dst,
+                        int64_t ld_dst, hipStream_t s) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(n, 256), ncols), dim3(256), 0, s, src, ld_src, idx, n, dst,
+                       ld_dst);
+}
+
+// ------------------------------------------------------------------ Chebyshev helpers
+// Per-axis node counts: axes >= d have a single node with S = 1, so 1-D/2-D trees run
+// through the same 3-D index arithmetic (node index = (i0*P1 + i1)*P2 + i2).
+__device__ inline void axis_sizes(int p, int d, int &P0, int &P1, int &P2) {
+    P0 = p;
+    P1 = d > 1 ? p : 1;
+    P2 = d > 2 ? p : 1;
+}
+
+// S_j(x) = (2 sum_k T_k(x) T_k(node_j) - 1)/p ; dS_j = (2/p) sum_k T'_k(x) T_k(node_j)
+// (chebyshev.rs:47-142).  Results go to S[j*stride] (thread-private LDS columns).
+template <bool GRAD>
+__device__ inline void cheb_S_to(int p, double x, const double *__restrict__ polyn, double *S, double *dS, int stride) {
+    double T[kMaxOrder], dT[kMaxOrder];
+    T[0] = 1.0;
+    dT[0] = 0.0;
+    T[1] = x;
+    dT[1] = 1.0;
+#pragma unroll
+    for (int j = 2; j < kMaxOrder; ++j) {
+        if (j < p) {
+            T[j] = 2.0 * x * T[j - 1] - T[j - 2];
+            if (GRAD) dT[j] = 2.0 * T[j - 1] + 2.0 * x * dT[j - 1] - dT[j - 2];
+        }
+    }
+    for (int j = 0; j < p; ++j) {
+        double s = 0.0, ds = 0.0;
+#pragma unroll
+        for (int k = 0; k < kMaxOrder; ++k) {
+            if (k < p) {
+                const double pk = polyn[j * p + k];
+                s += T[k] * pk;
+                if (GRAD) ds += dT[k] * pk;
+            }
+        }
+        S[j * stride] = (s * 2.0 - 1.0) / (double)p;
+        if (GRAD) dS[j * stride] = ds * (2.0 / (double)p);
+    }
+}
+
+// ------------------------------------------------------------------ P2M
+// particle_to_multipole (bbfmm.rs:691-739): M_c[:, k] += S(x_leaf)^T w_leaf[:, k].
+// One workgroup per leaf; points in chunks of P2M_PTS; the three 1-D factor tables of a
+// chunk live in LDS; each thread owns output nodes tid, tid+256, ...
+constexpr int P2M_PTS = 64;
+constexpr int P2M_KB = 4;
+
+__global__ __launch_bounds__(256) void p2m_kernel(const DevCheb *__restrict__ chp, Xyz src,
+                                                  const double *__restrict__ ws, int64_t N, int K, int64_t C,
+                                                  const int32_t *__restrict__ leaf_cells,
+                                                  const int32_t *__restrict__ pt_begin,
+                                                  const int32_t *__restrict__ pt_end,
+                                                  const double *__restrict__ centers,
+                                                  const double *__restrict__ lengths, double *__restrict__ M) {
+    __shared__ double s_polyn[kMaxOrder * kMaxOrder];
+    __shared__ double s_S[3][kMaxOrder][P2M_PTS];
+    __shared__ double s_w[P2M_KB][P2M_PTS];
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p * p; i += 256) s_polyn[i] = chp->polyn[i];
+    const int cell = leaf_cells[blockIdx.x];
+    const int b = pt_begin[cell], e = pt_end[cell];
+    const double len = lengths[cell];
+    const double cx = centers[cell * 3 + 0], cy = centers[cell * 3 + 1], cz = centers[cell * 3 + 2];
+    __syncthreads();
+    for (int base = b; base < e; base += P2M_PTS) {
+        const int npts = min(P2M_PTS, e - base);
+        // 1-D factors: thread -> (axis, point)
+        if (tid < 3 * P2M_PTS) {
+            const int axis = tid / P2M_PTS, pt = tid % P2M_PTS;
+            if (pt < npts) {
+                if (axis < d) {
+                    const double *co = axis == 0 ? src.x : (axis == 1 ? src.y : src.z);
+                    const double c0 = axis == 0 ? cx : (axis == 1 ? cy : cz);
+                    const double x = (co[base + pt] - c0) / (len * 0.5); // chebyshev.rs:841-845
+                    cheb_S_to<false>(p, x, s_polyn, &s_S[axis][0][pt], nullptr, P2M_PTS);
+                } else {
+                    s_S[axis][0][pt] = 1.0;
+                }
+            }
+        }
+        for (int k0 = 0; k0 < K; k0 += P2M_KB) {
+            const int kb = min(P2M_KB, K - k0);
+            __syncthreads();
+            if (tid < P2M_PTS)
+                for (int kk = 0; kk < kb; ++kk)
+                    if (tid < npts) s_w[kk][tid] = ws[(int64_t)(k0 + kk) * N + base + tid];
+            __syncthreads();
+            for (int I = tid; I < n; I += 256) {
+                const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1);
+                double acc[P2M_KB] = {0.0, 0.0, 0.0, 0.0};
+                for (int pt = 0; pt < npts; ++pt) {
+                    const double v = s_S[0][i0][pt] * s_S[1][i1][pt] * s_S[2][i2][pt];
+#pragma unroll
+                    for (int kk = 0; kk < P2M_KB; ++kk)
+                        if (kk < kb) acc[kk] += v * s_w[kk][pt];
+                }
+#pragma unroll
+                for (int kk = 0; kk < P2M_KB; ++kk)
+                    if (kk < kb) M[((int64_t)(k0 + kk) * C + cell) * n_pad + I] += acc[kk];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ M2M / L2L
+// One pass of a sum-factorised transfer along `axis`.  in/out are n-vectors in LDS with
+// index (i0*P1 + i1)*P2 + i2.  FORWARD (M2M): out[.., i, ..] = sum_a xf[a][i] in[.., a, ..];
+// transposed (L2L): out[.., a, ..] = sum_i xf[a][i] in[.., i, ..].  xf = xfer[side] (p x p).
+template <bool FORWARD>
+__device__ inline void transfer_pass(const double *in, double *out, const double *xf, int axis, int p, int P0, int P1,
+                                     int P2, int n, int tid, int nthreads) {
+    const int stride = axis == 0 ? P1 * P2 : (axis == 1 ? P2 : 1);
+    for (int I = tid; I < n; I += nthreads) {
+        const int ia = (I / stride) % p;
+        const int base = I - ia * stride;
+        double s = 0.0;
+        for (int a = 0; a < p; ++a) {
+            const double f = FORWARD ? xf[a * p + ia] : xf[ia * p + a];
+            s += f * in[base + a * stride];
+        }
+        out[I] = s;
+    }
+}
+
+// multipole_to_multipole (bbfmm.rs:742-772): one workgroup per parent.
+__global__ __launch_bounds__(256) void m2m_kernel(const DevCheb *__restrict__ chp, int K, int64_t C,
+                                                  const int32_t *__restrict__ parents,
+                                                  const int64_t *__restrict__ child_ptr,
+                                                  const int32_t *__restrict__ child_idx,
+                                                  const int32_t *__restrict__ octant, double *__restrict__ M) {
+    extern __shared__ double lds[];
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    double *bufA = lds, *bufB = lds + n, *acc = lds + 2 * n, *xf = lds + 3 * n;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * p * p; i += 256) xf[i] = chp->xfer[i];
+    const int P = parents[blockIdx.x];
+    const int64_t c0 = child_ptr[P], c1 = child_ptr[P + 1];
+    for (int k = 0; k < K; ++k) {
+        for (int I = tid; I < n; I += 256) acc[I] = 0.0;
+        for (int64_t q = c0; q < c1; ++q) {
+            const int ch = child_idx[q];
+            const int oct = octant[ch];
+            const double *Mc = M + ((int64_t)k * C + ch) * n_pad;
+            __syncthreads();
+            for (int I = tid; I < n; I += 256) bufA[I] = Mc[I];
+            __syncthreads();
+            double *in = bufA, *out = bufB;
+            for (int axis = d - 1; axis >= 0; --axis) {
+                const double *x1 = xf + ((oct >> axis) & 1) * p * p; // chebyshev.rs:183-192: bit a <-> axis a
+                transfer_pass<true>(in, out, x1, axis, p, P0, P1, P2, n, tid, 256);
+                __syncthreads();
+                double *t = in;
+                in = out;
+                out = t;
+            }
+            for (int I = tid; I < n; I += 256) acc[I] += in[I];
+        }
+        __syncthreads();
+        double *Mp = M + ((int64_t)k * C + P) * n_pad;
+        for (int I = tid; I < n; I += 256) Mp[I] += acc[I];
+        __syncthreads();
+    }
+}
+
+// local_to_local (bbfmm.rs:1051-1086): one workgroup per child cell.
+__global__ __launch_bounds__(256) void l2l_kernel(const DevCheb *__restrict__ chp, int K, int64_t C,
+                                                  const int32_t *__restrict__ cells,
+                                                  const int32_t *__restrict__ parent,
+                                                  const int32_t *__restrict__ octant,
+                                                  const uint8_t *__restrict__ active, double *__restrict__ L) {
+    extern __shared__ double lds[];
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    double *bufA = lds, *bufB = lds + n, *xf = lds + 2 * n;
+    const int tid = threadIdx.x;
+    const int c = cells[blockIdx.x];
+    if (active && !active[c]) return;
+    const int P = parent[c];
+    if (P < 0) return;
+    for (int i = tid; i < 2 * p * p; i += 256) xf[i] = chp->xfer[i];
+    const int oct = octant[c];
+    for (int k = 0; k < K; ++k) {
+        const double *Lp = L + ((int64_t)k * C + P) * n_pad;
+        __syncthreads();
+        for (int I = tid; I < n; I += 256) bufA[I] = Lp[I];
+        __syncthreads();
+        double *in = bufA, *out = bufB;
+        for (int axis = 0; axis < d; ++axis) {
+            const double *x1 = xf + ((oct >> axis) & 1) * p * p;
+            transfer_pass<false>(in, out, x1, axis, p, P0, P1, P2, n, tid, 256);
+            __syncthreads();
+            double *t = in;
+            in = out;
+            out = t;
+        }
+        double *Lc = L + ((int64_t)k * C + c) * n_pad;
+        for (int I = tid; I < n; I += 256) Lc[I] += in[I];
+    }
+}
+
+// ------------------------------------------------------------------ L2P
+// local_to_particle (bbfmm.rs:1358-1440): y[t] += S(x_t) . L_leaf, optionally gradients
+// (dS scaled by 2/length, chebyshev.rs:862-869).  Thread per target; per-thread factor
+// columns in LDS (index [axis][j][tid]); L_leaf broadcast from LDS.
+constexpr int L2P_THREADS = 128;
+
+template <bool GRAD>
+__global__ __launch_bounds__(L2P_THREADS) void l2p_kernel(const DevCheb *__restrict__ chp,
+                                                          const int32_t *__restrict__ leaf_cells,
+                                                          const int32_t *__restrict__ tgt_begin,
+                                                          const int32_t *__restrict__ tgt_end,
+                                                          const double *__restrict__ centers,
+                                                          const double *__restrict__ lengths, Xyz tgt, int64_t n_tgt,
+                                                          int K, int64_t C, const double *__restrict__ L,
+                                                          double *__restrict__ out, double *__restrict__ grad) {
+    extern __shared__ double lds[];
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    const int tid = threadIdx.x;
+    double *s_polyn = lds;                          // p*p
+    double *s_L = s_polyn + kMaxOrder * kMaxOrder;  // n
+    double *s_S = s_L + n;                          // 3 * p * L2P_THREADS
+    double *s_dS = s_S + 3 * p * L2P_THREADS;       // 3 * p * L2P_THREADS (GRAD)
+    for (int i = tid; i < p * p; i += L2P_THREADS) s_polyn[i] = chp->polyn[i];
+    const int cell = leaf_cells[blockIdx.x];
+    const int b = tgt_begin[blockIdx.x], e = tgt_end[blockIdx.x];
+    const double len = lengths[cell];
+    const double cc[3] = {centers[cell * 3 + 0], centers[cell * 3 + 1], centers[cell * 3 + 2]};
+    __syncthreads();
+    for (int base = b; base < e; base += L2P_THREADS) {
+        const int t = base + tid;
+        const bool valid = t < e;
+        if (valid) {
+            for (int axis = 0; axis < 3; ++axis) {
+                double *S = s_S + (axis * p) * L2P_THREADS + tid;
+                double *dS = s_dS + (axis * p) * L2P_THREADS + tid;
+                if (axis < d) {
+                    const double *co = axis == 0 ? tgt.x : (axis == 1 ? tgt.y : tgt.z);
+                    const double x = (co[t] - cc[axis]) / (len * 0.5);
+                    cheb_S_to<GRAD>(p, x, s_polyn, S, dS, L2P_THREADS);
+                    if (GRAD)
+                        for (int j = 0; j < p; ++j) dS[j * L2P_THREADS] *= 2.0 / len;
+                } else {
+                    S[0] = 1.0;
+                    if (GRAD) dS[0] = 0.0;
+                }
+            }
+        }
+        for (int k = 0; k < K; ++k) {
+            __syncthreads();
+            const double *Lc = L + ((int64_t)k * C + cell) * n_pad;
+            for (int I = tid; I < n; I += L2P_THREADS) s_L[I] = Lc[I];
+            __syncthreads();
+            if (valid) {
+                const double *S0 = s_S + tid, *S1 = s_S + p * L2P_THREADS + tid, *S2 = s_S + 2 * p * L2P_THREADS + tid;
+                const double *D0 = s_dS + tid, *D1 = s_dS + p * L2P_THREADS + tid,
+                             *D2 = s_dS + 2 * p * L2P_THREADS + tid;
+                double y = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+                for (int a = 0; a < P0; ++a) {
+                    double ua = 0.0, uay = 0.0, uaz = 0.0;
+                    for (int bb = 0; bb < P1; ++bb) {
+                        double t0 = 0.0, t0z = 0.0;
+                        const double *Lr = s_L + (a * P1 + bb) * P2;
+                        for (int c = 0; c < P2; ++c) {
+                            const double lv = Lr[c];
+                            t0 += S2[c * L2P_THREADS] * lv;
+                            if (GRAD) t0z += D2[c * L2P_THREADS] * lv;
+                        }
+                        const double s1 = S1[bb * L2P_THREADS];
+                        ua += s1 * t0;
+                        if (GRAD) {
+                            uay += D1[bb * L2P_THREADS] * t0;
+                            uaz += s1 * t0z;
+                        }
+                    }
+                    const double s0 = S0[a * L2P_THREADS];
+                    y += s0 * ua;
+                    if (GRAD) {
+                        gx += D0[a * L2P_THREADS] * ua;
+                        gy += s0 * uay;
+                        gz += s0 * uaz;
+                    }
+                }
+                out[(int64_t)k * n_tgt + t] += y;
+                if (GRAD) {
+                    grad[((int64_t)k * d + 0) * n_tgt + t] += gx;
+                    if (d > 1) grad[((int64_t)k * d + 1) * n_tgt + t] += gy;
+                    if (d > 2) grad[((int64_t)k * d + 2) * n_tgt + t] += gz;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ direct interactions
+// Shared inner loop of P2P / M2P / P2L: every thread owns one target and one "slice" of
+// the staged source tile (stride S); sources are read from LDS as two 16-byte values
+// {x, y} {z, w}.  acc[kk] += K(t, s) * w_kk(s); gradient accumulators optional.
+constexpr int DIRECT_TILE = 512;
+constexpr int DIRECT_KB = 4;
+
+struct SrcTile {
+    double2 xy[DIRECT_TILE];
+    double zs[DIRECT_TILE];
+    double w[DIRECT_KB][DIRECT_TILE];
+};
+
+template <int KID, bool GRAD, int KB>
+__device__ inline void direct_tile(const KernelSpec &ks, const SrcTile &tile, int count, int first, int stride,
+                                   double tx, double ty, double tz, double (&acc)[KB], double (&gacc)[KB][3]) {
+    for (int j = first; j < count; j += stride) {
+        const double2 xy = tile.xy[j];
+        const double dx = tx - xy.x, dy = ty - xy.y, dz = tz - tile.zs[j];
+        const double r2 = dx * dx + dy * dy + dz * dz; // distance_sq, utils.rs:230-237
+        if (GRAD) {
+            double f;
+            const double v = kernel_value_grad_r2<KID>(ks, r2, &f);
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                const double wk = tile.w[kk][j];
+                acc[kk] += v * wk;
+                gacc[kk][0] += (f * dx) * wk;
+                gacc[kk][1] += (f * dy) * wk;
+                gacc[kk][2] += (f * dz) * wk;
+            }
+        } else {
+            const double v = kernel_value_r2<KID>(ks, r2);
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) acc[kk] += v * tile.w[kk][j];
+        }
+    }
+}
+
+// Cross-slice reduction through LDS; returns the total in the slice-0 thread.
+__device__ inline double slice_reduce(double v, double *red, int ti, int sl, int S, int nt, bool participates) {
+    __syncthreads();
+    if (participates) red[sl * nt + ti] = v;
+    __syncthreads();
+    double s = 0.0;
+    if (participates && sl == 0)
+        for (int q = 0; q < S; ++q) s += red[q * nt + ti];
+    return s;
+}
+
+// particle_to_particle (bbfmm.rs:1162-1251).  One workgroup per target leaf.
+template <int KID, bool GRAD, int KB>
+__global__ __launch_bounds__(256) void p2p_kernel(KernelSpec ks, int d, DirectJobs jobs, Xyz tgt, int64_t n_tgt,
+                                                  Xyz src, const double *__restrict__ ws, int64_t N, int k0, int kb,
+                                                  double *__restrict__ out, double *__restrict__ grad) {
+    __shared__ SrcTile tile;
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int job = blockIdx.x;
+    const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
+    const int jcell = jobs.job_cell[job];
+    const int64_t r0 = jobs.run_ptr[jcell], r1 = jobs.run_ptr[jcell + 1];
+    for (int tc = t0; tc < t1; tc += 256) {
+        const int nt = min(256, t1 - tc);
+        const int S = 256 / nt;
+        const int ti = tid % nt, sl = tid / nt;
+        const bool part = sl < S;
+        double tx = 0, ty = 0, tz = 0;
+        if (part) {
+            tx = tgt.x[tc + ti];
+            ty = tgt.y[tc + ti];
+            tz = tgt.z[tc + ti];
+        }
+        double acc[KB], gacc[KB][3];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) acc[kk] = gacc[kk][0] = gacc[kk][1] = gacc[kk][2] = 0.0;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int sb = jobs.runs[2 * r], se = jobs.runs[2 * r + 1];
+            for (int base = sb; base < se; base += DIRECT_TILE) {
+                const int cnt = min(DIRECT_TILE, se - base);
+                __syncthreads();
+                for (int j = tid; j < cnt; j += 256) {
+                    tile.xy[j] = make_double2(src.x[base + j], src.y[base + j]);
+                    tile.zs[j] = src.z[base + j];
+#pragma unroll
+                    for (int kk = 0; kk < KB; ++kk)
+                        tile.w[kk][j] = kk < kb ? ws[(int64_t)(k0 + kk) * N + base + j] : 0.0;
+                }
+                __syncthreads();
+                if (part) direct_tile<KID, GRAD, KB>(ks, tile, cnt, sl, S, tx, ty, tz, acc, gacc);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            if (kk >= kb) break;
+            const double v = slice_reduce(acc[kk], red, ti, sl, S, nt, part);
+            if (part && sl == 0) out[(int64_t)(k0 + kk) * n_tgt + tc + ti] += v;
+            if (GRAD) {
+                for (int a = 0; a < d; ++a) {
+                    const double g = slice_reduce(gacc[kk][a], red, ti, sl, S, nt, part);
+                    if (part && sl == 0) grad[((int64_t)(k0 + kk) * d + a) * n_tgt + tc + ti] += g;
+                }
+            }
+        }
+    }
+}
+
+// Stage the Chebyshev nodes of `cell` (scale_cheb_nodes_to_cell, chebyshev.rs:951-968) and
+// its coefficients as a source tile (n <= DIRECT_TILE assumed per chunk).
+__device__ inline void stage_nodes(SrcTile &tile, const DevCheb *chp, int P1, int P2, int j0, int cnt, double cx,
+                                   double cy, double cz, double half, int d, const double *coef, int64_t coef_stride,
+                                   int kb, int tid, int nthreads) {
+    for (int j = tid; j < cnt; j += nthreads) {
+        const int I = j0 + j;
+        const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1);
+        const double x = cx + half * chp->nodes[i0];
+        const double y = d > 1 ? cy + half * chp->nodes[i1] : 0.0;
+        const double z = d > 2 ? cz + half * chp->nodes[i2] : 0.0;
+        tile.xy[j] = make_double2(x, y);
+        tile.zs[j] = z;
+#pragma unroll
+        for (int kk = 0; kk < DIRECT_KB; ++kk) tile.w[kk][j] = (kk < kb && coef) ? coef[kk * coef_stride + I] : 0.0;
+    }
+}
+
+// multipole_to_particle (bbfmm.rs:1254-1355).  One workgroup per target leaf with a W list.
+template <int KID, bool GRAD, int KB>
+__global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *__restrict__ chp,
+                                                  const int32_t *__restrict__ job_cell,
+                                                  const int32_t *__restrict__ tgt_begin,
+                                                  const int32_t *__restrict__ tgt_end,
+                                                  const int64_t *__restrict__ w_ptr,
+                                                  const int32_t *__restrict__ w_cells,
+                                                  const double *__restrict__ centers,
+                                                  const double *__restrict__ lengths, Xyz tgt, int64_t n_tgt, int k0,
+                                                  int kb, int64_t C, const double *__restrict__ M,
+                                                  double *__restrict__ out, double *__restrict__ grad) {
+    __shared__ SrcTile tile;
+    __shared__ double red[256];
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    const int tid = threadIdx.x;
+    const int job = blockIdx.x;
+    const int t0 = tgt_begin[job], t1 = tgt_end[job];
+    const int jcell = job_cell[job];
+    const int64_t r0 = w_ptr[jcell], r1 = w_ptr[jcell + 1];
+    for (int tc = t0; tc < t1; tc += 256) {
+        const int nt = min(256, t1 - tc);
+        const int S = 256 / nt;
+        const int ti = tid % nt, sl = tid / nt;
+        const bool part = sl < S;
+        double tx = 0, ty = 0, tz = 0;
+        if (part) {
+            tx = tgt.x[tc + ti];
+            ty = tgt.y[tc + ti];
+            tz = tgt.z[tc + ti];
+        }
+        double acc[KB], gacc[KB][3];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) acc[kk] = gacc[kk][0] = gacc[kk][1] = gacc[kk][2] = 0.0;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int wc = w_cells[r];
+            const double half = lengths[wc] * 0.5;
+            const double cx = centers[wc * 3], cy = centers[wc * 3 + 1], cz = centers[wc * 3 + 2];
+            const double *coef = M + ((int64_t)k0 * C + wc) * n_pad;
+            for (int j0 = 0; j0 < n; j0 += DIRECT_TILE) {
+                const int cnt = min(DIRECT_TILE, n - j0);
+                __syncthreads();
+                stage_nodes(tile, chp, P1, P2, j0, cnt, cx, cy, cz, half, d, coef, C * n_pad, kb, tid, 256);
+                __syncthreads();
+                if (part) direct_tile<KID, GRAD, KB>(ks, tile, cnt, sl, S, tx, ty, tz, acc, gacc);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            if (kk >= kb) break;
+            const double v = slice_reduce(acc[kk], red, ti, sl, S, nt, part);
+            if (part && sl == 0) out[(int64_t)(k0 + kk) * n_tgt + tc + ti] += v;
+            if (GRAD) {
+                for (int a = 0; a < d; ++a) {
+                    const double g = slice_reduce(gacc[kk][a], red, ti, sl, S, nt, part);
+                    if (part && sl == 0) grad[((int64_t)(k0 + kk) * d + a) * n_tgt + tc + ti] += g;
+                }
+            }
+        }
+    }
+}
+
+// particle_to_local (bbfmm.rs:1001-1048).  One workgroup per cell with an X list; the
+// targets are the cell's Chebyshev nodes.
+template <int KID, int KB>
+__global__ __launch_bounds__(256) void p2l_kernel(KernelSpec ks, const DevCheb *__restrict__ chp,
+                                                  const int32_t *__restrict__ cells,
+                                                  const int64_t *__restrict__ run_ptr,
+                                                  const int32_t *__restrict__ runs,
+                                                  const double *__restrict__ centers,
+                                                  const double *__restrict__ lengths, Xyz src,
+                                                  const double *__restrict__ ws, int64_t N, int k0, int kb, int64_t C,
+                                                  double *__restrict__ L) {
+    __shared__ SrcTile tile;
+    __shared__ double red[256];
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    const int tid = threadIdx.x;
+    const int job = blockIdx.x;
+    const int cell = cells[job];
+    const double half = lengths[cell] * 0.5;
+    const double cx = centers[cell * 3], cy = centers[cell * 3 + 1], cz = centers[cell * 3 + 2];
+    const int64_t r0 = run_ptr[job], r1 = run_ptr[job + 1];
+    for (int tc = 0; tc < n; tc += 256) {
+        const int nt = min(256, n - tc);
+        const int S = 256 / nt;
+        const int ti = tid % nt, sl = tid / nt;
+        const bool part = sl < S;
+        double tx = 0, ty = 0, tz = 0;
+        if (part) {
+            const int I = tc + ti;
+            const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1);
+            tx = cx + half * chp->nodes[i0];
+            ty = d > 1 ? cy + half * chp->nodes[i1] : 0.0;
+            tz = d > 2 ? cz + half * chp->nodes[i2] : 0.0;
+        }
+        double acc[KB], gacc[KB][3];
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) acc[kk] = 0.0;
+        for (int64_t r = r0; r < r1; ++r) {
+            const int sb = runs[2 * r], se = runs[2 * r + 1];
+            for (int base = sb; base < se; base += DIRECT_TILE) {
+                const int cnt = min(DIRECT_TILE, se - base);
+                __syncthreads();
+                for (int j = tid; j < cnt; j += 256) {
+                    tile.xy[j] = make_double2(src.x[base + j], src.y[base + j]);
+                    tile.zs[j] = src.z[base + j];
+#pragma unroll
+                    for (int kk = 0; kk < KB; ++kk)
+                        tile.w[kk][j] = kk < kb ? ws[(int64_t)(k0 + kk) * N + base + j] : 0.0;
+                }
+                __syncthreads();
+                if (part) direct_tile<KID, false, KB>(ks, tile, cnt, sl, S, tx, ty, tz, acc, gacc);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < KB; ++kk) {
+            if (kk >= kb) break;
+            const double v = slice_reduce(acc[kk], red, ti, sl, S, nt, part);
+            if (part && sl == 0) L[((int64_t)(k0 + kk) * C + cell) * n_pad + tc + ti] += v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ M2L (MFMA FP64)
+// multipole_to_local (bbfmm.rs:864-986) regrouped for the matrix cores.  The reference
+// permutes each V cell's multipoles onto one of 16 reference operators, multiplies by
+// Vt then U, and permutes back.  Here the permutations are folded into per-transfer-
+// vector operators stacked per octant class (host side, fmm_tree.cpp), which turns the
+// whole level into two dense streamed-operator GEMMs with no data permutation:
+//   stage 1:  Cbuf[target(V,t)][(t,kk)] = sum_m VtAll[(t,kk)][m] * M_V[m]   (X-stationary)
+//   stage 2:  L_B[i]                    = sum_k UAll[i][k] * Cbuf[B][k]     (accumulator-stationary)
+// v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
+// D[i = (lane>>4) + 4*reg][j = lane&15].
+//
+// The K index inside a block of 16 is permuted (k = 16q + 4g + s for k-step 4q+s, g =
+// lane>>4) so that every lane fetches its four A values of a block with one 32-byte load.
+
+// Stage 1.  Workgroup = 4 waves = 64 source cells of one (level, class).  NKS = k-steps
+// (of 4) held in registers per launch chunk; LDS holds one 16-row tile of the stacked
+// operator in MFMA-fragment order.
+template <int NKS, int MINW>
+__global__ __launch_bounds__(256, MINW) void m2l_stage1_kernel(const M2lClass *__restrict__ classes,
+                                                              const M2lTileDesc *__restrict__ tiles, int n_pad,
+                                                              int ks0, int nks, int accumulate, int64_t C,
+                                                              const double *__restrict__ M,
+                                                              double *__restrict__ cbuf, int64_t cbuf_len) {
+    extern __shared__ double lds[]; // nks * 64 doubles
+    const M2lTileDesc tile = tiles[blockIdx.x];
+    const M2lClass cls = classes[tile.level_class];
+    const int k = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col16 = lane & 15, g = lane >> 4;
+
+    const int mypos = wave * 16 + col16;
+    const bool valid = mypos < tile.count;
+    const int cell = valid ? cls.cells[tile.first + mypos] : 0;
+    const double *Mc = M + ((int64_t)k * C + cell) * n_pad + (int64_t)ks0 * 4 + 4 * g;
+
+    double a[NKS];
+#pragma unroll
+    for (int q = 0; q < NKS / 4; ++q) {
+        if (4 * q < nks && valid) {
+            const double2 v0 = *reinterpret_cast<const double2 *>(Mc + 16 * q);
+            const double2 v1 = *reinterpret_cast<const double2 *>(Mc + 16 * q + 2);
+            a[4 * q + 0] = v0.x;
+            a[4 * q + 1] = v0.y;
+            a[4 * q + 2] = v1.x;
+            a[4 * q + 3] = v1.y;
+        } else {
+            a[4 * q + 0] = a[4 * q + 1] = a[4 * q + 2] = a[4 * q + 3] = 0.0;
+        }
+    }
+
+    double *cb = cbuf + (int64_t)k * cbuf_len;
+    const int n_ntiles = cls.r_pad16 / 16;
+    const int rows = nks * 4;
+    for (int jt = 0; jt < n_ntiles; ++jt) {
+        __syncthreads();
+        // stage VtAll[m][16 jt .. 16 jt + 16) for the chunk's m range, fragment order
+        for (int e = tid; e < rows * 8; e += 256) {
+            const int ml = e >> 3, j2 = (e & 7) * 2;
+            const double2 v =
+                *reinterpret_cast<const double2 *>(cls.vt_all + (int64_t)(ks0 * 4 + ml) * cls.r_pad16 + 16 * jt + j2);
+            const int q = ml >> 4, gg = (ml >> 2) & 3, s = ml & 3;
+            *reinterpret_cast<double2 *>(lds + (4 * q + s) * 64 + gg * 16 + j2) = v;
+        }
+        __syncthreads();
+        v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ks += 2) {
+            if (ks < nks) {
+                const double b0 = lds[ks * 64 + lane];
+                const double b1 = lds[(ks + 1) * 64 + lane];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks + 1], b1, acc1, 0, 0, 0);
+            }
+        }
+        const v4f64 acc = acc0 + acc1;
+        // epilogue: column = tall row 16 jt + col16, rows = source cells g + 4 reg
+        const int j = 16 * jt + col16;
+        const int tpos = cls.row_tpos[j];
+        if (tpos >= 0) {
+            const int off = cls.row_off[j];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int sp = wave * 16 + g + 4 * reg;
+                if (sp < tile.count) {
+                    const int slot = cls.cslot[(int64_t)(tile.first + sp) * cls.n_t + tpos];
+                    if (slot >= 0) {
+                        double *dst = cb + (int64_t)slot * 4 + off;
+                        if (accumulate)
+                            *dst += acc[reg];
+                        else
+                            *dst = acc[reg];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// Stage 2.  Workgroup = 4 waves = 64 target cells of one (level, class); every wave keeps
+// NT 16x16 accumulator tiles (its 16 targets x 16*NT output nodes) in registers and streams
+// the stacked operator UAll through LDS in blocks of 16 k.
+template <int NT, int MINW>
+__global__ __launch_bounds__(256, MINW) void m2l_stage2_kernel(const M2lClass *__restrict__ classes,
+                                                              const M2lTileDesc *__restrict__ tiles, int n_pad,
+                                                              int jt0, int nt, int64_t C,
+                                                              const double *__restrict__ cbuf, int64_t cbuf_len,
+                                                              double *__restrict__ L) {
+    extern __shared__ double lds[]; // 4 * nt * 64 doubles
+    const M2lTileDesc tile = tiles[blockIdx.x];
+    const M2lClass cls = classes[tile.level_class];
+    const int k = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col16 = lane & 15, g = lane >> 4;
+
+    const int mypos = wave * 16 + col16;
+    const bool valid = mypos < tile.count;
+    const int64_t cbase = valid ? cls.cbase[tile.first + mypos] : 0;
+    const double *Cp = cbuf + (int64_t)k * cbuf_len + cbase + 4 * g;
+
+    v4f64 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+
+    const int nq = cls.k_pad / 16;
+    const int width = nt * 16; // output nodes handled by this launch chunk
+    for (int q = 0; q < nq; ++q) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (valid) {
+            const double2 v0 = *reinterpret_cast<const double2 *>(Cp + 16 * q);
+            const double2 v1 = *reinterpret_cast<const double2 *>(Cp + 16 * q + 2);
+            a0 = v0.x;
+            a1 = v0.y;
+            a2 = v1.x;
+            a3 = v1.y;
+        }
+        __syncthreads();
+        // stage UAll rows [16q, 16q+16) x [16 jt0, 16 jt0 + width) in fragment order
+        for (int e = tid; e < 16 * (width / 2); e += 256) {
+            const int kl = e / (width / 2), c2 = (e % (width / 2)) * 2;
+            const double2 v =
+                *reinterpret_cast<const double2 *>(cls.u_all + (int64_t)(16 * q + kl) * n_pad + 16 * jt0 + c2);
+            const int gg = kl >> 2, s = kl & 3, jt = c2 >> 4, jj = c2 & 15;
+            *reinterpret_cast<double2 *>(lds + (s * nt + jt) * 64 + gg * 16 + jj) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t < nt) {
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, lds[(0 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, lds[(1 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, lds[(2 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, lds[(3 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: rows = targets g + 4 reg, column = node 16 (jt0 + t) + col16
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        const int tp = wave * 16 + g + 4 * reg;
+        if (tp < tile.count) {
+            const int cell = cls.cells[tile.first + tp];
+            double *Lc = L + ((int64_t)k * C + cell) * n_pad + 16 * jt0 + col16;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                if (t < nt) Lc[16 * t] = acc[t][reg];
+        }
+    }
+}
+
+// ------------------------------------------------------------------ launch helpers
+static Xyz make_xyz(const double *const *p) { return Xyz{p[0], p[1], p[2]}; }
+
+void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w_sorted, int64_t N, int K, int64_t C,
+                const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin, const int32_t *pt_end,
+                const double *centers, const double *lengths, double *M, hipStream_t s) {
+    if (n_leaves == 0) return;
+    hipLaunchKernelGGL(p2m_kernel, dim3(n_leaves), dim3(256), 0, s, ch.dev, make_xyz(src_xyz), w_sorted, N, K, C,
+                       leaf_cells, pt_begin, pt_end, centers, lengths, M);
+}
+
+void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents, const int64_t *child_ptr,
+                const int32_t *child_idx, const int32_t *octant, double *M, hipStream_t s) {
+    if (n_parents == 0) return;
+    const size_t lds = sizeof(double) * (3 * (size_t)ch.n + 2 * ch.p * ch.p);
+    hipLaunchKernelGGL(m2m_kernel, dim3(n_parents), dim3(256), lds, s, ch.dev, K, C, parents, child_ptr, child_idx,
+                       octant, M);
+}
+
+void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_cells, const int32_t *parent,
+                const int32_t *octant, const uint8_t *active, double *L, hipStream_t s) {
+    if (n_cells == 0) return;
+    const size_t lds = sizeof(double) * (2 * (size_t)ch.n + 2 * ch.p * ch.p);
+    hipLaunchKernelGGL(l2l_kernel, dim3(n_cells), dim3(256), lds, s, ch.dev, K, C, cells, parent, octant, active, L);
+}
+
+void launch_l2p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const int32_t *tgt_begin,
+                const int32_t *tgt_end, const double *centers, const double *lengths, const double *const *tgt_xyz,
+                int64_t n_tgt, int K, int64_t C, const double *L, double *out_sorted, double *grad_sorted,
+                hipStream_t s) {
+    if (n_jobs == 0) return;
+    const size_t lds =
+        sizeof(double) * (kMaxOrder * kMaxOrder + (size_t)ch.n + 2 * 3 * (size_t)ch.p * L2P_THREADS);
+    if (grad_sorted)
+        hipLaunchKernelGGL(l2p_kernel<true>, dim3(n_jobs), dim3(L2P_THREADS), lds, s, ch.dev, leaf_cells, tgt_begin,
+                           tgt_end, centers, lengths, make_xyz(tgt_xyz), n_tgt, K, C, L, out_sorted, grad_sorted);
+    else
+        hipLaunchKernelGGL(l2p_kernel<false>, dim3(n_jobs), dim3(L2P_THREADS), lds, s, ch.dev, leaf_cells, tgt_begin,
+                           tgt_end, centers, lengths, make_xyz(tgt_xyz), n_tgt, K, C, L, out_sorted, grad_sorted);
+}
+
+// Kernel-id dispatch: F is a generic lambda taking std::integral_constant<int, ID>.
+template <class F> static void dispatch_kernel_id(int id, F &&f) {
+    switch (id) {
+    case kLinear: f(std::integral_constant<int, kLinear>{}); break;
+    case kThinPlateSpline: f(std::integral_constant<int, kThinPlateSpline>{}); break;
+    case kCubic: f(std::integral_constant<int, kCubic>{}); break;
+    case kSpheroidal3: f(std::integral_constant<int, kSpheroidal3>{}); break;
+    case kSpheroidal5: f(std::integral_constant<int, kSpheroidal5>{}); break;
+    case kSpheroidal7: f(std::integral_constant<int, kSpheroidal7>{}); break;
+    case kSpheroidal9: f(std::integral_constant<int, kSpheroidal9>{}); break;
+    case kLaplacian: f(std::integral_constant<int, kLaplacian>{}); break;
+    case kOneOverR2: f(std::integral_constant<int, kOneOverR2>{}); break;
+    case kOneOverR4: f(std::integral_constant<int, kOneOverR4>{}); break;
+    case kGaussianExt: f(std::integral_constant<int, kGaussianExt>{}); break;
+    case kMultiquadricExt: f(std::integral_constant<int, kMultiquadricExt>{}); break;
+    default: break;
+    }
+}
+
+void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const double *const *tgt_xyz, int64_t n_tgt,
+                const double *const *src_xyz, const double *w_sorted, int64_t N, int K, double *out_sorted,
+                double *grad_sorted, hipStream_t s) {
+    if (jobs.n_jobs == 0) return;
+    dispatch_kernel_id(ks.id, [&](auto idc) {
+        constexpr int ID = decltype(idc)::value;
+        for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
+            const int kb = std::min(DIRECT_KB, K - k0);
+            if (grad_sorted) {
+                hipLaunchKernelGGL((p2p_kernel<ID, true, DIRECT_KB>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d, jobs,
+                                   make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted,
+                                   grad_sorted);
+            } else if (kb == 1) {
+                hipLaunchKernelGGL((p2p_kernel<ID, false, 1>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d, jobs,
+                                   make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted,
+                                   grad_sorted);
+            } else {
+                hipLaunchKernelGGL((p2p_kernel<ID, false, DIRECT_KB>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d,
+                                   jobs, make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb,
+                                   out_sorted, grad_sorted);
+            }
+        }
+    });
+}
+
+void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *job_cell,
+                const int32_t *tgt_begin, const int32_t *tgt_end, const int64_t *w_ptr,
+                const int32_t *w_cells, const double *centers,
+                const double *lengths, const double *const *tgt_xyz, int64_t n_tgt, int K, int64_t C,
+                const double *M, double *out_sorted, double *grad_sorted, hipStream_t s) {
+    if (n_jobs == 0) return;
+    dispatch_kernel_id(ks.id, [&](auto idc) {
+        constexpr int ID = decltype(idc)::value;
+        for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
+            const int kb = std::min(DIRECT_KB, K - k0);
+            if (grad_sorted)
+                hipLaunchKernelGGL((m2p_kernel<ID, true, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev,
+                                   job_cell, tgt_begin, tgt_end, w_ptr, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
+                                   kb, C, M, out_sorted, grad_sorted);
+            else
+                hipLaunchKernelGGL((m2p_kernel<ID, false, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev,
+                                   job_cell, tgt_begin, tgt_end, w_ptr, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
+                                   kb, C, M, out_sorted, grad_sorted);
+        }
+    });
+}
+
+void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *cells, const int64_t *run_ptr,
+                const int32_t *runs, const double *centers, const double *lengths, const double *const *src_xyz,
+                const double *w_sorted, int64_t N, int K, int64_t C, double *L, hipStream_t s) {
+    if (n_jobs == 0) return;
+    dispatch_kernel_id(ks.id, [&](auto idc) {
+        constexpr int ID = decltype(idc)::value;
+        for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
+            const int kb = std::min(DIRECT_KB, K - k0);
+            hipLaunchKernelGGL((p2l_kernel<ID, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev, cells, run_ptr,
+                               runs, centers, lengths, make_xyz(src_xyz), w_sorted, N, k0, kb, C, L);
+        }
+    });
+}
+
+// Stage-1 instantiations: k-steps held in registers per launch chunk.
+template <int NKS, int MINW>
+static void stage1_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int ks0, int nks,
+                          int accumulate, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
+                          hipStream_t s) {
+    const size_t lds = sizeof(double) * 64 * (size_t)nks;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage1_kernel<NKS, MINW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((m2l_stage1_kernel<NKS, MINW>), dim3(n_tiles, K), dim3(256), lds, s, classes, tiles, n_pad,
+                       ks0, nks, accumulate, C, M, cbuf, cbuf_len);
+}
+
+void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
+                       const double *M, double *cbuf, int64_t cbuf_len, hipStream_t s) {
+    if (n_tiles == 0) return;
+    const int total = n_pad / 4; // k-steps
+    // chunk size: the smallest instantiation that covers the rest, at most 184 per launch
+    int done = 0;
+    while (done < total) {
+        const int left = total - done;
+        const int acc = done > 0 ? 1 : 0;
+        if (left <= 16) { stage1_launch<16, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
+        else if (left <= 32) { stage1_launch<32, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
+        else if (left <= 64) { stage1_launch<64, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
+        else if (left <= 88) { stage1_launch<88, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
+        else if (left <= 128) { stage1_launch<128, 1>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
+        else { const int take = std::min(left, 184); stage1_launch<184, 1>(classes, tiles, n_tiles, n_pad, done, take, acc, K, C, M, cbuf, cbuf_len, s); done += take; }
+    }
+}
+
+template <int NT, int MINW>
+static void stage2_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int jt0, int nt,
+                          int K, int64_t C, const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
+    const size_t lds = sizeof(double) * 64 * 4 * (size_t)nt;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage2_kernel<NT, MINW>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((m2l_stage2_kernel<NT, MINW>), dim3(n_tiles, K), dim3(256), lds, s, classes, tiles, n_pad, jt0,
+                       nt, C, cbuf, cbuf_len, L);
+}
+
+void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
+                       const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
+    if (n_tiles == 0) return;
+    const int total = n_pad / 16; // 16-node output tiles
+    int done = 0;
+    while (done < total) {
+        const int left = total - done;
+        if (left <= 4) { stage2_launch<4, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
+        else if (left <= 8) { stage2_launch<8, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
+        else if (left <= 16) { stage2_launch<16, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
+        else if (left <= 22) { stage2_launch<22, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
+        else if (left <= 32) { stage2_launch<32, 1>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
+        else { const int take = std::min(left, 46); stage2_launch<46, 1>(classes, tiles, n_tiles, n_pad, done, take, K, C, cbuf, cbuf_len, L, s); done += take; }
+    }
+}
+
+// ------------------------------------------------------------------ MFMA self test
+__global__ void mfma_layout_kernel(const double *A, const double *B, double *D) {
+    // A: 16x4 row-major, B: 4x16 row-major, D: 16x16 row-major
+    const int lane = threadIdx.x & 63;
+    const double a = A[(lane & 15) * 4 + (lane >> 4)];
+    const double b = B[(lane >> 4) * 16 + (lane & 15)];
+    v4f64 c = {0.0, 0.0, 0.0, 0.0};
+    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+    for (int reg = 0; reg < 4; ++reg) D[((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = c[reg];
+}
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters) {
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+    v4f64 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    for (int i = 0; i < iters; ++i) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+    }
+    const v4f64 c = c0 + c1 + c2 + c3;
+    if (c[0] == 12345.678) sink[0] = c[1] + c[2] + c[3];
+}
+
+int mfma_f64_selftest(double *tflops, int *layout_errors) {
+    double hA[64], hB[64], hD[256], ref[256];
+    for (int i = 0; i < 16; ++i)
+        for (int k = 0; k < 4; ++k) hA[i * 4 + k] = (double)(1 + i * 5 + k * 3);
+    for (int k = 0; k < 4; ++k)
+        for (int j = 0; j < 16; ++j) hB[k * 16 + j] = (double)(2 + k * 7 + j * j); // asymmetric
+    for (int i = 0; i < 16; ++i)
+        for (int j = 0; j < 16; ++j) {
+            double s = 0;
+            for (int k = 0; k < 4; ++k) s += hA[i * 4 + k] * hB[k * 16 + j];
+            ref[i * 16 + j] = s;
+        }
+    double *dA = nullptr, *dB = nullptr, *dD = nullptr;
+    if (hipMalloc(&dA, sizeof hA) != hipSuccess) return 1;
+    if (hipMalloc(&dB, sizeof hB) != hipSuccess) return 1;
+    if (hipMalloc(&dD, sizeof hD) != hipSuccess) return 1;
+    hipMemcpy(dA, hA, sizeof hA, hipMemcpyHostToDevice);
+    hipMemcpy(dB, hB, sizeof hB, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+    if (hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+    int errs = 0;
+    for (int i = 0; i < 256; ++i)
+        if (hD[i] != ref[i]) ++errs;
+    *layout_errors = errs;
+    // peak: 256 CUs x 8 blocks x 4 waves, 4 independent accumulators per wave
+    const int iters = 4096, blocks = 2048;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, dD, 16); // warm-up
+    hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, dD, iters);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 4.0 * iters * 4.0 * (2.0 * 16 * 16 * 4);
+    *tflops = flops / (ms * 1e-3) / 1e12;
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    hipFree(dA);
+    hipFree(dB);
+    hipFree(dD);
+    return 0;
+}
+
+} // namespace bbfmm

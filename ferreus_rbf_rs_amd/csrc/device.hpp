@@ -1,0 +1,124 @@
+// Device-side data structures and kernel launchers (implemented in device.hip).
+//
+// HBM layout (all f64 unless noted; "sorted" = hierarchical Morton order in which
+// every tree cell owns a contiguous range of points):
+//   src_xyz      d arrays of N sorted source coordinates (SoA -> coalesced loads)
+//   w_sorted     K x N   sorted weights, rhs-major
+//   M, L         K x C x n_pad   multipole / local coefficients, cell-major,
+//                n_pad = n rounded up to 16 (rows >= n stay zero) so that one
+//                cell's column is a whole number of 128-B lines and of MFMA tiles
+//   cbuf         K x cbuf_len   compressed M2L intermediates c = Vt * M (per target,
+//                per transfer vector; see M2lLevel)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "kernels.hpp"
+
+namespace bbfmm {
+
+constexpr int kMaxOrder = 16;      // Chebyshev nodes per axis supported on device
+constexpr int kM2lTile = 64;       // cells (GEMM columns) per M2L workgroup: 4 waves x 16
+
+struct DevCheb { // lives in device memory; kernels take a pointer
+    int p, d, n, n_pad;
+    double polyn[kMaxOrder * kMaxOrder]; // T_k(node_j), row j
+    double nodes[kMaxOrder];
+    double xfer[2 * kMaxOrder * kMaxOrder]; // [side][child node a][parent node i]
+};
+
+struct ChebRef { // device pointer + the host copies the launchers size their grids with
+    const DevCheb *dev;
+    int p, d, n, n_pad;
+};
+
+// One tree level of M2L work (levels 2..depth).  Cells of the level are grouped by
+// octant class o (position inside the parent); all cells of a class share the set
+// of admissible transfer vectors t, hence one stacked ("tall") operator per class.
+struct M2lClass {
+    // stage 1 (source side): c[(t,kk)] = sum_m VtAllT[m][row] * M_V[m]
+    const double *vt_all;   // n_pad x r_pad16 (row m contiguous over tall rows)
+    const int32_t *row_tpos; // r_pad16: position of the row's transfer vector in the class list (or -1)
+    const int32_t *row_off;  // r_pad16: offset of the row inside the target's slot (= off_target_class[t] + kk)
+    int32_t n_rows;          // exact number of tall rows
+    int32_t r_pad16;
+    int32_t n_t;             // number of transfer vectors of this class (189 in 3-D)
+    // stage 2 (target side): L_B[i] = sum_k UAllT[k][i] * ccat_B[k]
+    const double *u_all;     // k_pad x n_pad
+    int32_t k_pad;           // slot length of a target of this class (multiple of 16)
+    // cells of this class at this level
+    const int32_t *cells;    // cell indices
+    int32_t n_cells;
+    const int32_t *cslot;    // n_cells x n_t: slot base (units of 4 doubles) of target V+t, -1 if absent
+    const int64_t *cbase;    // n_cells: slot base of the cell itself as a target (units of doubles)
+};
+
+struct M2lTileDesc { // one workgroup of stage 1 or stage 2
+    int32_t level_class; // index into the M2lClass table
+    int32_t first;       // first cell (position inside the class list)
+    int32_t count;       // <= kM2lTile
+    int32_t pad;
+};
+
+// ---- launchers (all asynchronous on `s`) ----
+void launch_gather_weights(const double *w, int64_t ldw, int K, const int32_t *order, int64_t N,
+                           double *w_sorted, hipStream_t s);
+void launch_scatter_output(const double *out_sorted, int64_t n, int K, const int32_t *perm,
+                           double *out, int64_t ldo, int accumulate, hipStream_t s);
+void launch_gather_rows(const double *src, int64_t ld_src, int ncols, const int32_t *idx, int64_t n,
+                        double *dst, int64_t ld_dst, hipStream_t s);
+
+void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w_sorted, int64_t N,
+                int K, int64_t C, const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin,
+                const int32_t *pt_end, const double *centers, const double *lengths, double *M,
+                hipStream_t s);
+void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents,
+                const int64_t *child_ptr, const int32_t *child_idx, const int32_t *octant, double *M,
+                hipStream_t s);
+void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_cells,
+                const int32_t *parent, const int32_t *octant, const uint8_t *active, double *L,
+                hipStream_t s);
+
+void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
+                       int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
+                       hipStream_t s);
+void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
+                       int K, int64_t C, const double *cbuf, int64_t cbuf_len, double *L,
+                       hipStream_t s);
+
+// Direct (kernel-evaluating) interactions.  Targets are sorted by leaf; job i handles
+// the targets [tgt_begin[i], tgt_end[i]) of leaf job_cell[i] against the source runs
+// runs[run_ptr[cell] .. run_ptr[cell+1]) (pairs of [begin, end) into the sorted sources;
+// adjacent U-list leaves are merged into one run on the host).
+struct DirectJobs {
+    int n_jobs;
+    const int32_t *job_cell;
+    const int32_t *tgt_begin, *tgt_end;
+    const int64_t *run_ptr; // per cell
+    const int32_t *runs;    // 2 ints per run
+};
+void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const double *const *tgt_xyz,
+                int64_t n_tgt, const double *const *src_xyz, const double *w_sorted, int64_t N, int K,
+                double *out_sorted, double *grad_sorted, hipStream_t s);
+// M2P: sources are the Chebyshev nodes of the W-list cells, weights their multipoles.
+void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *job_cell,
+                const int32_t *tgt_begin, const int32_t *tgt_end, const int64_t *w_ptr,
+                const int32_t *w_cells,
+                const double *centers, const double *lengths, const double *const *tgt_xyz,
+                int64_t n_tgt, int K, int64_t C, const double *M, double *out_sorted,
+                double *grad_sorted, hipStream_t s);
+// P2L: targets are the Chebyshev nodes of the cell, sources the points of the X-list leaves.
+void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *cells,
+                const int64_t *run_ptr, const int32_t *runs, const double *centers,
+                const double *lengths, const double *const *src_xyz, const double *w_sorted,
+                int64_t N, int K, int64_t C, double *L, hipStream_t s);
+void launch_l2p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const int32_t *tgt_begin,
+                const int32_t *tgt_end, const double *centers, const double *lengths,
+                const double *const *tgt_xyz, int64_t n_tgt, int K, int64_t C, const double *L,
+                double *out_sorted, double *grad_sorted, hipStream_t s);
+
+// FP64 MFMA lane-layout check + peak microbenchmark.
+int mfma_f64_selftest(double *tflops, int *layout_errors);
+
+} // namespace bbfmm

@@ -1,0 +1,1071 @@
+// FmmTree host orchestration.  See fmm_tree.hpp.
+#include "fmm_tree.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+
+#include "morton.hpp"
+#include "parallel.hpp"
+
+namespace bbfmm {
+
+#define HIPCHK(expr)                                              \
+    do {                                                          \
+        hipError_t e__ = (expr);                                  \
+        if (e__ != hipSuccess) return hip_fail(e__, #expr);       \
+    } while (0)
+#define CHK(expr)                                                 \
+    do {                                                          \
+        int rc__ = (expr);                                        \
+        if (rc__ != BBFMM_OK) return rc__;                        \
+    } while (0)
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+namespace {
+struct StageTimer { // BBFMM_VERBOSE=1 prints host setup stage times to stderr
+    bool on = std::getenv("BBFMM_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm] %-28s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+} // namespace
+
+int FmmTree::fail(int code, const std::string &msg) {
+    err_ = msg;
+    return code;
+}
+int FmmTree::hip_fail(hipError_t e, const char *what) {
+    err_ = std::string("HIP error: ") + hipGetErrorString(e) + " in " + what;
+    return BBFMM_DEVICE_ERROR;
+}
+
+template <class T> int FmmTree::dalloc(DevBuf<T> *b, size_t n, bool zero) {
+    b->n = n;
+    b->p = nullptr;
+    if (n == 0) n = 1;
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, n * sizeof(T)));
+    owned_.push_back(p);
+    b->p = static_cast<T *>(p);
+    if (zero) HIPCHK(hipMemsetAsync(p, 0, n * sizeof(T), stream_));
+    return BBFMM_OK;
+}
+template <class T> int FmmTree::dupload(DevBuf<T> *b, const std::vector<T> &v) {
+    CHK(dalloc(b, v.size()));
+    if (!v.empty()) HIPCHK(hipMemcpy(b->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BBFMM_OK;
+}
+template <class T> void FmmTree::dfree(DevBuf<T> *b) {
+    if (b->p) {
+        auto it = std::find(owned_.begin(), owned_.end(), static_cast<void *>(b->p));
+        if (it != owned_.end()) owned_.erase(it);
+        (void)hipFree(b->p);
+    }
+    b->p = nullptr;
+    b->n = 0;
+}
+
+FmmTree::~FmmTree() {
+    if (!host_only_ && stream_) (void)hipStreamSynchronize(stream_);
+    for (void *p : owned_) (void)hipFree(p);
+    owned_.clear();
+    if (ev_[0]) (void)hipEventDestroy(ev_[0]);
+    if (ev_[1]) (void)hipEventDestroy(ev_[1]);
+    if (stream_) (void)hipStreamDestroy(stream_);
+}
+
+void FmmTree::phase_begin() {
+    if (profiling_) (void)hipEventRecord(ev_[0], stream_);
+}
+void FmmTree::phase_end(int ph) {
+    if (!profiling_) return;
+    (void)hipEventRecord(ev_[1], stream_);
+    (void)hipEventSynchronize(ev_[1]);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, ev_[0], ev_[1]);
+    phase_ms_[ph] += ms;
+}
+
+// Merge the point ranges of `cells` (those that hold points) into sorted runs.
+static void merged_runs(const HostTree &t, const int32_t *cells, int64_t count, std::vector<int32_t> *runs) {
+    std::vector<std::pair<int64_t, int64_t>> r;
+    for (int64_t i = 0; i < count; ++i) {
+        const int32_t c = cells[i];
+        if (t.pt_end[c] > t.pt_begin[c]) r.emplace_back(t.pt_begin[c], t.pt_end[c]);
+    }
+    std::sort(r.begin(), r.end());
+    size_t i = 0;
+    while (i < r.size()) {
+        int64_t b = r[i].first, e = r[i].second;
+        size_t j = i + 1;
+        while (j < r.size() && r[j].first == e) {
+            e = r[j].second;
+            ++j;
+        }
+        runs->push_back(static_cast<int32_t>(b));
+        runs->push_back(static_cast<int32_t>(e));
+        i = j;
+    }
+}
+
+int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, int kernel_type, double base_range,
+                    double total_sill, bool adaptive, bool sparse, const double *extents,
+                    const bbfmm_params *params, uint32_t flags) {
+    if (d < 1 || d > 3) // bbfmm.rs:293-298
+        return fail(BBFMM_BAD_ARGUMENT, "Unsupported number of dimensions: " + std::to_string(d));
+    if (!pts || n < 1 || ld < n) return fail(BBFMM_BAD_ARGUMENT, "source_points must hold at least one row");
+    if (n >= (int64_t(1) << 31)) return fail(BBFMM_BAD_ARGUMENT, "more than 2^31-1 source points");
+    if (!kernel_id_valid(kernel_type)) return fail(BBFMM_BAD_ARGUMENT, "unknown kernel_type");
+    if (order < 2 || order > kMaxOrder)
+        return fail(BBFMM_BAD_ARGUMENT, "interpolation_order must be in [2, " + std::to_string(kMaxOrder) + "]");
+    if (!(base_range > 0.0)) return fail(BBFMM_BAD_ARGUMENT, "base_range must be positive"); // kernel_helpers.rs:69
+    host_only_ = (flags & BBFMM_FLAG_HOST_ONLY) != 0;
+    order_ = order;
+    d_ = d;
+    kernel_ = make_kernel_spec(kernel_type, base_range, total_sill);
+    if (params)
+        params_ = *params;
+    else
+        bbfmm_params_defaults(order, &params_);
+    if (params_.max_points_per_cell < 1) return fail(BBFMM_BAD_ARGUMENT, "max_points_per_cell must be >= 1");
+    if (params_.compression_type < 0 || params_.compression_type > 2)
+        return fail(BBFMM_BAD_ARGUMENT, "unknown compression_type");
+
+    pts_.resize(static_cast<size_t>(n) * d);
+    for (int a = 0; a < d; ++a) std::copy(pts + a * ld, pts + a * ld + n, pts_.begin() + static_cast<size_t>(a) * n);
+
+    double ext[6];
+    if (extents) {
+        std::copy(extents, extents + 2 * d, ext);
+    } else { // utils.rs:13-46
+        for (int a = 0; a < d; ++a) {
+            const double *col = &pts_[static_cast<size_t>(a) * n];
+            double lo = col[0], hi = col[0];
+            for (int64_t i = 1; i < n; ++i) {
+                if (col[i] < lo) lo = col[i];
+                if (col[i] > hi) hi = col[i];
+            }
+            ext[a] = lo;
+            ext[d + a] = hi;
+        }
+    }
+    double center[3] = {0, 0, 0}, radius = 0;
+    calculate_tree_center_and_radius(ext, d, center, &radius);
+    if (!(radius > 0.0) || !std::isfinite(radius)) return fail(BBFMM_BAD_ARGUMENT, "degenerate or non-finite extents");
+
+    StageTimer timer;
+    build_tree(pts_.data(), n, n, d, center, radius, params_.max_points_per_cell, !sparse, adaptive, &tree_);
+    timer.lap("tree + interaction lists");
+    precompute_operators(order, d, radius, tree_.depth, kernel_, params_.compression_type, params_.epsilon, &ops_);
+    timer.lap("operators (ACA/SVD)");
+
+    // ---- host-side work lists
+    const HostTree &t = tree_;
+    const int64_t C = t.n_cells();
+    level_cells_.assign(t.depth + 1, {});
+    m2m_parents_.assign(t.depth + 1, {});
+    for (int64_t c = 0; c < C; ++c) {
+        level_cells_[t.level[c]].push_back(static_cast<int32_t>(c));
+        if (t.children.ptr[c + 1] > t.children.ptr[c]) m2m_parents_[t.level[c]].push_back(static_cast<int32_t>(c));
+        if (t.is_leaf[c] && t.pt_end[c] > t.pt_begin[c]) src_leaves_.push_back(static_cast<int32_t>(c));
+    }
+    // leaves in sorted-point (DFS Morton) order: spatially coherent job order
+    std::sort(src_leaves_.begin(), src_leaves_.end(),
+              [&](int32_t a, int32_t b) { return t.pt_begin[a] < t.pt_begin[b]; });
+    u_runs_.ptr.assign(C + 1, 0);
+    x_runs_.ptr.assign(C + 1, 0);
+    for (int64_t c = 0; c < C; ++c) {
+        merged_runs(t, t.u.idx.data() + t.u.ptr[c], t.u.ptr[c + 1] - t.u.ptr[c], &u_runs_.idx);
+        u_runs_.ptr[c + 1] = static_cast<int64_t>(u_runs_.idx.size() / 2);
+        merged_runs(t, t.x.idx.data() + t.x.ptr[c], t.x.ptr[c + 1] - t.x.ptr[c], &x_runs_.idx);
+        x_runs_.ptr[c + 1] = static_cast<int64_t>(x_runs_.idx.size() / 2);
+        if (x_runs_.ptr[c + 1] > x_runs_.ptr[c]) x_cells_.push_back(static_cast<int32_t>(c));
+    }
+    part_rows_.clear();
+    timer.lap("run lists");
+
+    if (!host_only_) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(BBFMM_DEVICE_ERROR, "no HIP device available (the BBFMM passes have no CPU fallback)");
+        HIPCHK(hipStreamCreate(&stream_));
+        HIPCHK(hipEventCreate(&ev_[0]));
+        HIPCHK(hipEventCreate(&ev_[1]));
+    }
+    CHK(build_m2l_tables());
+    timer.lap("stacked M2L tables");
+    if (!host_only_) {
+        CHK(upload());
+        CHK(build_source_target_set());
+        HIPCHK(hipStreamSynchronize(stream_));
+        timer.lap("upload");
+    }
+    return BBFMM_OK;
+}
+
+// Stacked operators of one (level, class): VtAll (n_pad x r_pad16) and UAll (k_pad x n_pad).
+void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<double> *vt_all,
+                                       std::vector<double> *u_all) const {
+    const int n = ops_.n, n_pad = round_up(n, 16);
+    const bool compressed = ops_.compression != kCompressionNone;
+    const auto &lops = ops_.m2l[hc.level];
+    vt_all->assign(static_cast<size_t>(n_pad) * hc.r_pad16, 0.0);
+    u_all->assign(static_cast<size_t>(hc.k_pad) * n_pad, 0.0);
+    struct RowSrc {
+        const M2lOperator *op;
+        const int32_t *inv;
+        int first_row;
+    };
+    std::vector<RowSrc> row_src;
+    int row = 0;
+    for (int tv : hc.src_tv) {
+        const M2lOperator &op = lops[ops_.ref_lookup[tv]];
+        row_src.push_back(RowSrc{&op, &ops_.invperm[static_cast<size_t>(ops_.perm_lookup[tv]) * n], row});
+        row += op.rank;
+    }
+    // c[kk] = sum_m Vt[kk][invperm[m]] * M_V[m]   (bbfmm.rs:924-930 folded)
+    parallel_for(n, 8, [&](int64_t m) {
+        double *dst = vt_all->data() + static_cast<size_t>(m) * hc.r_pad16;
+        for (const RowSrc &rs : row_src) {
+            const int r = rs.op->rank;
+            const int im = rs.inv[m];
+            if (compressed) {
+                const double *src = &rs.op->vt[static_cast<size_t>(im) * r];
+                for (int kk = 0; kk < r; ++kk) dst[rs.first_row + kk] = src[kk];
+            } else {
+                dst[rs.first_row + im] = 1.0;
+            }
+        }
+    });
+    // L_B[i] += sum_kk U[invperm[i]][kk] * c[kk]   (bbfmm.rs:975-981 folded)
+    parallel_for(static_cast<int64_t>(hc.tgt_tv.size()), 1, [&](int64_t pos) {
+        const int tv = hc.tgt_tv[pos];
+        const M2lOperator &op = lops[ops_.ref_lookup[tv]];
+        const int32_t *inv = &ops_.invperm[static_cast<size_t>(ops_.perm_lookup[tv]) * n];
+        for (int kk = 0; kk < op.rank; ++kk) {
+            double *dst = u_all->data() + static_cast<size_t>(hc.tgt_off[pos] + kk) * n_pad;
+            const double *ucol = &op.u[static_cast<size_t>(kk) * n];
+            for (int i = 0; i < n; ++i) dst[i] = ucol[inv[i]];
+        }
+    });
+}
+
+// ------------------------------------------------------------------ M2L tables
+// Folds the reference's symmetry permutations (bbfmm.rs:910-931,964-982) into stacked
+// per-octant-class operators; see device.hip "M2L".
+int FmmTree::build_m2l_tables() {
+    const HostTree &t = tree_;
+    const int d = d_, n = ops_.n, n_pad = round_up(n, 16);
+    const int ncls = 1 << d, nvec = ops_.n_vec;
+    const bool compressed = ops_.compression != kCompressionNone;
+    m2l_host_.clear();
+    m2l_classes_h_.clear();
+    m2l_tiles_h_.clear();
+    cbuf_len_ = 0;
+    m2l_flops_k1_ = 0;
+    if (t.depth < 2) return BBFMM_OK;
+
+    auto comp = [&](int tv, int a) { return ops_.all_vecs[static_cast<size_t>(tv) * d + a]; };
+    auto far = [&](int tv) {
+        int mx = 0;
+        for (int a = 0; a < d; ++a) mx = std::max(mx, std::abs(comp(tv, a)));
+        return mx >= 2;
+    };
+    // admissible transfer vectors per class (B = V + t, both children of neighbouring parents)
+    std::vector<std::vector<int>> tgt_list(ncls), src_list(ncls), tpos_tgt(ncls, std::vector<int>(nvec, -1)),
+        tpos_src(ncls, std::vector<int>(nvec, -1));
+    for (int o = 0; o < ncls; ++o)
+        for (int tv = 0; tv < nvec; ++tv) {
+            if (!far(tv)) continue;
+            bool okt = true, oks = true;
+            for (int a = 0; a < d; ++a) {
+                const int oa = (o >> a) & 1, ta = comp(tv, a);
+                okt = okt && ta >= oa - 3 && ta <= oa + 2;
+                oks = oks && ta >= -2 - oa && ta <= 3 - oa;
+            }
+            if (okt) {
+                tpos_tgt[o][tv] = static_cast<int>(tgt_list[o].size());
+                tgt_list[o].push_back(tv);
+            }
+            if (oks) {
+                tpos_src[o][tv] = static_cast<int>(src_list[o].size());
+                src_list[o].push_back(tv);
+            }
+        }
+    auto target_class = [&](int o, int tv) {
+        int oc = 0;
+        for (int a = 0; a < d; ++a) {
+            const int v = ((o >> a) & 1) + comp(tv, a);
+            oc |= (((v % 2) + 2) % 2) << a;
+        }
+        return oc;
+    };
+
+    std::vector<int32_t> pos_in_class(t.n_cells(), -1);
+    int64_t cbuf_cursor = 0;
+    int64_t bad_pairs = 0;
+    for (int level = 2; level <= t.depth; ++level) {
+        const auto &lops = ops_.m2l[level];
+        auto rank_of = [&](int tv) { return lops[ops_.ref_lookup[tv]].rank; };
+        // slot layout of a target of class o
+        std::vector<std::vector<int>> off_tgt(ncls);
+        std::vector<int> k_pad(ncls, 0);
+        for (int o = 0; o < ncls; ++o) {
+            int off = 0;
+            for (int tv : tgt_list[o]) {
+                off_tgt[o].push_back(off);
+                off += round_up(rank_of(tv), 4);
+            }
+            k_pad[o] = round_up(std::max(off, 16), 16);
+        }
+        const size_t first_class = m2l_host_.size();
+        m2l_host_.resize(first_class + ncls);
+        for (int64_t c = t.level_ptr[level]; c < t.level_ptr[level + 1]; ++c) {
+            auto &hc = m2l_host_[first_class + t.octant[c]];
+            pos_in_class[c] = static_cast<int32_t>(hc.cells.size());
+            hc.cells.push_back(static_cast<int32_t>(c));
+        }
+        for (int o = 0; o < ncls; ++o) {
+            HostM2lClass &hc = m2l_host_[first_class + o];
+            hc.level = level;
+            hc.octant = o;
+            hc.n_t = static_cast<int>(src_list[o].size());
+            hc.k_pad = k_pad[o];
+            // stage 1 tall operator rows
+            hc.n_rows = 0;
+            for (int tv : src_list[o]) hc.n_rows += rank_of(tv);
+            hc.r_pad16 = round_up(std::max(hc.n_rows, 16), 16);
+            hc.row_tpos.assign(hc.r_pad16, -1);
+            hc.row_off.assign(hc.r_pad16, 0);
+            if (hc.cells.empty()) continue;
+            hc.src_tv = src_list[o];
+            hc.tgt_tv = tgt_list[o];
+            hc.tgt_off = off_tgt[o];
+            int row = 0;
+            for (size_t pos = 0; pos < src_list[o].size(); ++pos) {
+                const int tv = src_list[o][pos];
+                const int oc = target_class(o, tv);
+                const int base_off = off_tgt[oc][tpos_tgt[oc][tv]];
+                for (int kk = 0; kk < rank_of(tv); ++kk, ++row) {
+                    hc.row_tpos[row] = static_cast<int32_t>(pos);
+                    hc.row_off[row] = base_off + kk;
+                }
+            }
+            if (host_only_) fill_m2l_operator_arrays(hc, &hc.vt_all, &hc.u_all);
+            hc.cbase.resize(hc.cells.size());
+            for (size_t i = 0; i < hc.cells.size(); ++i) {
+                hc.cbase[i] = cbuf_cursor;
+                cbuf_cursor += hc.k_pad;
+            }
+            hc.cslot.assign(hc.cells.size() * static_cast<size_t>(hc.n_t), -1);
+        }
+        // cslot: for every V pair (B <- V, t) the slot of B as seen from V
+        for (int64_t B = t.level_ptr[level]; B < t.level_ptr[level + 1]; ++B) {
+            const HostM2lClass &hb = m2l_host_[first_class + t.octant[B]];
+            const int64_t base = hb.cbase[pos_in_class[B]];
+            for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
+                const int32_t V = t.v.idx[q];
+                const int tv = t.v_tidx[q];
+                HostM2lClass &hv = m2l_host_[first_class + t.octant[V]];
+                const int ps = (tv >= 0 && tv < nvec) ? tpos_src[t.octant[V]][tv] : -1;
+                if (ps < 0 || t.level[V] != level || tpos_tgt[t.octant[B]][tv] < 0) {
+                    ++bad_pairs;
+                    continue;
+                }
+                hv.cslot[static_cast<size_t>(pos_in_class[V]) * hv.n_t + ps] = static_cast<int32_t>(base / 4);
+                const int r = rank_of(tv);
+                m2l_flops_k1_ += compressed ? 4.0 * n * r : 2.0 * n * static_cast<double>(n);
+            }
+        }
+        for (int o = 0; o < ncls; ++o) {
+            const HostM2lClass &hc = m2l_host_[first_class + o];
+            for (int32_t first = 0; first < static_cast<int32_t>(hc.cells.size()); first += kM2lTile) {
+                M2lTileDesc td;
+                td.level_class = static_cast<int32_t>(first_class + o);
+                td.first = first;
+                td.count = std::min<int32_t>(kM2lTile, static_cast<int32_t>(hc.cells.size()) - first);
+                td.pad = 0;
+                m2l_tiles_h_.push_back(td);
+            }
+        }
+    }
+    if (bad_pairs > 0)
+        return fail(BBFMM_UNSUPPORTED,
+                    "V-list pairs outside the admissible transfer-vector set (source points outside the root box?)");
+    cbuf_len_ = cbuf_cursor;
+    if (cbuf_len_ / 4 >= (int64_t(1) << 31)) return fail(BBFMM_UNSUPPORTED, "M2L intermediate buffer too large");
+    return BBFMM_OK;
+}
+
+// ------------------------------------------------------------------ upload
+int FmmTree::upload() {
+    const HostTree &t = tree_;
+    const int d = d_;
+    const int64_t N = t.n_points, C = t.n_cells();
+    // Chebyshev tables
+    DevCheb hc{};
+    hc.p = order_;
+    hc.d = d;
+    hc.n = ops_.n;
+    hc.n_pad = round_up(ops_.n, 16);
+    std::copy(ops_.polyn.begin(), ops_.polyn.end(), hc.polyn);
+    std::copy(ops_.nodes.begin(), ops_.nodes.end(), hc.nodes);
+    std::copy(ops_.xfer.begin(), ops_.xfer.end(), hc.xfer);
+    CHK(dalloc(&d_cheb_, 1));
+    HIPCHK(hipMemcpy(d_cheb_.p, &hc, sizeof hc, hipMemcpyHostToDevice));
+    cheb_ = ChebRef{d_cheb_.p, hc.p, hc.d, hc.n, hc.n_pad};
+
+    // sorted sources (SoA); unused axes alias one zero array
+    CHK(dalloc(&d_zero_axis_, static_cast<size_t>(N), true));
+    {
+        std::vector<double> tmp(static_cast<size_t>(N));
+        for (int a = 0; a < 3; ++a) {
+            if (a < d) {
+                const double *col = &pts_[static_cast<size_t>(a) * N];
+                parallel_for(N, 1 << 16, [&](int64_t i) { tmp[i] = col[t.order[i]]; });
+                CHK(dupload(&d_src_[a], tmp));
+                src_ptr_[a] = d_src_[a].p;
+            } else {
+                src_ptr_[a] = d_zero_axis_.p;
+            }
+        }
+        std::vector<int32_t> ord(static_cast<size_t>(N));
+        for (int64_t i = 0; i < N; ++i) ord[i] = static_cast<int32_t>(t.order[i]);
+        CHK(dupload(&d_order_, ord));
+    }
+    {
+        std::vector<double> c3(static_cast<size_t>(C) * 3, 0.0);
+        for (int64_t c = 0; c < C; ++c)
+            for (int a = 0; a < d; ++a) c3[c * 3 + a] = t.centers[c * d + a];
+        CHK(dupload(&d_centers_, c3));
+        CHK(dupload(&d_lengths_, t.lengths));
+        std::vector<int32_t> b(C), e(C);
+        for (int64_t c = 0; c < C; ++c) {
+            b[c] = static_cast<int32_t>(t.pt_begin[c]);
+            e[c] = static_cast<int32_t>(t.pt_end[c]);
+        }
+        CHK(dupload(&d_pt_begin_, b));
+        CHK(dupload(&d_pt_end_, e));
+        CHK(dupload(&d_parent_, t.parent));
+        CHK(dupload(&d_octant_, t.octant));
+        CHK(dupload(&d_child_ptr_, t.children.ptr));
+        CHK(dupload(&d_child_idx_, t.children.idx));
+        CHK(dupload(&d_src_leaves_, src_leaves_));
+    }
+    d_m2m_parents_.resize(level_cells_.size());
+    d_level_cells_.resize(level_cells_.size());
+    for (size_t l = 0; l < level_cells_.size(); ++l) {
+        CHK(dupload(&d_m2m_parents_[l], m2m_parents_[l]));
+        CHK(dupload(&d_level_cells_[l], level_cells_[l]));
+    }
+    CHK(dupload(&d_u_run_ptr_, u_runs_.ptr));
+    CHK(dupload(&d_u_runs_, u_runs_.idx));
+    CHK(dupload(&d_w_ptr_, t.w.ptr));
+    CHK(dupload(&d_w_idx_, t.w.idx));
+    {
+        // P2L jobs: compact run_ptr over the cells that have an X list
+        std::vector<int64_t> job_ptr(x_cells_.size() + 1, 0);
+        std::vector<int32_t> job_runs;
+        for (size_t j = 0; j < x_cells_.size(); ++j) {
+            const int32_t c = x_cells_[j];
+            for (int64_t r = x_runs_.ptr[c]; r < x_runs_.ptr[c + 1]; ++r) {
+                job_runs.push_back(x_runs_.idx[2 * r]);
+                job_runs.push_back(x_runs_.idx[2 * r + 1]);
+            }
+            job_ptr[j + 1] = static_cast<int64_t>(job_runs.size() / 2);
+        }
+        CHK(dupload(&d_x_cells_, x_cells_));
+        CHK(dupload(&d_x_job_run_ptr_, job_ptr));
+        CHK(dupload(&d_x_runs_, job_runs));
+    }
+    // M2L tables
+    m2l_classes_h_.resize(m2l_host_.size());
+    std::vector<double> vt_scratch, u_scratch; // reused: page-faulting fresh host memory is slow
+    for (size_t i = 0; i < m2l_host_.size(); ++i) {
+        HostM2lClass &h = m2l_host_[i];
+        M2lClass &c = m2l_classes_h_[i];
+        std::memset(&c, 0, sizeof c);
+        c.n_rows = h.n_rows;
+        c.r_pad16 = h.r_pad16;
+        c.n_t = h.n_t;
+        c.k_pad = h.k_pad;
+        c.n_cells = static_cast<int32_t>(h.cells.size());
+        if (h.cells.empty()) continue;
+        DevBuf<double> vt, ua;
+        DevBuf<int32_t> rt, ro, ce, cs;
+        DevBuf<int64_t> cb;
+        fill_m2l_operator_arrays(h, &vt_scratch, &u_scratch);
+        CHK(dupload(&vt, vt_scratch));
+        CHK(dupload(&ua, u_scratch));
+        CHK(dupload(&rt, h.row_tpos));
+        CHK(dupload(&ro, h.row_off));
+        CHK(dupload(&ce, h.cells));
+        CHK(dupload(&cs, h.cslot));
+        CHK(dupload(&cb, h.cbase));
+        c.vt_all = vt.p;
+        c.u_all = ua.p;
+        c.row_tpos = rt.p;
+        c.row_off = ro.p;
+        c.cells = ce.p;
+        c.cslot = cs.p;
+        c.cbase = cb.p;
+        std::vector<int32_t>().swap(h.cslot); // only needed for uploading
+    }
+    CHK(dupload(&d_m2l_classes_, m2l_classes_h_));
+    CHK(dupload(&d_m2l_tiles_, m2l_tiles_h_));
+    std::vector<uint8_t> act(static_cast<size_t>(C), 1);
+    CHK(dupload(&d_active_, act));
+    return BBFMM_OK;
+}
+
+int FmmTree::ensure_rhs_capacity(int k) {
+    if (k <= k_cap_) return BBFMM_OK;
+    const int64_t N = tree_.n_points, C = tree_.n_cells();
+    dfree(&d_w_sorted_);
+    dfree(&d_M_);
+    dfree(&d_L_);
+    dfree(&d_cbuf_);
+    dfree(&d_out_);
+    dfree(&src_targets_.out);
+    dfree(&src_targets_.grad);
+    const size_t coef = static_cast<size_t>(k) * C * cheb_.n_pad;
+    CHK(dalloc(&d_w_sorted_, static_cast<size_t>(k) * N));
+    CHK(dalloc(&d_M_, coef, true));
+    CHK(dalloc(&d_L_, coef, true));
+    CHK(dalloc(&d_cbuf_, static_cast<size_t>(k) * std::max<int64_t>(cbuf_len_, 1), true)); // absent pairs stay 0
+    CHK(dalloc(&d_out_, static_cast<size_t>(k) * N));
+    CHK(dalloc(&src_targets_.out, static_cast<size_t>(k) * N));
+    k_cap_ = k;
+    return BBFMM_OK;
+}
+
+// targets = sources: jobs and ranges come straight from the tree
+int FmmTree::build_source_target_set() {
+    const HostTree &t = tree_;
+    TargetSet &ts = src_targets_;
+    ts.m = t.n_points;
+    for (int a = 0; a < 3; ++a) ts.xyz_ptr[a] = src_ptr_[a];
+    ts.perm = d_order_;
+    std::vector<int32_t> jc, tb, te, wjc, wtb, wte;
+    for (int32_t c : src_leaves_) {
+        jc.push_back(c);
+        tb.push_back(static_cast<int32_t>(t.pt_begin[c]));
+        te.push_back(static_cast<int32_t>(t.pt_end[c]));
+        if (t.w.ptr[c + 1] > t.w.ptr[c]) {
+            wjc.push_back(c);
+            wtb.push_back(tb.back());
+            wte.push_back(te.back());
+        }
+    }
+    ts.n_jobs = static_cast<int>(jc.size());
+    ts.n_w_jobs = static_cast<int>(wjc.size());
+    CHK(dupload(&ts.job_cell, jc));
+    CHK(dupload(&ts.tgt_begin, tb));
+    CHK(dupload(&ts.tgt_end, te));
+    CHK(dupload(&ts.w_job_cell, wjc));
+    CHK(dupload(&ts.w_tgt_begin, wtb));
+    CHK(dupload(&ts.w_tgt_end, wte));
+    return BBFMM_OK;
+}
+
+int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index) {
+    const HostTree &t = tree_;
+    std::vector<int32_t> cell(static_cast<size_t>(m));
+    const int64_t bad = points_to_leaves(t, x, m, ldx, cell.data());
+    if (bad >= 0) {
+        if (bad_point_index) *bad_point_index = bad;
+        return fail(BBFMM_POINT_OUTSIDE_TREE, "FMM evaluation failed: target point at row " + std::to_string(bad) +
+                                                  " lies outside the tree extents");
+    }
+    // group rows by leaf, ascending rows inside a leaf (linear_tree.rs:522-534)
+    const int64_t C = t.n_cells();
+    std::vector<int64_t> cnt(static_cast<size_t>(C) + 1, 0);
+    for (int64_t i = 0; i < m; ++i) ++cnt[cell[i] + 1];
+    // visit leaves in sorted-point order for locality: rank leaves by pt_begin, empty ones by key
+    std::vector<int32_t> leaves;
+    for (int64_t c = 0; c < C; ++c)
+        if (cnt[c + 1] > 0) leaves.push_back(static_cast<int32_t>(c));
+    std::vector<int64_t> start(static_cast<size_t>(C), 0);
+    int64_t cur = 0;
+    std::vector<int32_t> jc, tb, te, wjc, wtb, wte;
+    for (int32_t c : leaves) {
+        start[c] = cur;
+        jc.push_back(c);
+        tb.push_back(static_cast<int32_t>(cur));
+        cur += cnt[c + 1];
+        te.push_back(static_cast<int32_t>(cur));
+        if (t.w.ptr[c + 1] > t.w.ptr[c]) {
+            wjc.push_back(c);
+            wtb.push_back(tb.back());
+            wte.push_back(te.back());
+        }
+    }
+    std::vector<int32_t> perm(static_cast<size_t>(m));
+    {
+        std::vector<int64_t> pos(start);
+        for (int64_t i = 0; i < m; ++i) perm[pos[cell[i]]++] = static_cast<int32_t>(i);
+    }
+    ts->m = m;
+    std::vector<double> tmp(static_cast<size_t>(m));
+    for (int a = 0; a < 3; ++a) {
+        if (a < d_) {
+            for (int64_t i = 0; i < m; ++i) tmp[i] = x[a * ldx + perm[i]];
+            CHK(dupload(&ts->xyz[a], tmp));
+            ts->xyz_ptr[a] = ts->xyz[a].p;
+        } else {
+            if (static_cast<size_t>(m) > d_zero_axis_.n) {
+                CHK(dalloc(&ts->xyz[a], static_cast<size_t>(m), true));
+                ts->xyz_ptr[a] = ts->xyz[a].p;
+            } else {
+                ts->xyz_ptr[a] = d_zero_axis_.p;
+            }
+        }
+    }
+    CHK(dupload(&ts->perm, perm));
+    ts->n_jobs = static_cast<int>(jc.size());
+    ts->n_w_jobs = static_cast<int>(wjc.size());
+    CHK(dupload(&ts->job_cell, jc));
+    CHK(dupload(&ts->tgt_begin, tb));
+    CHK(dupload(&ts->tgt_end, te));
+    CHK(dupload(&ts->w_job_cell, wjc));
+    CHK(dupload(&ts->w_tgt_begin, wtb));
+    CHK(dupload(&ts->w_tgt_end, wte));
+    return BBFMM_OK;
+}
+
+void FmmTree::free_target_set(TargetSet *ts) {
+    for (int a = 0; a < 3; ++a) dfree(&ts->xyz[a]);
+    dfree(&ts->perm);
+    dfree(&ts->job_cell);
+    dfree(&ts->tgt_begin);
+    dfree(&ts->tgt_end);
+    dfree(&ts->w_job_cell);
+    dfree(&ts->w_tgt_begin);
+    dfree(&ts->w_tgt_end);
+    dfree(&ts->out);
+    dfree(&ts->grad);
+}
+
+int FmmTree::upload_weights(const double *w, int64_t rows, int k, int64_t ldw) {
+    const int64_t N = tree_.n_points;
+    if (!w || rows < N || ldw < rows || k < 1) return fail(BBFMM_BAD_ARGUMENT, "weights must be rows x k with rows >= N");
+    CHK(ensure_rhs_capacity(k));
+    if (static_cast<size_t>(k) * N > d_w_in_.n) {
+        dfree(&d_w_in_);
+        CHK(dalloc(&d_w_in_, static_cast<size_t>(k) * N));
+    }
+    // only rows < N are read (bbfmm.rs:704-708)
+    HIPCHK(hipMemcpy2DAsync(d_w_in_.p, N * sizeof(double), w, ldw * sizeof(double), N * sizeof(double), k,
+                            hipMemcpyHostToDevice, stream_));
+    phase_begin();
+    launch_gather_weights(d_w_in_.p, N, k, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_end(kPhGather);
+    return BBFMM_OK;
+}
+
+// upward_pass (bbfmm.rs:666-688)
+int FmmTree::upward(int k) {
+    const HostTree &t = tree_;
+    const int64_t C = t.n_cells();
+    HIPCHK(hipMemsetAsync(d_M_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_)); // 619-624
+    phase_begin();
+    launch_p2m(cheb_, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_src_leaves_.p, static_cast<int>(src_leaves_.size()),
+               d_pt_begin_.p, d_pt_end_.p, d_centers_.p, d_lengths_.p, d_M_.p, stream_);
+    phase_end(kPhP2M);
+    phase_begin();
+    for (int level = t.depth - 1; level >= 1; --level) // (1..depth).rev(), bbfmm.rs:675
+        launch_m2m(cheb_, k, C, d_m2m_parents_[level].p, static_cast<int>(m2m_parents_[level].size()), d_child_ptr_.p,
+                   d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
+    phase_end(kPhM2M);
+    HIPCHK(hipGetLastError());
+    return BBFMM_OK;
+}
+
+// downward_pass (bbfmm.rs:778-857).  All cells are treated as "with targets": locals of
+// cells without targets are never read by the leaf pass, so results are unchanged.
+int FmmTree::downward(int k) {
+    const HostTree &t = tree_;
+    const int64_t C = t.n_cells();
+    HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_)); // 627-632
+    const M2lTileDesc *tiles = have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles_.p;
+    const int n_tiles = have_part_ ? n_m2l_tiles_part_ : static_cast<int>(m2l_tiles_h_.size());
+    phase_begin();
+    launch_m2l_stage1(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
+    phase_end(kPhM2L1);
+    phase_begin();
+    launch_m2l_stage2(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_L_.p, stream_);
+    phase_end(kPhM2L2);
+    phase_begin();
+    if (t.adaptive)
+        launch_p2l(kernel_, cheb_, static_cast<int>(x_cells_.size()), d_x_cells_.p, d_x_job_run_ptr_.p, d_x_runs_.p,
+                   d_centers_.p, d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p, stream_);
+    phase_end(kPhP2L);
+    phase_begin();
+    for (int level = 2; level <= t.depth; ++level) // children of level-1.. cells (bbfmm.rs:834-856)
+        launch_l2l(cheb_, k, C, d_level_cells_[level].p, static_cast<int>(level_cells_[level].size()), d_parent_.p,
+                   d_octant_.p, d_active_.p, d_L_.p, stream_);
+    phase_end(kPhL2L);
+    HIPCHK(hipGetLastError());
+    have_locals_ = true;
+    return BBFMM_OK;
+}
+
+// leaf_pass (bbfmm.rs:1089-1159) into ts.out / ts.grad (sorted order)
+int FmmTree::leaf_pass(const TargetSet &ts, int k, bool with_grads) {
+    const HostTree &t = tree_;
+    const int64_t C = t.n_cells();
+    HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), stream_));
+    double *grad = nullptr;
+    if (with_grads) {
+        grad = ts.grad.p;
+        HIPCHK(hipMemsetAsync(grad, 0, static_cast<size_t>(k) * d_ * ts.m * sizeof(double), stream_));
+    }
+    DirectJobs jobs{ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_u_run_ptr_.p, d_u_runs_.p};
+    phase_begin();
+    launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, stream_);
+    phase_end(kPhP2P);
+    phase_begin();
+    if (t.adaptive)
+        launch_m2p(kernel_, cheb_, ts.n_w_jobs, ts.w_job_cell.p, ts.w_tgt_begin.p, ts.w_tgt_end.p, d_w_ptr_.p,
+                   d_w_idx_.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr, ts.m, k, C, d_M_.p, ts.out.p, grad, stream_);
+    phase_end(kPhM2P);
+    phase_begin();
+    launch_l2p(cheb_, ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr,
+               ts.m, k, C, d_L_.p, ts.out.p, grad, stream_);
+    phase_end(kPhL2P);
+    HIPCHK(hipGetLastError());
+    return BBFMM_OK;
+}
+
+int FmmTree::set_weights(const double *w, int64_t rows, int k, int64_t ldw) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    CHK(upload_weights(w, rows, k, ldw));
+    nrhs_ = k; // bbfmm.rs:384
+    CHK(upward(k));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return BBFMM_OK;
+}
+
+int FmmTree::set_local_coefficients(const double *w, int64_t rows, int k, int64_t ldw) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (nrhs_ == 0) return fail(BBFMM_BAD_ARGUMENT, "set_weights must be called first");
+    if (k != nrhs_) return fail(BBFMM_BAD_ARGUMENT, "weights must have the column count given to set_weights");
+    CHK(upload_weights(w, rows, k, ldw));
+    CHK(downward(k));
+    HIPCHK(hipStreamSynchronize(stream_));
+    return BBFMM_OK;
+}
+
+int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const double *x, int64_t m, int64_t ldx,
+                      double *out, int64_t ldo, double *grad, int64_t ldg, bool with_grads, bool leaves_only,
+                      int64_t *bad_point_index) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (nrhs_ == 0) return fail(BBFMM_BAD_ARGUMENT, "set_weights must be called first");
+    if (k != nrhs_) return fail(BBFMM_BAD_ARGUMENT, "weights must have the column count given to set_weights");
+    if (m < 0 || (m > 0 && (!x || !out || ldx < m || ldo < m))) return fail(BBFMM_BAD_ARGUMENT, "bad target/output arrays");
+    if (with_grads && m > 0 && (!grad || ldg < m)) return fail(BBFMM_BAD_ARGUMENT, "bad gradient array");
+    if (leaves_only && !have_locals_) return fail(BBFMM_BAD_ARGUMENT, "set_local_coefficients must be called first");
+    if (m >= (int64_t(1) << 31)) return fail(BBFMM_BAD_ARGUMENT, "more than 2^31-1 target points");
+    TargetSet ts;
+    int rc = build_target_set(x, m, ldx, &ts, bad_point_index); // points_to_keys, bbfmm.rs:455-465
+    if (rc == BBFMM_OK) rc = upload_weights(w, rows, k, ldw);
+    if (rc == BBFMM_OK && !leaves_only) rc = downward(k);
+    if (rc == BBFMM_OK && with_grads && !kernel_supports_gradients(kernel_.id)) // bbfmm.rs:634-658
+        rc = fail(BBFMM_KERNEL_NO_GRADIENTS,
+                  "FMM evaluation failed: gradient evaluation requested but kernel does not support gradients");
+    DevBuf<double> o_dev, g_dev;
+    if (rc == BBFMM_OK && m > 0) {
+        rc = dalloc(&ts.out, static_cast<size_t>(k) * m);
+        if (rc == BBFMM_OK && with_grads) rc = dalloc(&ts.grad, static_cast<size_t>(k) * d_ * m);
+        if (rc == BBFMM_OK) rc = leaf_pass(ts, k, with_grads);
+        if (rc == BBFMM_OK) rc = dalloc(&o_dev, static_cast<size_t>(k) * m);
+        if (rc == BBFMM_OK) {
+            phase_begin();
+            launch_scatter_output(ts.out.p, m, k, ts.perm.p, o_dev.p, m, 0, stream_);
+            phase_end(kPhScatter);
+            hipError_t e = hipMemcpy2DAsync(out, ldo * sizeof(double), o_dev.p, m * sizeof(double), m * sizeof(double), k,
+                                            hipMemcpyDeviceToHost, stream_);
+            if (e != hipSuccess) rc = hip_fail(e, "copy values to host");
+        }
+        if (rc == BBFMM_OK && with_grads) {
+            rc = dalloc(&g_dev, static_cast<size_t>(k) * d_ * m);
+            if (rc == BBFMM_OK) {
+                launch_scatter_output(ts.grad.p, m, k * d_, ts.perm.p, g_dev.p, m, 0, stream_);
+                hipError_t e = hipMemcpy2DAsync(grad, ldg * sizeof(double), g_dev.p, m * sizeof(double),
+                                                m * sizeof(double), static_cast<size_t>(k) * d_, hipMemcpyDeviceToHost,
+                                                stream_);
+                if (e != hipSuccess) rc = hip_fail(e, "copy gradients to host");
+            }
+        }
+    }
+    if (stream_) {
+        hipError_t e = hipStreamSynchronize(stream_);
+        if (rc == BBFMM_OK && e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
+    }
+    dfree(&o_dev);
+    dfree(&g_dev);
+    free_target_set(&ts);
+    return rc;
+}
+
+int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out, int64_t ldo, bool sync) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    const int64_t N = tree_.n_points;
+    if (!d_w || !d_out || k < 1 || ldw < N || ldo < N) return fail(BBFMM_BAD_ARGUMENT, "bad device matvec arguments");
+    CHK(ensure_rhs_capacity(k));
+    nrhs_ = k;
+    phase_begin();
+    launch_gather_weights(d_w, ldw, k, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_end(kPhGather);
+    CHK(upward(k));
+    CHK(downward(k));
+    if (have_part_ && part_targets_.out.n < static_cast<size_t>(k) * part_targets_.m) {
+        dfree(&part_targets_.out);
+        CHK(dalloc(&part_targets_.out, static_cast<size_t>(k) * part_targets_.m));
+    }
+    const TargetSet &ts = have_part_ ? part_targets_ : src_targets_;
+    CHK(leaf_pass(ts, k, false));
+    phase_begin();
+    launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);
+    phase_end(kPhScatter);
+    HIPCHK(hipGetLastError());
+    if (sync) HIPCHK(hipStreamSynchronize(stream_));
+    return BBFMM_OK;
+}
+
+int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t basis_size,
+                                        const int64_t *target_indices, int64_t n_target_indices, const double *poly,
+                                        int64_t ldp, double nugget, double *result) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    const int64_t N = tree_.n_points;
+    if (!w || !result || basis_size < 0 || rows != N + basis_size)
+        return fail(BBFMM_BAD_ARGUMENT, "weights must have N + basis_size rows");
+    if (poly && ldp < N) return fail(BBFMM_BAD_ARGUMENT, "polynomial matrix needs N rows");
+    std::fill(result, result + rows, 0.0); // rbf.rs:1346
+    CHK(set_weights(w, rows, 1, rows));    // rbf.rs:1357
+    std::vector<double> vals;
+    std::vector<int64_t> idx;
+    if (!target_indices) { // all sources: the targets already live on the device
+        CHK(downward(1));
+        CHK(leaf_pass(src_targets_, 1, false));
+        launch_scatter_output(src_targets_.out.p, N, 1, d_order_.p, d_out_.p, N, 0, stream_);
+        vals.resize(static_cast<size_t>(N));
+        HIPCHK(hipMemcpyAsync(vals.data(), d_out_.p, N * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        idx.resize(static_cast<size_t>(N));
+        std::iota(idx.begin(), idx.end(), int64_t(0));
+    } else {
+        idx.assign(target_indices, target_indices + n_target_indices);
+        for (int64_t i : idx)
+            if (i < 0 || i >= N) return fail(BBFMM_BAD_ARGUMENT, "target index out of range");
+        const int64_t m = n_target_indices;
+        std::vector<double> x(static_cast<size_t>(m) * d_);
+        for (int a = 0; a < d_; ++a)
+            for (int64_t j = 0; j < m; ++j) x[static_cast<size_t>(a) * m + j] = pts_[static_cast<size_t>(a) * N + idx[j]];
+        vals.resize(static_cast<size_t>(m));
+        int64_t bad = -1;
+        CHK(evaluate(w, rows, 1, rows, x.data(), m, m, vals.data(), m, nullptr, 0, false, false, &bad)); // rbf.rs:1359-1364
+    }
+    for (size_t j = 0; j < idx.size(); ++j) { // rbf.rs:1366-1376
+        const int64_t i = idx[j];
+        double r = vals[j];
+        r += w[i] * nugget;
+        if (poly) {
+            double s = 0.0;
+            for (int64_t b = 0; b < basis_size; ++b) s += poly[b * ldp + i] * w[N + b];
+            r += s;
+        }
+        result[i] = r;
+    }
+    return BBFMM_OK;
+}
+
+// Multi-GPU: own a contiguous range of the leaves in sorted-point (Morton DFS) order.
+int FmmTree::set_partition(int rank, int world) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (world < 1 || rank < 0 || rank >= world) return fail(BBFMM_BAD_ARGUMENT, "bad rank/world");
+    const HostTree &t = tree_;
+    const int64_t N = t.n_points, C = t.n_cells();
+    part_rank_ = rank;
+    part_world_ = world;
+    if (have_part_) {
+        free_target_set(&part_targets_);
+        dfree(&d_m2l_tiles_part_);
+        have_part_ = false;
+    }
+    part_rows_.clear();
+    std::vector<uint8_t> active(static_cast<size_t>(C), 1);
+    if (world == 1) {
+        HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
+        return BBFMM_OK;
+    }
+    // balance the leaf-pass + M2L work proxy: P2P pair count + a per-point share of the far field
+    const size_t nl = src_leaves_.size();
+    std::vector<double> work(nl);
+    double total = 0;
+    const double far_per_point = m2l_flops_k1_ / std::max<double>(1.0, static_cast<double>(N)) / 30.0;
+    for (size_t i = 0; i < nl; ++i) {
+        const int32_t c = src_leaves_[i];
+        double ns = 0;
+        for (int64_t r = u_runs_.ptr[c]; r < u_runs_.ptr[c + 1]; ++r) ns += u_runs_.idx[2 * r + 1] - u_runs_.idx[2 * r];
+        const double nt = static_cast<double>(t.pt_end[c] - t.pt_begin[c]);
+        work[i] = nt * ns + nt * far_per_point;
+        total += work[i];
+    }
+    auto cut = [&](int r) {
+        const double goal = total * r / world;
+        double acc = 0;
+        size_t i = 0;
+        while (i < nl && acc + 0.5 * work[i] < goal) acc += work[i++];
+        return i;
+    };
+    const size_t lb = rank == 0 ? 0 : cut(rank), le = rank == world - 1 ? nl : cut(rank + 1);
+    std::fill(active.begin(), active.end(), 0);
+    for (size_t i = lb; i < le; ++i) {
+        int32_t c = src_leaves_[i];
+        while (c >= 0 && !active[c]) {
+            active[c] = 1;
+            c = t.parent[c];
+        }
+    }
+    HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
+    // M2L tiles that contain an active target (stage 2) or a source of one (stage 1)
+    std::vector<uint8_t> needed(static_cast<size_t>(C), 0);
+    for (int64_t B = 0; B < C; ++B) {
+        if (!active[B] || t.level[B] < 2) continue;
+        needed[B] = 1;
+        for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) needed[t.v.idx[q]] = 1;
+    }
+    m2l_tiles_part_h_.clear();
+    for (const M2lTileDesc &td : m2l_tiles_h_) {
+        const HostM2lClass &hc = m2l_host_[td.level_class];
+        bool any = false;
+        for (int32_t i = 0; i < td.count && !any; ++i) any = needed[hc.cells[td.first + i]] != 0;
+        if (any) m2l_tiles_part_h_.push_back(td);
+    }
+    n_m2l_tiles_part_ = static_cast<int>(m2l_tiles_part_h_.size());
+    CHK(dupload(&d_m2l_tiles_part_, m2l_tiles_part_h_));
+    // owned targets: one contiguous range of the sorted sources
+    TargetSet &ts = part_targets_;
+    const int64_t pb = lb < le ? t.pt_begin[src_leaves_[lb]] : 0;
+    const int64_t pe = lb < le ? t.pt_end[src_leaves_[le - 1]] : 0;
+    ts.m = pe - pb;
+    for (int a = 0; a < 3; ++a) ts.xyz_ptr[a] = src_ptr_[a] + pb;
+    std::vector<int32_t> perm(static_cast<size_t>(ts.m)), jc, tb, te, wjc, wtb, wte;
+    part_rows_.resize(static_cast<size_t>(ts.m));
+    for (int64_t i = 0; i < ts.m; ++i) {
+        perm[i] = static_cast<int32_t>(t.order[pb + i]);
+        part_rows_[i] = t.order[pb + i];
+    }
+    for (size_t i = lb; i < le; ++i) {
+        const int32_t c = src_leaves_[i];
+        jc.push_back(c);
+        tb.push_back(static_cast<int32_t>(t.pt_begin[c] - pb));
+        te.push_back(static_cast<int32_t>(t.pt_end[c] - pb));
+        if (t.w.ptr[c + 1] > t.w.ptr[c]) {
+            wjc.push_back(c);
+            wtb.push_back(tb.back());
+            wte.push_back(te.back());
+        }
+    }
+    ts.n_jobs = static_cast<int>(jc.size());
+    ts.n_w_jobs = static_cast<int>(wjc.size());
+    CHK(dupload(&ts.perm, perm));
+    CHK(dupload(&ts.job_cell, jc));
+    CHK(dupload(&ts.tgt_begin, tb));
+    CHK(dupload(&ts.tgt_end, te));
+    CHK(dupload(&ts.w_job_cell, wjc));
+    CHK(dupload(&ts.w_tgt_begin, wtb));
+    CHK(dupload(&ts.w_tgt_end, wte));
+    CHK(dalloc(&ts.out, static_cast<size_t>(std::max(k_cap_, 1)) * std::max<int64_t>(ts.m, 1)));
+    have_part_ = true;
+    return BBFMM_OK;
+}
+
+void FmmTree::stats(bbfmm_tree_stats *out) const {
+    const HostTree &t = tree_;
+    std::memset(out, 0, sizeof *out);
+    out->d = d_;
+    out->order = order_;
+    out->n_nodes = ops_.n;
+    out->depth = t.depth;
+    out->n_points = t.n_points;
+    out->n_cells = t.n_cells();
+    for (int64_t c = 0; c < t.n_cells(); ++c) out->n_leaves += t.is_leaf[c];
+    out->n_u = static_cast<int64_t>(t.u.idx.size());
+    out->n_v = static_cast<int64_t>(t.v.idx.size());
+    out->n_w = static_cast<int64_t>(t.w.idx.size());
+    out->n_x = static_cast<int64_t>(t.x.idx.size());
+    int64_t pairs = 0, tile_bytes = 0;
+    const int64_t per_pt = 8 * d_ + 8; // coordinates + one weight
+    for (int32_t c : src_leaves_) {
+        const int64_t nt = t.pt_end[c] - t.pt_begin[c];
+        int64_t ns = 0;
+        for (int64_t r = u_runs_.ptr[c]; r < u_runs_.ptr[c + 1]; ++r) ns += u_runs_.idx[2 * r + 1] - u_runs_.idx[2 * r];
+        pairs += nt * ns;
+        tile_bytes += (nt + ns) * per_pt;
+    }
+    out->p2p_pairs = pairs;
+    out->p2p_tile_bytes_k1 = tile_bytes;
+    out->m2l_flops_k1 = m2l_flops_k1_;
+    for (int a = 0; a < d_; ++a) out->center[a] = t.center[a];
+    out->radius = t.radius;
+}
+
+int FmmTree::debug_get_coefficients(char which, int k, double *out) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (k < 1 || k > k_cap_ || !out) return fail(BBFMM_BAD_ARGUMENT, "bad coefficient request");
+    const double *src = (which == 'M' || which == 'm') ? d_M_.p : d_L_.p;
+    const int64_t C = tree_.n_cells();
+    const int n = ops_.n, n_pad = cheb_.n_pad;
+    HIPCHK(hipStreamSynchronize(stream_));
+    HIPCHK(hipMemcpy2D(out, n * sizeof(double), src, n_pad * sizeof(double), n * sizeof(double),
+                       static_cast<size_t>(k) * C, hipMemcpyDeviceToHost));
+    return BBFMM_OK;
+}
+
+// Test hook: apply the stacked M2L tables on the host (plain loops).  Validates the table
+// construction without a GPU; never reached from a compute entry point.
+int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
+    const int n = ops_.n, n_pad = round_up(n, 16);
+    std::vector<double> cbuf(static_cast<size_t>(std::max<int64_t>(cbuf_len_, 1)), 0.0);
+    for (const HostM2lClass &hc : m2l_host_) {
+        if (hc.cells.empty()) continue;
+        if (hc.vt_all.empty()) return BBFMM_UNSUPPORTED; // tables were released after upload
+        for (size_t pos = 0; pos < hc.cells.size(); ++pos) {
+            const double *Mv = M + static_cast<size_t>(hc.cells[pos]) * n;
+            for (int row = 0; row < hc.n_rows; ++row) {
+                const int32_t slot = hc.cslot[pos * hc.n_t + hc.row_tpos[row]];
+                if (slot < 0) continue;
+                double s = 0.0;
+                for (int m = 0; m < n; ++m) s += hc.vt_all[static_cast<size_t>(m) * hc.r_pad16 + row] * Mv[m];
+                cbuf[static_cast<size_t>(slot) * 4 + hc.row_off[row]] = s;
+            }
+        }
+    }
+    for (const HostM2lClass &hc : m2l_host_) {
+        for (size_t pos = 0; pos < hc.cells.size(); ++pos) {
+            double *Lb = L + static_cast<size_t>(hc.cells[pos]) * n;
+            const double *cc = &cbuf[static_cast<size_t>(hc.cbase[pos])];
+            for (int i = 0; i < n; ++i) {
+                double s = 0.0;
+                for (int k = 0; k < hc.k_pad; ++k) s += hc.u_all[static_cast<size_t>(k) * n_pad + i] * cc[k];
+                Lb[i] += s;
+            }
+        }
+    }
+    return BBFMM_OK;
+}
+
+} // namespace bbfmm

@@ -1,0 +1,178 @@
+// FmmTree: host-side mirror of ferreus_rbf_utils::FmmTree (utils.rs:383-494), i.e. of
+// ferreus_bbfmm::FmmTree<K> for the closed kernel set (bbfmm.rs:194-616).  Owns the
+// host tree / operators and all device state; every pass runs on the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "device.hpp"
+#include "ferreus_bbfmm_hip.h"
+#include "kernels.hpp"
+#include "operators.hpp"
+#include "tree.hpp"
+
+namespace bbfmm {
+
+enum Phase {
+    kPhGather = 0, kPhP2M, kPhM2M, kPhM2L1, kPhM2L2, kPhP2L, kPhL2L, kPhP2P, kPhM2P, kPhL2P, kPhScatter,
+    kNumPhases
+};
+static_assert(kNumPhases == BBFMM_N_PHASES, "phase table");
+
+// RAII-free device buffer helper (freed in ~FmmTree).
+template <class T> struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+};
+
+// Host copy of one (level, octant class) M2L table set; see device.hpp M2lClass.
+struct HostM2lClass {
+    int level = 0, octant = 0;
+    int n_rows = 0, r_pad16 = 16, n_t = 0, k_pad = 16;
+    std::vector<double> vt_all, u_all; // kept only on BBFMM_FLAG_HOST_ONLY handles
+    std::vector<int> src_tv, tgt_tv, tgt_off; // transfer vectors (source / target side), slot offsets
+    std::vector<int32_t> row_tpos, row_off, cells, cslot;
+    std::vector<int64_t> cbase;
+};
+
+struct TargetSet { // targets sorted by leaf, resident on the device
+    int64_t m = 0;
+    DevBuf<double> xyz[3];
+    const double *xyz_ptr[3] = {nullptr, nullptr, nullptr};
+    DevBuf<int32_t> perm;      // sorted position -> caller's row
+    DevBuf<int32_t> job_cell, tgt_begin, tgt_end; // leaves with targets
+    int n_jobs = 0;
+    DevBuf<int32_t> w_job_cell, w_tgt_begin, w_tgt_end; // ... that also have a W list
+    int n_w_jobs = 0;
+    DevBuf<double> out, grad;  // K x m, K*d x m (sorted order)
+};
+
+class FmmTree {
+  public:
+    FmmTree() = default;
+    ~FmmTree();
+    FmmTree(const FmmTree &) = delete;
+    FmmTree &operator=(const FmmTree &) = delete;
+
+    // FmmTree::new (bbfmm.rs:272-353)
+    int create(const double *pts, int64_t n, int d, int64_t ld, int order, int kernel_type, double base_range,
+               double total_sill, bool adaptive, bool sparse, const double *extents, const bbfmm_params *params,
+               uint32_t flags);
+    int set_weights(const double *w, int64_t rows, int k, int64_t ldw);                 // bbfmm.rs:383-401
+    int set_local_coefficients(const double *w, int64_t rows, int k, int64_t ldw);      // bbfmm.rs:518-524
+    int evaluate(const double *w, int64_t rows, int k, int64_t ldw, const double *x, int64_t m, int64_t ldx,
+                 double *out, int64_t ldo, double *grad, int64_t ldg, bool with_grads, bool leaves_only,
+                 int64_t *bad_point_index);                                             // bbfmm.rs:444-616
+    int fast_matrix_vector_product(const double *w, int64_t rows, int64_t basis_size, const int64_t *target_indices,
+                                   int64_t n_target_indices, const double *poly, int64_t ldp, double nugget,
+                                   double *result);                                     // rbf.rs:1338-1379
+    int matvec_device(const double *d_w, int64_t ldw, int k, double *d_out, int64_t ldo, bool sync);
+    int set_partition(int rank, int world);
+
+    const HostTree &tree() const { return tree_; }
+    const Operators &ops() const { return ops_; }
+    const std::vector<double> &source_points() const { return pts_; } // n x d column-major, ld = n
+    int order() const { return order_; }
+    const char *last_error() const { return err_.c_str(); }
+    hipStream_t stream() const { return stream_; }
+    bool host_only() const { return host_only_; }
+    void stats(bbfmm_tree_stats *out) const;
+    void set_profiling(bool on) { profiling_ = on; }
+    const double *phase_ms() const { return phase_ms_; }
+    void reset_phase_ms() { for (double &v : phase_ms_) v = 0.0; }
+    const std::vector<int64_t> &partition_rows() const { return part_rows_; }
+    const std::vector<HostM2lClass> &m2l_host() const { return m2l_host_; }
+    // Test hook (host loops over the stacked M2L tables; needs BBFMM_FLAG_HOST_ONLY).
+    // M, L: n_cells x n (cell-major, one rhs).  L is accumulated into.
+    int debug_apply_m2l_tables_host(const double *M, double *L) const;
+    int debug_get_coefficients(char which, int k, double *out);
+
+  private:
+    int fail(int code, const std::string &msg);
+    int hip_fail(hipError_t e, const char *what);
+    int upload();
+    int build_m2l_tables();
+    void fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<double> *vt_all,
+                                  std::vector<double> *u_all) const;
+    int ensure_rhs_capacity(int k);
+    int upward(int k);                                  // P2M + M2M from w_sorted_
+    int downward(int k);                                // M2L + P2L + L2L into L_
+    int leaf_pass(const TargetSet &ts, int k, bool with_grads);
+    int build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index);
+    int build_source_target_set();
+    void free_target_set(TargetSet *ts);
+    int upload_weights(const double *w, int64_t rows, int k, int64_t ldw);
+    void phase_begin();
+    void phase_end(int ph);
+
+    // ---- host state
+    std::string err_;
+    bool host_only_ = false;
+    int order_ = 0, d_ = 0;
+    KernelSpec kernel_{};
+    bbfmm_params params_{};
+    std::vector<double> pts_;
+    HostTree tree_;
+    Operators ops_;
+    int nrhs_ = 0;           // set by set_weights (bbfmm.rs:384); 0 = no weights yet
+    bool have_locals_ = false;
+    // leaf-pass run lists per cell (merged sorted-source ranges)
+    Csr u_runs_;             // ptr per cell, idx = 2 ints per run
+    Csr x_runs_;
+    std::vector<int32_t> src_leaves_;                   // leaves with sources
+    std::vector<std::vector<int32_t>> m2m_parents_;     // per level: cells with children
+    std::vector<std::vector<int32_t>> level_cells_;     // per level
+    std::vector<int32_t> x_cells_;                      // cells with an X list
+    // M2L tables (host copies kept for stats / tests)
+    std::vector<HostM2lClass> m2l_host_;
+    std::vector<M2lClass> m2l_classes_h_;
+    std::vector<M2lTileDesc> m2l_tiles_h_;
+    int64_t cbuf_len_ = 0;
+    double m2l_flops_k1_ = 0;
+    // partition
+    int part_rank_ = 0, part_world_ = 1;
+    std::vector<int64_t> part_rows_;
+    std::vector<M2lTileDesc> m2l_tiles_part_h_;
+
+    // ---- device state
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_[2] = {nullptr, nullptr};
+    bool profiling_ = false;
+    double phase_ms_[kNumPhases] = {0};
+    std::vector<void *> owned_; // every hipMalloc'd pointer, freed in the destructor
+    template <class T> int dalloc(DevBuf<T> *b, size_t n, bool zero = false);
+    template <class T> int dupload(DevBuf<T> *b, const std::vector<T> &v);
+    template <class T> void dfree(DevBuf<T> *b);
+
+    ChebRef cheb_{};
+    DevBuf<DevCheb> d_cheb_;
+    DevBuf<double> d_src_[3];
+    const double *src_ptr_[3] = {nullptr, nullptr, nullptr};
+    DevBuf<double> d_zero_axis_;
+    DevBuf<int32_t> d_order_;
+    DevBuf<double> d_centers_, d_lengths_;
+    DevBuf<int32_t> d_pt_begin_, d_pt_end_, d_parent_, d_octant_;
+    DevBuf<int64_t> d_child_ptr_;
+    DevBuf<int32_t> d_child_idx_;
+    DevBuf<int32_t> d_src_leaves_;
+    std::vector<DevBuf<int32_t>> d_m2m_parents_, d_level_cells_;
+    DevBuf<int64_t> d_u_run_ptr_, d_x_run_ptr_, d_w_ptr_;
+    DevBuf<int32_t> d_u_runs_, d_x_runs_, d_w_idx_, d_x_cells_;
+    DevBuf<int64_t> d_x_job_run_ptr_;
+    DevBuf<M2lClass> d_m2l_classes_;
+    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles_part_;
+    int n_m2l_tiles_part_ = 0;
+    DevBuf<uint8_t> d_active_;
+    // per-rhs-capacity buffers
+    int k_cap_ = 0;
+    DevBuf<double> d_w_in_, d_w_sorted_, d_M_, d_L_, d_cbuf_, d_out_;
+    int64_t w_in_rows_ = 0;
+    TargetSet src_targets_;  // targets = sources (the matvec)
+    TargetSet part_targets_; // sources owned by this rank (multi-GPU)
+    bool have_part_ = false;
+};
+
+} // namespace bbfmm

@@ -1,0 +1,55 @@
+// Minimal host thread pool helper: dynamic chunked parallel_for over [0, n).
+// (The reference parallelises its host loops with rayon; this plays that role for
+// the host-side tree / list / operator setup.  No OpenMP runtime dependency.)
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cstdint>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+namespace bbfmm {
+
+inline int host_threads() {
+    static int n = [] {
+        if (const char *e = std::getenv("BBFMM_HOST_THREADS")) {
+            const int v = std::atoi(e);
+            if (v > 0) return v;
+        }
+        const unsigned hc = std::thread::hardware_concurrency();
+        return static_cast<int>(hc == 0 ? 1 : std::min(hc, 64u));
+    }();
+    return n;
+}
+
+// fn(begin, end) is called on disjoint chunks.
+template <class F> void parallel_for_chunks(int64_t n, int64_t chunk, F &&fn) {
+    if (n <= 0) return;
+    const int nt = static_cast<int>(std::min<int64_t>(host_threads(), (n + chunk - 1) / chunk));
+    if (nt <= 1) {
+        fn(int64_t(0), n);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    auto worker = [&]() {
+        while (true) {
+            const int64_t b = next.fetch_add(chunk);
+            if (b >= n) break;
+            fn(b, std::min(n, b + chunk));
+        }
+    };
+    std::vector<std::thread> threads;
+    threads.reserve(nt - 1);
+    for (int i = 0; i < nt - 1; ++i) threads.emplace_back(worker);
+    worker();
+    for (auto &t : threads) t.join();
+}
+
+template <class F> void parallel_for(int64_t n, int64_t chunk, F &&fn) {
+    parallel_for_chunks(n, chunk, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) fn(i);
+    });
+}
+
+} // namespace bbfmm

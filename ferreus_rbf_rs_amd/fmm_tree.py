@@ -1,0 +1,398 @@
+"""Python host-side mirror of the reference's evaluator API over the C ABI.
+
+Mirrors the only existing foreign-language binding of the seam, `py_ferreus_bbfmm`
+(py_ferreus_bbfmm/src/python_bindings.rs:66-390): same class names, constructor
+arguments, method names, array conventions and error behaviour, so the parity
+tests read like the reference's examples.  All compute goes through
+libferreus_bbfmm_hip.so (HIP kernels); nothing here computes potentials.
+"""
+from __future__ import annotations
+
+import ctypes
+import enum
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+class KernelType(enum.IntEnum):
+    """ferreus_rbf_utils::KernelType (ferreus_rbf_utils/src/utils.rs:558-571)."""
+    LinearRbf = 0
+    ThinPlateSplineRbf = 1
+    CubicRbf = 2
+    Spheroidal3Rbf = 3
+    Spheroidal5Rbf = 4
+    Spheroidal7Rbf = 5
+    Spheroidal9Rbf = 6
+    Laplacian = 7
+    OneOverR2 = 8
+    OneOverR4 = 9
+    # extension kernels of this repository (not in the reference)
+    GaussianExt = 100
+    MultiquadricExt = 101
+
+
+class FmmKernelType(enum.Enum):
+    """py_ferreus_bbfmm FmmKernelType (python_bindings.rs:66-76) + the two extensions."""
+    LinearRbf = "LinearRbf"
+    ThinPlateSplineRbf = "ThinPlateSplineRbf"
+    CubicRbf = "CubicRbf"
+    SpheroidalRbf = "SpheroidalRbf"
+    Laplacian = "Laplacian"
+    OneOverR2 = "OneOverR2"
+    OneOverR4 = "OneOverR4"
+    GaussianExt = "GaussianExt"
+    MultiquadricExt = "MultiquadricExt"
+
+
+class SpheroidalOrder(enum.Enum):
+    """python_bindings.rs:78-85"""
+    Three = 3
+    Five = 5
+    Seven = 7
+    Nine = 9
+
+
+class M2LCompressionType(enum.IntEnum):
+    """ferreus_bbfmm::M2LCompressionType (bbfmm.rs:62-73; python name None_)."""
+    None_ = 0
+    SVD = 1
+    ACA = 2
+
+
+class FmmParams:
+    """FmmParams (bbfmm.rs:77-104; python_bindings.rs:106-131)."""
+
+    def __init__(self, max_points_per_cell: int, compression_type: M2LCompressionType,
+                 epsilon: float, eval_chunk_size: int):
+        self.max_points_per_cell = int(max_points_per_cell)
+        self.compression_type = M2LCompressionType(compression_type)
+        self.epsilon = float(epsilon)
+        self.eval_chunk_size = int(eval_chunk_size)
+
+    @staticmethod
+    def new_defaults(interpolation_order: int) -> "FmmParams":
+        p = L.Params()
+        L.load().bbfmm_params_defaults(interpolation_order, ctypes.byref(p))
+        return FmmParams(p.max_points_per_cell, M2LCompressionType(p.compression_type), p.epsilon,
+                         p.eval_chunk_size)
+
+    def _c(self) -> L.Params:
+        return L.Params(self.max_points_per_cell, int(self.compression_type), self.epsilon,
+                        self.eval_chunk_size)
+
+
+class KernelParams:
+    """KernelParams (kernel_helpers.rs:17-79; python_bindings.rs:133-188)."""
+
+    def __init__(self, kernel_type, *, spheroidal_order: Optional[SpheroidalOrder] = None,
+                 base_range: Optional[float] = None, total_sill: Optional[float] = None):
+        if isinstance(kernel_type, KernelType):
+            kt = kernel_type
+        else:
+            kernel_type = FmmKernelType(kernel_type)
+            if kernel_type is FmmKernelType.SpheroidalRbf:
+                order = spheroidal_order if spheroidal_order is not None else SpheroidalOrder.Three
+                kt = {3: KernelType.Spheroidal3Rbf, 5: KernelType.Spheroidal5Rbf,
+                      7: KernelType.Spheroidal7Rbf, 9: KernelType.Spheroidal9Rbf}[
+                    SpheroidalOrder(order).value]
+            else:
+                kt = KernelType[kernel_type.name]
+        self.kernel_type = kt
+        self.base_range = 1.0 if base_range is None else float(base_range)     # builder defaults,
+        self.total_sill = 1.0 if total_sill is None else float(total_sill)     # kernel_helpers.rs:25-31
+        # KernelParamsBuilder::build asserts (kernel_helpers.rs:69-70)
+        assert self.base_range > 0.0
+        assert self.total_sill <= self.base_range
+
+
+class FmmError(ValueError):
+    """FmmError (bbfmm.rs:20-45); the PyO3 binding raises ValueError with these messages."""
+
+
+class PointOutsideTree(FmmError):
+    def __init__(self, point_index: int, leaf: bool = False):
+        what = "FMM leaf evaluation failed" if leaf else "FMM evaluation failed"
+        super().__init__(f"{what}: target point at row {point_index} lies outside the tree extents")
+        self.point_index = point_index
+
+
+class KernelDoesNotSupportGradients(FmmError):
+    def __init__(self):
+        super().__init__("FMM evaluation failed: gradient evaluation requested but kernel does "
+                         "not support gradients")
+
+
+def _as_f64_2d(a, name):
+    """numpy_to_matref (python_bindings.rs:20-36): 1-D or 2-D float64."""
+    arr = np.asarray(a)
+    if arr.dtype != np.float64 or arr.ndim not in (1, 2):
+        raise TypeError(f"Expected a 1D/2D float64 array for {name}")
+    if arr.ndim == 1:
+        arr = arr[:, None]
+    return np.asfortranarray(arr)
+
+
+class FmmTree:
+    """ferreus_rbf_utils::FmmTree (utils.rs:383-494) / py FmmTree (python_bindings.rs:191-390)."""
+
+    def __init__(self, source_points, interpolation_order: int, kernel_params: KernelParams,
+                 adaptive_tree: bool, sparse: bool, *, extents=None,
+                 params: Optional[FmmParams] = None, host_only: bool = False):
+        lib = L.load()
+        pts = _as_f64_2d(source_points, "source_points")
+        n, d = pts.shape
+        ext = None
+        if extents is not None:
+            ext = np.ascontiguousarray(np.asarray(extents, dtype=np.float64).reshape(-1))
+            d = len(ext) // 2                       # bbfmm.rs:291
+        cpar = params._c() if params is not None else None
+        h = ctypes.c_void_p()
+        rc = lib.bbfmm_create(pts.ctypes.data, n, d, n, int(interpolation_order),
+                              int(kernel_params.kernel_type), kernel_params.base_range,
+                              kernel_params.total_sill, int(bool(adaptive_tree)), int(bool(sparse)),
+                              ext.ctypes.data if ext is not None else None,
+                              ctypes.byref(cpar) if cpar is not None else None,
+                              L.FLAG_HOST_ONLY if host_only else 0, ctypes.byref(h))
+        self._h = h
+        self._lib = lib
+        if rc != L.OK:
+            msg = lib.bbfmm_last_error(h).decode() if h else "bbfmm_create failed"
+            if h:
+                lib.bbfmm_destroy(h)
+                self._h = None
+            if rc == L.DEVICE_ERROR:
+                raise RuntimeError(msg)
+            raise ValueError(msg)              # the reference panics
+        self.interpolation_order = int(interpolation_order)
+        self.kernel_params = kernel_params
+        self.adaptive_tree = bool(adaptive_tree)
+        self.sparse = bool(sparse)
+        self.n_points = n
+        self.dim = d
+        self._nrhs = 0
+        self._compressed = params is None or params.compression_type != M2LCompressionType.None_
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.bbfmm_destroy(h)
+            self._h = None
+
+    # -- errors
+    def _raise(self, rc, bad=None, leaf=False):
+        if rc == L.OK:
+            return
+        msg = self._lib.bbfmm_last_error(self._h).decode()
+        if rc == L.POINT_OUTSIDE_TREE:
+            raise PointOutsideTree(int(bad.value), leaf)
+        if rc == L.KERNEL_NO_GRADIENTS:
+            raise KernelDoesNotSupportGradients()
+        if rc == L.DEVICE_ERROR:
+            raise RuntimeError(msg)
+        raise ValueError(msg)
+
+    # -- API
+    def set_weights(self, weights) -> None:
+        w = _as_f64_2d(weights, "weights")
+        self._raise(self._lib.bbfmm_set_weights(self._h, w.ctypes.data, w.shape[0], w.shape[1],
+                                                w.shape[0]))
+        self._nrhs = w.shape[1]
+
+    def set_local_coefficients(self, weights) -> None:
+        w = _as_f64_2d(weights, "weights")
+        self._raise(self._lib.bbfmm_set_local_coefficients(self._h, w.ctypes.data, w.shape[0],
+                                                           w.shape[1], w.shape[0]))
+
+    def _eval(self, fn, weights, target_points, grads, leaf):
+        w = _as_f64_2d(weights, "weights")
+        x = _as_f64_2d(target_points, "target_points")
+        m, k = x.shape[0], w.shape[1]
+        out = np.zeros((m, k), order="F")
+        bad = ctypes.c_int64(-1)
+        if grads:
+            g = np.zeros((m, k * self.dim), order="F")
+            rc = fn(self._h, w.ctypes.data, w.shape[0], k, w.shape[0], x.ctypes.data, m, max(m, 1),
+                    out.ctypes.data, max(m, 1), g.ctypes.data, max(m, 1), ctypes.byref(bad))
+            self._raise(rc, bad, leaf)
+            return out, g
+        rc = fn(self._h, w.ctypes.data, w.shape[0], k, w.shape[0], x.ctypes.data, m, max(m, 1),
+                out.ctypes.data, max(m, 1), ctypes.byref(bad))
+        self._raise(rc, bad, leaf)
+        return out
+
+    def evaluate(self, weights, target_points):
+        return self._eval(self._lib.bbfmm_evaluate, weights, target_points, False, False)
+
+    def evaluate_with_gradients(self, weights, target_points):
+        return self._eval(self._lib.bbfmm_evaluate_with_gradients, weights, target_points, True, False)
+
+    def evaluate_leaves(self, weights, target_points):
+        return self._eval(self._lib.bbfmm_evaluate_leaves, weights, target_points, False, True)
+
+    def evaluate_leaves_with_gradients(self, weights, target_points):
+        return self._eval(self._lib.bbfmm_evaluate_leaves_with_gradients, weights, target_points,
+                          True, True)
+
+    def source_points(self):
+        out = np.zeros((self.n_points, self.dim), order="F")
+        self._raise(self._lib.bbfmm_source_points(self._h, out.ctypes.data, self.n_points))
+        return out
+
+    # -- the FGMRES matvec (ferreus_rbf/src/rbf.rs:1338-1379)
+    def fast_matrix_vector_product(self, weights, basis_size=0, target_indices=None,
+                                   polynomial_matrix=None, nugget=0.0):
+        w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64).reshape(-1))
+        res = np.zeros_like(w)
+        idx = None
+        if target_indices is not None:
+            idx = np.ascontiguousarray(np.asarray(target_indices, dtype=np.int64))
+        poly = None
+        if polynomial_matrix is not None:
+            poly = np.asfortranarray(np.asarray(polynomial_matrix, dtype=np.float64))
+        rc = self._lib.bbfmm_fast_matrix_vector_product(
+            self._h, w.ctypes.data, len(w), int(basis_size),
+            idx.ctypes.data if idx is not None else None, len(idx) if idx is not None else 0,
+            poly.ctypes.data if poly is not None else None,
+            poly.shape[0] if poly is not None else 0, float(nugget), res.ctypes.data)
+        self._raise(rc)
+        return res
+
+    # -- device-resident matvec (what bench.py times); d_w / d_out are device pointers
+    def matvec_device(self, d_w_ptr: int, ldw: int, k: int, d_out_ptr: int, ldo: int, sync=True):
+        self._raise(self._lib.bbfmm_matvec_device(self._h, d_w_ptr, ldw, k, d_out_ptr, ldo,
+                                                  int(sync)))
+
+    def stream(self) -> int:
+        return int(self._lib.bbfmm_stream(self._h) or 0)
+
+    def set_partition(self, rank: int, world: int):
+        self._raise(self._lib.bbfmm_set_partition(self._h, rank, world))
+
+    def partition_rows(self) -> np.ndarray:
+        n = self._lib.bbfmm_partition_row_count(self._h)
+        rows = np.zeros(n, dtype=np.int64)
+        self._raise(self._lib.bbfmm_partition_rows(self._h, rows.ctypes.data))
+        return rows
+
+    def set_profiling(self, on: bool):
+        self._lib.bbfmm_set_profiling(self._h, int(on))
+
+    def phase_ms(self, reset=False) -> dict:
+        ms = (ctypes.c_double * L.N_PHASES)()
+        self._lib.bbfmm_get_phase_ms(self._h, ms)
+        if reset:
+            self._lib.bbfmm_reset_phase_ms(self._h)
+        return dict(zip(L.PHASE_NAMES, list(ms)))
+
+    # -- introspection
+    def stats(self) -> L.TreeStats:
+        s = L.TreeStats()
+        self._raise(self._lib.bbfmm_get_tree_stats(self._h, ctypes.byref(s)))
+        return s
+
+    def cells(self):
+        s = self.stats()
+        keys = np.zeros(s.n_cells, dtype=np.uint64)
+        leaf = np.zeros(s.n_cells, dtype=np.uint8)
+        self._raise(self._lib.bbfmm_get_cells(self._h, keys.ctypes.data, leaf.ctypes.data))
+        return keys, leaf
+
+    def leaf_sources(self):
+        s = self.stats()
+        ptr = np.zeros(s.n_cells + 1, dtype=np.int64)
+        idx = np.zeros(max(s.n_points, 1), dtype=np.int64)
+        self._raise(self._lib.bbfmm_get_leaf_sources(self._h, ptr.ctypes.data, idx.ctypes.data))
+        return ptr, idx[:ptr[-1]]
+
+    def interaction_list(self, which: str):
+        s = self.stats()
+        n = ctypes.c_int64(0)
+        self._raise(self._lib.bbfmm_get_list(self._h, which.encode()[0:1], None, None, ctypes.byref(n)))
+        ptr = np.zeros(s.n_cells + 1, dtype=np.int64)
+        idx = np.zeros(max(n.value, 1), dtype=np.int32)
+        self._raise(self._lib.bbfmm_get_list(self._h, which.encode()[0:1], ptr.ctypes.data,
+                                             idx.ctypes.data, ctypes.byref(n)))
+        return ptr, idx[:n.value]
+
+    def m2l_ranks(self):
+        s = self.stats()
+        nref = ctypes.c_int32(0)
+        self._raise(self._lib.bbfmm_get_m2l_ranks(self._h, None, ctypes.byref(nref)))
+        ranks = np.zeros((s.depth + 1, nref.value), dtype=np.int32)
+        self._raise(self._lib.bbfmm_get_m2l_ranks(self._h, ranks.ctypes.data, ctypes.byref(nref)))
+        return ranks
+
+    def m2l_operator(self, level: int, ref: int):
+        n = self.stats().n_nodes
+        out = np.zeros((n, n), order="F")
+        self._raise(self._lib.bbfmm_get_m2l_operator(self._h, level, ref, out.ctypes.data))
+        return out
+
+    def m2l_factors(self, level: int, ref: int):
+        """(U [n x r], Vt [r x n] or None) of one reference operator."""
+        n = self.stats().n_nodes
+        r = int(self.m2l_ranks()[level, ref])
+        u = np.zeros((n, r), order="F")
+        compressed = r < n or self._compressed
+        vt = np.zeros((r, n), order="F") if compressed else None
+        self._raise(self._lib.bbfmm_get_m2l_factors(self._h, level, ref, u.ctypes.data,
+                                                    vt.ctypes.data if vt is not None else None))
+        return u, vt
+
+    def permutation_tables(self):
+        n = self.stats().n_nodes
+        nperm = ctypes.c_int32(0)
+        self._raise(self._lib.bbfmm_get_permutation_tables(self._h, ctypes.byref(nperm), None, None,
+                                                           None, None))
+        nvec = 7 ** self.dim
+        perm = np.zeros((nperm.value, n), dtype=np.int32)
+        inv = np.zeros((nperm.value, n), dtype=np.int32)
+        pl = np.zeros(nvec, dtype=np.int32)
+        rl = np.zeros(nvec, dtype=np.int32)
+        self._raise(self._lib.bbfmm_get_permutation_tables(
+            self._h, ctypes.byref(nperm), perm.ctypes.data, inv.ctypes.data, pl.ctypes.data,
+            rl.ctypes.data))
+        return perm, inv, pl, rl
+
+    def points_to_leaves(self, x):
+        x = _as_f64_2d(x, "target_points")
+        m = x.shape[0]
+        cells = np.zeros(max(m, 1), dtype=np.int32)
+        bad = ctypes.c_int64(-1)
+        rc = self._lib.bbfmm_points_to_leaves(self._h, x.ctypes.data, m, max(m, 1),
+                                              cells.ctypes.data, ctypes.byref(bad))
+        self._raise(rc, bad)
+        return cells[:m]
+
+    def debug_dense_m2m(self, child_index: int):
+        n = self.stats().n_nodes
+        out = np.zeros((n, n), order="F")
+        self._raise(self._lib.bbfmm_debug_dense_m2m(self._h, child_index, out.ctypes.data))
+        return out
+
+    def debug_get_coefficients(self, which: str, k: int) -> np.ndarray:
+        s = self.stats()
+        out = np.zeros((k, s.n_cells, s.n_nodes))
+        self._raise(self._lib.bbfmm_debug_get_coefficients(self._h, which.encode()[0:1], k,
+                                                           out.ctypes.data))
+        return out
+
+    def debug_apply_m2l_tables_host(self, M: np.ndarray) -> np.ndarray:
+        M = np.ascontiguousarray(M, dtype=np.float64)
+        Lc = np.zeros_like(M)
+        self._raise(self._lib.bbfmm_debug_apply_m2l_tables_host(self._h, M.ctypes.data,
+                                                                Lc.ctypes.data))
+        return Lc
+
+
+def mfma_f64_selftest():
+    """(measured FP64 MFMA TFLOP/s, lane-layout mismatches) on the current device."""
+    tf = ctypes.c_double(0)
+    errs = ctypes.c_int32(-1)
+    rc = L.load().bbfmm_mfma_f64_selftest(ctypes.byref(tf), ctypes.byref(errs))
+    if rc != L.OK:
+        raise RuntimeError("MFMA self-test needs a HIP device")
+    return tf.value, errs.value

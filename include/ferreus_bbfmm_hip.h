@@ -1,0 +1,247 @@
+/*
+ * ferreus_bbfmm_hip.h -- C ABI of the MI355X-native BBFMM evaluator.
+ *
+ * Drop-in boundary for the hot path of graphic-goose/ferreus_rbf_rs: the
+ * `ferreus_bbfmm` matrix-vector product behind the type-erased evaluator
+ * `ferreus_rbf_utils::FmmTree` (ferreus_rbf_utils/src/utils.rs:383-494).  The
+ * reference has no FFI for this path; every entry point below cites the Rust
+ * method it replaces (paths relative to the reference repository root).  A
+ * Rust `extern "C"` shim / ctypes stub binding these symbols is shown in
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *   - all matrices are f64, column-major with an explicit leading dimension
+ *     (faer::Mat layout); `pts` are N x d (column a at pts + a*ld).
+ *   - one in-flight call per handle (the reference wraps the tree in a Mutex,
+ *     ferreus_rbf/src/rbf.rs:87,106,124); a handle may be used from any thread.
+ *   - nothing throws across the ABI; every function returns a bbfmm_status.
+ *   - the library fails loudly (BBFMM_DEVICE_ERROR) when no HIP device is
+ *     usable: there is no CPU fallback for the compute entry points.
+ */
+#ifndef FERREUS_BBFMM_HIP_H
+#define FERREUS_BBFMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Return codes.  1 and 2 mirror FmmError (ferreus_bbfmm/src/bbfmm.rs:20-27). */
+typedef enum {
+    BBFMM_OK = 0,
+    BBFMM_POINT_OUTSIDE_TREE = 1,         /* FmmError::PointOutsideTree{point_index} */
+    BBFMM_KERNEL_NO_GRADIENTS = 2,        /* FmmError::KernelDoesNotSupportGradients */
+    BBFMM_BAD_ARGUMENT = 3,               /* the reference panics (e.g. bbfmm.rs:293-298) */
+    BBFMM_DEVICE_ERROR = 4,               /* HIP failure or no device */
+    BBFMM_UNSUPPORTED = 5                 /* valid in the reference, not built here yet */
+} bbfmm_status;
+
+/* KernelType, in registry order (ferreus_rbf_utils/src/utils.rs:558-571).
+ * Ids >= 100 are extension kernels of this repository that the reference does
+ * not ship (BASELINE.json configs name them); their only oracle is the dense sum. */
+typedef enum {
+    BBFMM_KERNEL_LINEAR_RBF = 0,
+    BBFMM_KERNEL_THIN_PLATE_SPLINE_RBF = 1,
+    BBFMM_KERNEL_CUBIC_RBF = 2,
+    BBFMM_KERNEL_SPHEROIDAL3_RBF = 3,
+    BBFMM_KERNEL_SPHEROIDAL5_RBF = 4,
+    BBFMM_KERNEL_SPHEROIDAL7_RBF = 5,
+    BBFMM_KERNEL_SPHEROIDAL9_RBF = 6,
+    BBFMM_KERNEL_LAPLACIAN = 7,
+    BBFMM_KERNEL_ONE_OVER_R2 = 8,
+    BBFMM_KERNEL_ONE_OVER_R4 = 9,
+    BBFMM_KERNEL_GAUSSIAN_EXT = 100,      /* exp(-(r/base_range)^2)      -- extension */
+    BBFMM_KERNEL_MULTIQUADRIC_EXT = 101   /* sqrt(1+(r/base_range)^2)    -- extension */
+} bbfmm_kernel_type;
+
+/* M2LCompressionType (ferreus_bbfmm/src/bbfmm.rs:62-73). */
+typedef enum {
+    BBFMM_COMPRESSION_NONE = 0,
+    BBFMM_COMPRESSION_SVD = 1,
+    BBFMM_COMPRESSION_ACA = 2
+} bbfmm_compression_type;
+
+/* FmmParams (ferreus_bbfmm/src/bbfmm.rs:77-104). */
+typedef struct {
+    int64_t max_points_per_cell;   /* default 256 */
+    int32_t compression_type;      /* bbfmm_compression_type, default ACA */
+    double epsilon;                /* default 10^-interpolation_order */
+    int64_t eval_chunk_size;       /* default 1024 (host chunking knob of the reference; kept for API parity) */
+} bbfmm_params;
+
+/* Fills FmmParams::new_defaults(interpolation_order) (bbfmm.rs:96-103). */
+void bbfmm_params_defaults(int32_t interpolation_order, bbfmm_params *out);
+
+typedef struct bbfmm_handle bbfmm_handle;
+
+/* Creation flags. */
+#define BBFMM_FLAG_HOST_ONLY 1u /* build tree/lists/operators on the host only; no device is
+                                   touched and every compute call returns BBFMM_DEVICE_ERROR.
+                                   Used by the CPU-side structure tests. */
+
+/*
+ * FmmTree::new (ferreus_rbf_utils/src/utils.rs:392-421 -> ferreus_bbfmm/src/bbfmm.rs:272-353).
+ * Copies the points (the caller keeps its buffer), builds the Morton tree, the
+ * U/V/W/X lists and the M2L operators on the host and uploads them.
+ *   pts       N x d column-major, leading dimension ld (>= n)
+ *   extents   NULL (computed from the data, bbfmm.rs:281-284) or 2*d values
+ *             [mins..., maxs...]
+ *   params    NULL -> FmmParams::new_defaults(order)
+ * d must be 1, 2 or 3 (bbfmm.rs:293-298).
+ */
+int bbfmm_create(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t interpolation_order,
+                 int32_t kernel_type, double base_range, double total_sill, int32_t adaptive_tree,
+                 int32_t sparse, const double *extents, const bbfmm_params *params,
+                 uint32_t flags, bbfmm_handle **out);
+
+void bbfmm_destroy(bbfmm_handle *h);
+
+/* Message of the last failure on this handle ("" if none). Owned by the handle. */
+const char *bbfmm_last_error(const bbfmm_handle *h);
+
+/* FmmTree::set_weights (utils.rs:425-429 -> bbfmm.rs:383-401): upward pass.
+ * w is rows x k (rows >= N; only rows < N are read), leading dimension ldw. */
+int bbfmm_set_weights(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw);
+
+/* FmmTree::set_local_coefficients (utils.rs:433-437 -> bbfmm.rs:518-524). */
+int bbfmm_set_local_coefficients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k,
+                                 int64_t ldw);
+
+/* FmmTree::evaluate (utils.rs:441-449 -> bbfmm.rs:411-418): downward pass restricted
+ * to the ancestors of the target leaves + leaf pass.  x is m x d (ldx), out is
+ * m x k (ldo), caller allocated.  On BBFMM_POINT_OUTSIDE_TREE *bad_point_index
+ * receives the smallest offending row (linear_tree.rs:505-517). */
+int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
+                   const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo,
+                   int64_t *bad_point_index);
+
+/* FmmTree::evaluate_with_gradients (utils.rs:453-461 -> bbfmm.rs:434-441).
+ * grad is m x (k*d), columns [rhs0_dx, rhs0_dy, rhs0_dz, rhs1_dx, ...]. */
+int bbfmm_evaluate_with_gradients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k,
+                                  int64_t ldw, const double *x, int64_t m, int64_t ldx,
+                                  double *out, int64_t ldo, double *grad, int64_t ldg,
+                                  int64_t *bad_point_index);
+
+/* FmmTree::evaluate_leaves (utils.rs:465-473 -> bbfmm.rs:537-544): leaf pass only,
+ * after bbfmm_set_local_coefficients. */
+int bbfmm_evaluate_leaves(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
+                          const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo,
+                          int64_t *bad_point_index);
+
+/* FmmTree::evaluate_leaves_with_gradients (utils.rs:477-485 -> bbfmm.rs:560-567). */
+int bbfmm_evaluate_leaves_with_gradients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k,
+                                         int64_t ldw, const double *x, int64_t m, int64_t ldx,
+                                         double *out, int64_t ldo, double *grad, int64_t ldg,
+                                         int64_t *bad_point_index);
+
+/* FmmTree::source_points (utils.rs:489-493): copies the N x d points to out (ld). */
+int bbfmm_source_points(const bbfmm_handle *h, double *out, int64_t ld);
+
+/*
+ * The FGMRES matvec, ferreus_rbf/src/rbf.rs:1338-1379 (fast_matrix_vector_product):
+ *   set_weights(w); y = evaluate(w, source_points[target_indices])
+ *   result[i] = y + nugget*w[i] + P[i,:] * w[N..N+basis_size]   for i in target_indices,
+ *   every other row of result (incl. the last basis_size rows) = 0.
+ * w and result have N + basis_size rows, one column.  target_indices NULL -> all
+ * N sources.  poly is N x basis_size column-major (ldp) or NULL.
+ * Host buffers; the targets never leave the device (they are the sources).
+ */
+int bbfmm_fast_matrix_vector_product(bbfmm_handle *h, const double *w, int64_t rows,
+                                     int64_t basis_size, const int64_t *target_indices,
+                                     int64_t n_target_indices, const double *poly, int64_t ldp,
+                                     double nugget, double *result);
+
+/*
+ * Device-resident form of the same product for the case target_indices = all,
+ * basis_size = 0, nugget = 0 generalised to k right-hand sides:
+ *   d_out[:, j] = K(X, X) d_w[:, j]      (set_weights + evaluate at the sources)
+ * d_w / d_out are DEVICE pointers (N x k, ldw / ldo).  Asynchronous on the
+ * handle's stream unless sync != 0.  This is what bench.py times.
+ */
+int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_out,
+                        int64_t ldo, int32_t sync);
+
+/* HIP stream the handle launches on (hipStream_t as void*), for event timing. */
+void *bbfmm_stream(bbfmm_handle *h);
+
+/* Multi-GPU target partition: restrict the downward + leaf pass of
+ * bbfmm_matvec_device to the contiguous Morton range of target leaves owned by
+ * `rank` of `world`; rows of d_out that this rank does not own are left
+ * untouched.  The owned rows, in original point numbering, are reported by
+ * bbfmm_partition_rows.  rank=0, world=1 restores the full evaluation. */
+int bbfmm_set_partition(bbfmm_handle *h, int32_t rank, int32_t world);
+int64_t bbfmm_partition_row_count(const bbfmm_handle *h);
+int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out);
+
+/* ---- introspection (tests, bench statistics; host side, no device needed) ---- */
+typedef struct {
+    int32_t d, order, n_nodes, depth;
+    int64_t n_points, n_cells, n_leaves;
+    int64_t n_u, n_v, n_w, n_x;              /* total list entries */
+    int64_t p2p_pairs;                       /* sum_leaf n_t * sum_{U} n_s, targets = sources */
+    int64_t p2p_tile_bytes_k1;               /* SURVEY.md 8(d) tile-traffic bytes at K=1 */
+    double m2l_flops_k1;                     /* sum_pairs 4*n*r (2*n*n if uncompressed) */
+    double center[3];
+    double radius;
+} bbfmm_tree_stats;
+
+int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out);
+
+/* Cells in (level, key) order: Morton key (morton.rs:58-119), leaf flag. */
+int bbfmm_get_cells(const bbfmm_handle *h, uint64_t *keys, uint8_t *is_leaf);
+/* Source rows of every leaf: ptr has n_cells+1 entries, idx has n_points entries
+ * (ascending inside a leaf, linear_tree.rs:55-66). */
+int bbfmm_get_leaf_sources(const bbfmm_handle *h, int64_t *ptr, int64_t *idx);
+/* which: 'U','V','W','X'.  ptr may be NULL to query the size; returns entries via *n_entries.
+ * idx holds cell indices (positions in bbfmm_get_cells), sorted by key. */
+int bbfmm_get_list(const bbfmm_handle *h, char which, int64_t *ptr, int32_t *idx,
+                   int64_t *n_entries);
+/* M2L operator ranks per (level, reference vector): ranks[level*n_ref + ref], levels
+ * 0..depth (0 where no operator exists).  n_ref_out: 2/7/16 for d = 1/2/3. */
+int bbfmm_get_m2l_ranks(const bbfmm_handle *h, int32_t *ranks, int32_t *n_ref_out);
+/* Dense reconstruction U*Vt (n x n column-major) of one reference operator. */
+int bbfmm_get_m2l_operator(const bbfmm_handle *h, int32_t level, int32_t ref, double *out);
+/* The factors themselves: u is n x rank, vt is rank x n (both column-major; vt may be NULL,
+ * and is not written for uncompressed operators where U is the n x n kernel block). */
+int bbfmm_get_m2l_factors(const bbfmm_handle *h, int32_t level, int32_t ref, double *u, double *vt);
+/* Symmetry tables (chebyshev.rs:486-585): perm / invperm are n_perm x n (row-major),
+ * perm_lookup / ref_lookup have 7^d entries.  Any pointer may be NULL. */
+int bbfmm_get_permutation_tables(const bbfmm_handle *h, int32_t *n_perm, int32_t *perm,
+                                 int32_t *invperm, int32_t *perm_lookup, int32_t *ref_lookup);
+/* Target -> leaf assignment (linear_tree.rs:487-520) for arbitrary points; cell_out
+ * receives cell indices. */
+int bbfmm_points_to_leaves(const bbfmm_handle *h, const double *x, int64_t m, int64_t ldx,
+                           int32_t *cell_out, int64_t *bad_point_index);
+
+/* Per-phase device time of the last matvec in milliseconds (hipEvent based; only
+ * recorded when profiling was enabled with bbfmm_set_profiling(h, 1)).
+ * Order: gather, P2M, M2M, M2L_stage1, M2L_stage2, P2L, L2L, P2P, M2P, L2P, scatter. */
+#define BBFMM_N_PHASES 11
+int bbfmm_set_profiling(bbfmm_handle *h, int32_t enable);
+int bbfmm_get_phase_ms(const bbfmm_handle *h, double *ms_out);
+int bbfmm_reset_phase_ms(bbfmm_handle *h);
+
+/* FP64 MFMA self-test + peak microbenchmark (device): returns measured TFLOP/s of
+ * back-to-back v_mfma_f64_16x16x4 in *tflops and 0 mismatches in *layout_errors when
+ * the lane layout assumed by the M2L kernels holds on this device. */
+int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors);
+
+/* ---- test hooks (host loops, no device; never reached from a compute entry point) ----
+ * Dense n x n (column-major) M2M matrix of child `child_index` exactly as the reference
+ * stores it (chebyshev.rs:216-240); the device applies the same operator sum-factorised. */
+int bbfmm_debug_dense_m2m(const bbfmm_handle *h, int32_t child_index, double *out);
+/* Applies the stacked per-class M2L tables (what the MFMA kernels consume) with plain host
+ * loops: L[c][:] += M2L(M) for one rhs, M and L being n_cells x n cell-major.  Only valid on
+ * BBFMM_FLAG_HOST_ONLY handles (the tables are released after upload otherwise). */
+int bbfmm_debug_apply_m2l_tables_host(const bbfmm_handle *h, const double *M, double *L);
+
+/* Copies the device-resident multipole ('M') or local ('L') coefficients of the last pass to
+ * the host as k x n_cells x n (rhs-major, cell-major), i.e. column c + j*n_cells of the
+ * reference's n x (C*K) matrices (bbfmm.rs:234-242).  Per-phase parity checks. */
+int bbfmm_debug_get_coefficients(bbfmm_handle *h, char which, int32_t k, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FERREUS_BBFMM_HIP_H */

@@ -56,8 +56,9 @@ def build_passes(force: bool = False) -> str:
     if (not force) and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(src):
         return _SO
     os.makedirs(_BUILD, exist_ok=True)
-    cmd = ["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-std=c11",
-           "-o", _SO, src, "-lm"]
+    # -ffp-contract=off: the reference (rustc) never fuses a*b+c; keep plain IEEE arithmetic.
+    cmd = ["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
+           "-std=c11", "-o", _SO, src, "-lm"]
     try:
         subprocess.check_call(cmd)
     except subprocess.CalledProcessError:
@@ -914,6 +915,15 @@ class FmmTree:
                     vt_off.append(0)
             self.opbuf[level] = (np.concatenate(parts), np.array(u_off, dtype=np.int64),
                                  np.array(vt_off, dtype=np.int64), np.array(rank, dtype=np.int32))
+
+    def set_m2l_operators(self, factors):
+        """Replace the M2L operators: factors[level][ref] = (U, Vt or None).  Used by the parity
+        tests to run the oracle's passes on the product's host-computed operators, so that only
+        summation order differs."""
+        for level, lst in factors.items():
+            self.ops.u[level] = [np.asfortranarray(u) for u, _ in lst]
+            self.ops.vt[level] = [None if vt is None else np.asfortranarray(vt) for _, vt in lst]
+        self._flatten()
 
     # -- helpers
     def _ancestor_flags(self, leaf_cell_indices):
