@@ -72,9 +72,9 @@ SIGNATURES = {
     "bbfmm_get_permutation_tables": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, c_p]),
     "bbfmm_points_to_leaves": (ctypes.c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p]),
     "bbfmm_set_profiling": (ctypes.c_int, [c_p, c_i32]),
-    "bbfmm_get_phase_ms": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_get_phase_ms": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_reset_phase_ms": (ctypes.c_int, [c_p]),
-    "bbfmm_mfma_f64_selftest": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_mfma_f64_selftest": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_debug_dense_m2m": (ctypes.c_int, [c_p, c_i32, c_p]),
     "bbfmm_debug_apply_m2l_tables_host": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_debug_get_coefficients": (ctypes.c_int, [c_p, ctypes.c_char, c_i32, c_p]),
@@ -96,6 +96,13 @@ def load():
         raise LibraryMissing(
             f"{LIB_PATH} not found: build it with `python -m ferreus_rbf_rs_amd.build` "
             "(hipcc, gfx950).  There is no CPU fallback.")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; two HIP runtimes in one process do not
+    # both see the GPU.  Import torch first (when present) so this library binds to the copy
+    # torch already loaded (same SONAME) and tensors / RCCL share one runtime with the kernels.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

@@ -277,9 +277,10 @@ int bbfmm_set_profiling(bbfmm_handle *h, int32_t enable) {
     return BBFMM_OK;
 }
 
-int bbfmm_get_phase_ms(const bbfmm_handle *h, double *ms_out) {
+int bbfmm_get_phase_ms(bbfmm_handle *h, double *ms_out, int64_t *count_out) {
     if (!h || !ms_out) return BBFMM_BAD_ARGUMENT;
     std::memcpy(ms_out, h->tree.phase_ms(), sizeof(double) * BBFMM_N_PHASES);
+    if (count_out) std::memcpy(count_out, h->tree.phase_count(), sizeof(int64_t) * BBFMM_N_PHASES);
     return BBFMM_OK;
 }
 
@@ -289,12 +290,12 @@ int bbfmm_reset_phase_ms(bbfmm_handle *h) {
     return BBFMM_OK;
 }
 
-int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors) {
+int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors, double *info6) {
     double tf = 0;
     int errs = -1;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BBFMM_DEVICE_ERROR;
-    const int rc = bbfmm::mfma_f64_selftest(&tf, &errs);
+    const int rc = bbfmm::mfma_f64_selftest(&tf, &errs, info6);
     if (tflops) *tflops = tf;
     if (layout_errors) *layout_errors = errs;
     return rc == 0 ? BBFMM_OK : BBFMM_DEVICE_ERROR;

@@ -992,9 +992,10 @@ __global__ void mfma_layout_kernel(const double *A, const double *B, double *D) 
     for (int reg = 0; reg < 4; ++reg) D[((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = c[reg];
 }
 
-__global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters) {
+__global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters, unsigned long long *stamps) {
     const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
     v4f64 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
         c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
@@ -1003,9 +1004,15 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters)
     }
     const v4f64 c = c0 + c1 + c2 + c3;
     if (c[0] == 12345.678) sink[0] = c[1] + c[2] + c[3];
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && (threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[2 * w] = t1 - t0;     // shader cycles
+        stamps[2 * w + 1] = r1 - r0; // 100 MHz ticks
+    }
 }
 
-int mfma_f64_selftest(double *tflops, int *layout_errors) {
+int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
     double hA[64], hB[64], hD[256], ref[256];
     for (int i = 0; i < 16; ++i)
         for (int k = 0; k < 4; ++k) hA[i * 4 + k] = (double)(1 + i * 5 + k * 3);
@@ -1029,20 +1036,48 @@ int mfma_f64_selftest(double *tflops, int *layout_errors) {
     for (int i = 0; i < 256; ++i)
         if (hD[i] != ref[i]) ++errs;
     *layout_errors = errs;
-    // peak: 256 CUs x 8 blocks x 4 waves, 4 independent accumulators per wave
-    const int iters = 4096, blocks = 2048;
+    // peak: `blocks` x 4 waves, 4 independent accumulators per wave.  info[0..5]:
+    //   [0] cycles per MFMA, one wave alone on a CU        [1] its shader clock (MHz)
+    //   [2] cycles per MFMA per SIMD, 1 wave/SIMD, all CUs [3] clock under that load (MHz)
+    //   [4] TFLOP/s at 1 wave/SIMD                          [5] TFLOP/s at 2 waves/SIMD
+    const int iters = 4096;
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, dD, 16); // warm-up
-    hipEventRecord(e0, 0);
-    hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, dD, iters);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    const double flops = (double)blocks * 4.0 * iters * 4.0 * (2.0 * 16 * 16 * 4);
-    *tflops = flops / (ms * 1e-3) / 1e12;
+    unsigned long long *dS = nullptr;
+    const int max_blocks = 2048;
+    hipMalloc(&dS, sizeof(unsigned long long) * 2 * 4 * max_blocks);
+    std::vector<unsigned long long> hS(2 * 4 * max_blocks);
+    auto run = [&](int blocks, int threads, double *cyc, double *mhz) {
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(threads), 0, 0, dD, 16, nullptr); // warm-up
+        hipEventRecord(e0, 0);
+        hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(threads), 0, 0, dD, iters, dS);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms = 0;
+        hipEventElapsedTime(&ms, e0, e1);
+        const int waves = blocks * (threads / 64);
+        hipMemcpy(hS.data(), dS, sizeof(unsigned long long) * 2 * 4 * blocks, hipMemcpyDeviceToHost);
+        double sc = 0, sr = 0;
+        for (int b = 0; b < blocks; ++b)
+            for (int w = 0; w < threads / 64; ++w) {
+                sc += (double)hS[2 * (b * 4 + w)];
+                sr += (double)hS[2 * (b * 4 + w) + 1];
+            }
+        if (cyc) *cyc = sc / waves / (4.0 * iters);
+        if (mhz) *mhz = sr > 0 ? sc / sr * 100.0 : 0.0;
+        return (double)waves * iters * 4.0 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+    };
+    double i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    run(1, 64, &i0, &i1);
+    const double tf1 = run(256, 256, &i2, &i3);
+    const double tf2 = run(512, 256, nullptr, nullptr);
+    const double tf8 = run(2048, 256, nullptr, nullptr);
+    *tflops = tf8 > tf2 ? (tf8 > tf1 ? tf8 : tf1) : (tf2 > tf1 ? tf2 : tf1);
+    if (info) {
+        info[0] = i0; info[1] = i1; info[2] = i2; info[3] = i3; info[4] = tf1; info[5] = tf2;
+    }
+    hipFree(dS);
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     hipFree(dA);

@@ -119,6 +119,6 @@ void launch_l2p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const 
                 double *out_sorted, double *grad_sorted, hipStream_t s);
 
 // FP64 MFMA lane-layout check + peak microbenchmark.
-int mfma_f64_selftest(double *tflops, int *layout_errors);
+int mfma_f64_selftest(double *tflops, int *layout_errors, double *info);
 
 } // namespace bbfmm

@@ -80,21 +80,51 @@ FmmTree::~FmmTree() {
     if (!host_only_ && stream_) (void)hipStreamSynchronize(stream_);
     for (void *p : owned_) (void)hipFree(p);
     owned_.clear();
-    if (ev_[0]) (void)hipEventDestroy(ev_[0]);
-    if (ev_[1]) (void)hipEventDestroy(ev_[1]);
+    for (const PendingPhase &pp : pending_) {
+        (void)hipEventDestroy(pp.e0);
+        (void)hipEventDestroy(pp.e1);
+    }
+    for (hipEvent_t e : event_pool_) (void)hipEventDestroy(e);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
+// Phase timing: hipEvent pairs recorded on the launch stream without synchronising, so the
+// kernels of a timed region run back to back; collect_phase_times() resolves them later.
+hipEvent_t FmmTree::get_event() {
+    if (!event_pool_.empty()) {
+        hipEvent_t e = event_pool_.back();
+        event_pool_.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
 void FmmTree::phase_begin() {
-    if (profiling_) (void)hipEventRecord(ev_[0], stream_);
+    if (!profiling_) return;
+    pending_begin_ = get_event();
+    (void)hipEventRecord(pending_begin_, stream_);
 }
 void FmmTree::phase_end(int ph) {
-    if (!profiling_) return;
-    (void)hipEventRecord(ev_[1], stream_);
-    (void)hipEventSynchronize(ev_[1]);
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, ev_[0], ev_[1]);
-    phase_ms_[ph] += ms;
+    if (!profiling_ || !pending_begin_) return;
+    hipEvent_t e1 = get_event();
+    (void)hipEventRecord(e1, stream_);
+    pending_.push_back(PendingPhase{ph, pending_begin_, e1});
+    pending_begin_ = nullptr;
+}
+void FmmTree::collect_phase_times() {
+    if (pending_.empty()) return;
+    (void)hipStreamSynchronize(stream_);
+    for (const PendingPhase &pp : pending_) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, pp.e0, pp.e1) == hipSuccess) {
+            phase_ms_[pp.phase] += ms;
+            phase_count_[pp.phase] += 1;
+        }
+        event_pool_.push_back(pp.e0);
+        event_pool_.push_back(pp.e1);
+    }
+    pending_.clear();
 }
 
 // Merge the point ranges of `cells` (those that hold points) into sorted runs.
@@ -200,8 +230,6 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
             return fail(BBFMM_DEVICE_ERROR, "no HIP device available (the BBFMM passes have no CPU fallback)");
         HIPCHK(hipStreamCreate(&stream_));
-        HIPCHK(hipEventCreate(&ev_[0]));
-        HIPCHK(hipEventCreate(&ev_[1]));
     }
     CHK(build_m2l_tables());
     timer.lap("stacked M2L tables");

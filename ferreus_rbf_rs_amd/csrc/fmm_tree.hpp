@@ -81,8 +81,14 @@ class FmmTree {
     bool host_only() const { return host_only_; }
     void stats(bbfmm_tree_stats *out) const;
     void set_profiling(bool on) { profiling_ = on; }
-    const double *phase_ms() const { return phase_ms_; }
-    void reset_phase_ms() { for (double &v : phase_ms_) v = 0.0; }
+    // Resolves the recorded event pairs (synchronises the stream) and returns the totals.
+    const double *phase_ms() { collect_phase_times(); return phase_ms_; }
+    const int64_t *phase_count() { collect_phase_times(); return phase_count_; }
+    void reset_phase_ms() {
+        collect_phase_times();
+        for (double &v : phase_ms_) v = 0.0;
+        for (int64_t &v : phase_count_) v = 0;
+    }
     const std::vector<int64_t> &partition_rows() const { return part_rows_; }
     const std::vector<HostM2lClass> &m2l_host() const { return m2l_host_; }
     // Test hook (host loops over the stacked M2L tables; needs BBFMM_FLAG_HOST_ONLY).
@@ -107,6 +113,8 @@ class FmmTree {
     int upload_weights(const double *w, int64_t rows, int k, int64_t ldw);
     void phase_begin();
     void phase_end(int ph);
+    void collect_phase_times();
+    hipEvent_t get_event();
 
     // ---- host state
     std::string err_;
@@ -139,9 +147,16 @@ class FmmTree {
 
     // ---- device state
     hipStream_t stream_ = nullptr;
-    hipEvent_t ev_[2] = {nullptr, nullptr};
+    struct PendingPhase {
+        int phase;
+        hipEvent_t e0, e1;
+    };
+    std::vector<PendingPhase> pending_;
+    std::vector<hipEvent_t> event_pool_;
+    hipEvent_t pending_begin_ = nullptr;
     bool profiling_ = false;
     double phase_ms_[kNumPhases] = {0};
+    int64_t phase_count_[kNumPhases] = {0};
     std::vector<void *> owned_; // every hipMalloc'd pointer, freed in the destructor
     template <class T> int dalloc(DevBuf<T> *b, size_t n, bool zero = false);
     template <class T> int dupload(DevBuf<T> *b, const std::vector<T> &v);

@@ -280,12 +280,17 @@ class FmmTree:
     def set_profiling(self, on: bool):
         self._lib.bbfmm_set_profiling(self._h, int(on))
 
-    def phase_ms(self, reset=False) -> dict:
+    def phase_ms(self, reset=False, counts=False):
+        """Accumulated per-phase device milliseconds (and interval counts) since the last reset."""
         ms = (ctypes.c_double * L.N_PHASES)()
-        self._lib.bbfmm_get_phase_ms(self._h, ms)
+        cnt = (ctypes.c_int64 * L.N_PHASES)()
+        self._lib.bbfmm_get_phase_ms(self._h, ms, cnt)
         if reset:
             self._lib.bbfmm_reset_phase_ms(self._h)
-        return dict(zip(L.PHASE_NAMES, list(ms)))
+        d = dict(zip(L.PHASE_NAMES, list(ms)))
+        if counts:
+            return d, dict(zip(L.PHASE_NAMES, list(cnt)))
+        return d
 
     # -- introspection
     def stats(self) -> L.TreeStats:
@@ -392,7 +397,11 @@ def mfma_f64_selftest():
     """(measured FP64 MFMA TFLOP/s, lane-layout mismatches) on the current device."""
     tf = ctypes.c_double(0)
     errs = ctypes.c_int32(-1)
-    rc = L.load().bbfmm_mfma_f64_selftest(ctypes.byref(tf), ctypes.byref(errs))
+    info = (ctypes.c_double * 6)()
+    rc = L.load().bbfmm_mfma_f64_selftest(ctypes.byref(tf), ctypes.byref(errs), info)
     if rc != L.OK:
         raise RuntimeError("MFMA self-test needs a HIP device")
+    mfma_f64_selftest.info = dict(zip(["cycles_per_mfma_lone_wave", "clock_mhz_lone_wave",
+                                       "cycles_per_mfma_per_simd_busy", "clock_mhz_busy",
+                                       "tflops_1wave_per_simd", "tflops_2waves_per_simd"], list(info)))
     return tf.value, errs.value

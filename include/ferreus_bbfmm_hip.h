@@ -214,18 +214,22 @@ int bbfmm_get_permutation_tables(const bbfmm_handle *h, int32_t *n_perm, int32_t
 int bbfmm_points_to_leaves(const bbfmm_handle *h, const double *x, int64_t m, int64_t ldx,
                            int32_t *cell_out, int64_t *bad_point_index);
 
-/* Per-phase device time of the last matvec in milliseconds (hipEvent based; only
- * recorded when profiling was enabled with bbfmm_set_profiling(h, 1)).
+/* Per-phase device time in milliseconds, accumulated since the last reset while profiling is
+ * enabled.  hipEvent pairs are recorded on the handle's stream around each phase WITHOUT
+ * synchronising (the timed kernels still run back to back); this call synchronises once and
+ * resolves them.  count_out (optional) receives the number of recorded intervals per phase.
  * Order: gather, P2M, M2M, M2L_stage1, M2L_stage2, P2L, L2L, P2P, M2P, L2P, scatter. */
 #define BBFMM_N_PHASES 11
 int bbfmm_set_profiling(bbfmm_handle *h, int32_t enable);
-int bbfmm_get_phase_ms(const bbfmm_handle *h, double *ms_out);
+int bbfmm_get_phase_ms(bbfmm_handle *h, double *ms_out, int64_t *count_out);
 int bbfmm_reset_phase_ms(bbfmm_handle *h);
 
 /* FP64 MFMA self-test + peak microbenchmark (device): returns measured TFLOP/s of
  * back-to-back v_mfma_f64_16x16x4 in *tflops and 0 mismatches in *layout_errors when
- * the lane layout assumed by the M2L kernels holds on this device. */
-int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors);
+ * the lane layout assumed by the M2L kernels holds on this device.  info6 (optional, 6 doubles):
+ * cycles/MFMA of a lone wave, its clock (MHz), cycles/MFMA/SIMD and clock with every CU busy at
+ * 1 wave/SIMD, TFLOP/s at 1 and at 2 waves/SIMD. */
+int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors, double *info6);
 
 /* ---- test hooks (host loops, no device; never reached from a compute entry point) ----
  * Dense n x n (column-major) M2M matrix of child `child_index` exactly as the reference
