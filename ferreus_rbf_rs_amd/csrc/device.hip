@@ -12,6 +12,7 @@
 #include "device.hpp"
 
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace bbfmm {
@@ -637,162 +638,234 @@ __global__ __launch_bounds__(256) void p2l_kernel(KernelSpec ks, const DevCheb *
 // whole level into two dense streamed-operator GEMMs with no data permutation:
 //   stage 1:  Cbuf[target(V,t)][(t,kk)] = sum_m VtAll[(t,kk)][m] * M_V[m]   (X-stationary)
 //   stage 2:  L_B[i]                    = sum_k UAll[i][k] * Cbuf[B][k]     (accumulator-stationary)
-// v_mfma_f64_16x16x4_f64: A[i = lane&15][k = lane>>4], B[k = lane>>4][j = lane&15],
-// D[i = (lane>>4) + 4*reg][j = lane&15].
+// ------------------------------------------------------------------ M2L on v_mfma_f64_4x4x4_4b
+// Measured on MI355X (scripts/fp64_microbench.hip): v_mfma_f64_16x16x4 sustains ~46 TFLOP/s
+// chip-wide (~100-144 cycles per instruction), v_mfma_f64_4x4x4 (4 blocks) ~70 TFLOP/s (17
+// cycles per 512-flop instruction).  The kernels below are the same two streamed-operator
+// GEMMs as above on the faster instruction.  Lane layout (probed, scripts/mfma4_probe.hip):
+//   A[b][i][k]: lane = 16k + 4b + i    B[b][k][j]: lane = 16k + 4b + j    D[b][i][j]: lane = 16i + 4b + j
+// with D_b = A_b * B_b for the four independent blocks b.
 //
-// The K index inside a block of 16 is permuted (k = 16q + 4g + s for k-step 4q+s, g =
-// lane>>4) so that every lane fetches its four A values of a block with one 32-byte load.
+// Stage 1 uses the blocks as four slices of the contraction index (t = lane>>2 = 4k + b selects
+// the m values a lane owns), so one operator fragment feeds four cell groups and each D register
+// holds four partial sums that are added across lanes (xor 4, xor 8) once per tile.
+// Operator tiles are staged with the asynchronous global->LDS DMA (global_load_lds_dwordx4,
+// no VGPR round trip) into two LDS buffers: the tile for step i+1 streams in while step i is
+// multiplied.  The LDS image is in MFMA-fragment order, so every fragment read is a lane-linear,
+// conflict-free ds_read, and the per-lane DMA source address performs the permutation from the
+// operator's row-major HBM layout.  The DMA is issued from inline asm: through the builtin the
+// compiler must assume the in-flight LDS write may alias every later ds_read and drains it
+// (s_waitcnt vmcnt(0)) before each fragment read, which serialises the whole pipeline.
+typedef __attribute__((address_space(3))) void *lptr_t;
 
-// Stage 1.  Workgroup = 4 waves = 64 source cells of one (level, class).  NKS = k-steps
-// (of 4) held in registers per launch chunk; LDS holds one 16-row tile of the stacked
-// operator in MFMA-fragment order.
-template <int NKS, int MINW>
-__global__ __launch_bounds__(256, MINW) void m2l_stage1_kernel(const M2lClass *__restrict__ classes,
-                                                              const M2lTileDesc *__restrict__ tiles, int n_pad,
-                                                              int ks0, int nks, int accumulate, int64_t C,
-                                                              const double *__restrict__ M,
-                                                              double *__restrict__ cbuf, int64_t cbuf_len) {
-    extern __shared__ double lds[]; // nks * 64 doubles
+__device__ inline unsigned lds_offset(const double *p) {
+    return static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)p));
+}
+// 64 lanes x 16 B land at LDS byte offset m0 + lane * 16 (destination = wave-uniform base + lane*16).
+__device__ inline void dma16(const double *g, unsigned lds_wave_byte_offset) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g),
+                 "s"(lds_wave_byte_offset)
+                 : "memory", "m0");
+}
+__device__ inline void wait_dma_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+// v + (v rotated right by N lanes inside each row of 16 lanes), via DPP row_ror
+template <int N> __device__ inline double add_row_ror(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int rlo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+    const int rhi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+    return v + __hiloint2double(rhi, rlo);
+}
+
+// Stage 1.  Workgroup = 8 waves = 128 source cells of one (level, class).  NU = 32-m units of the
+// contraction index held in registers (exact).
+template <int NU>
+__global__ __launch_bounds__(512) void m2l_stage1_k4(const M2lClass *__restrict__ classes,
+                                                    const M2lTileDesc *__restrict__ tiles, int n_pad, int u0,
+                                                    int accumulate, int64_t C, const double *__restrict__ M,
+                                                    double *__restrict__ cbuf, int64_t cbuf_len) {
+    extern __shared__ double lds[]; // 2 buffers of NU * 8 fragments of 64 doubles: [(u*2+e)*4 + rg][lane]
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
     const int k = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, t = lane >> 2, j = lane & 3;
 
-    const int mypos = wave * 16 + col16;
-    const bool valid = mypos < tile.count;
-    const int cell = valid ? cls.cells[tile.first + mypos] : 0;
-    const double *Mc = M + ((int64_t)k * C + cell) * n_pad + (int64_t)ks0 * 4 + 4 * g;
-
-    double a[NKS];
+    // X fragments: x[g][u][e] = M[cell(4g + j)][32 (u0+u) + 2t + e]
+    double x[4][NU][2];
 #pragma unroll
-    for (int q = 0; q < NKS / 4; ++q) {
-        if (4 * q < nks && valid) {
-            const double2 v0 = *reinterpret_cast<const double2 *>(Mc + 16 * q);
-            const double2 v1 = *reinterpret_cast<const double2 *>(Mc + 16 * q + 2);
-            a[4 * q + 0] = v0.x;
-            a[4 * q + 1] = v0.y;
-            a[4 * q + 2] = v1.x;
-            a[4 * q + 3] = v1.y;
-        } else {
-            a[4 * q + 0] = a[4 * q + 1] = a[4 * q + 2] = a[4 * q + 3] = 0.0;
+    for (int g = 0; g < 4; ++g) {
+        const int pos = wave * 16 + 4 * g + j;
+        const bool valid = pos < tile.count;
+        const int cell = valid ? cls.cells[tile.first + pos] : 0;
+        const double *Mc = M + ((int64_t)k * C + cell) * n_pad + (int64_t)u0 * 32 + 2 * t;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            double2 v = make_double2(0.0, 0.0);
+            if (valid) v = *reinterpret_cast<const double2 *>(Mc + 32 * u);
+            x[g][u][0] = v.x;
+            x[g][u][1] = v.y;
         }
     }
 
     double *cb = cbuf + (int64_t)k * cbuf_len;
     const int n_ntiles = cls.r_pad16 / 16;
-    const int rows = nks * 4;
-    for (int jt = 0; jt < n_ntiles; ++jt) {
-        __syncthreads();
-        // stage VtAll[m][16 jt .. 16 jt + 16) for the chunk's m range, fragment order
-        for (int e = tid; e < rows * 8; e += 256) {
-            const int ml = e >> 3, j2 = (e & 7) * 2;
-            const double2 v =
-                *reinterpret_cast<const double2 *>(cls.vt_all + (int64_t)(ks0 * 4 + ml) * cls.r_pad16 + 16 * jt + j2);
-            const int q = ml >> 4, gg = (ml >> 2) & 3, s = ml & 3;
-            *reinterpret_cast<double2 *>(lds + (4 * q + s) * 64 + gg * 16 + j2) = v;
-        }
-        __syncthreads();
-        v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const int di = lane >> 4, db = (lane >> 2) & 3; // D layout: i, b (j as above)
+    // DMA plan.  Fragment f = (u*2+e)*4 + rg holds lanes (tt, i) -> Op[m = 32u + 2tt + e][row 4rg + i];
+    // 16-byte unit U = 32 f + 2 tt + ih covers rows 4rg + 2ih, +1 of that m-row.  One DMA
+    // instruction moves 64 consecutive units (two fragments); chunk c = wave + 8 i.
+    constexpr int N_CHUNKS = NU * 4;
+    constexpr int NCH = (N_CHUNKS + 7) / 8;
+    constexpr int BUF = NU * 512; // doubles per buffer
+    const double *dsrc[NCH];
 #pragma unroll
-        for (int ks = 0; ks < NKS; ks += 2) {
-            if (ks < nks) {
-                const double b0 = lds[ks * 64 + lane];
-                const double b1 = lds[(ks + 1) * 64 + lane];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], b0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks + 1], b1, acc1, 0, 0, 0);
+    for (int i = 0; i < NCH; ++i) {
+        const int U = (wave + 8 * i) * 64 + lane;
+        const int f = U >> 5, r = U & 31, tt = r >> 1, ih = r & 1;
+        const int rg = f & 3, ue = f >> 2, u = ue >> 1, e = ue & 1;
+        dsrc[i] = cls.vt_all + (int64_t)(u0 * 32 + 32 * u + 2 * tt + e) * cls.r_pad16 + 4 * rg + 2 * ih;
+    }
+    const unsigned lds0 = lds_offset(lds);
+    auto stage = [&](int jt, int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (wave + 8 * i < N_CHUNKS) dma16(dsrc[i] + 16 * jt, lds0 + (unsigned)(buf * BUF + (wave + 8 * i) * 128) * 8u);
+    };
+    stage(0, 0);
+    wait_dma_and_barrier();
+    for (int jt = 0; jt < n_ntiles; ++jt) {
+        const double *cur = lds + (jt & 1) * BUF + lane;
+        if (jt + 1 < n_ntiles) stage(jt + 1, (jt + 1) & 1); // streams in under the MFMAs below
+        double acc[4][4];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[rg][g] = 0.0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const double *ap = cur + ((u * 2 + e) * 4) * 64;
+                const double a0 = ap[0], a1 = ap[64], a2 = ap[128], a3 = ap[192];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[0][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, x[g][u][e], acc[0][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[1][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, x[g][u][e], acc[1][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[2][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, x[g][u][e], acc[2][g], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[3][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a3, x[g][u][e], acc[3][g], 0, 0, 0);
             }
         }
-        const v4f64 acc = acc0 + acc1;
-        // epilogue: column = tall row 16 jt + col16, rows = source cells g + 4 reg
-        const int j = 16 * jt + col16;
-        const int tpos = cls.row_tpos[j];
-        if (tpos >= 0) {
-            const int off = cls.row_off[j];
+        // add the four block partials (lanes 4b + j of each row of 16), then lane (i, b, j) writes g = b
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int sp = wave * 16 + g + 4 * reg;
-                if (sp < tile.count) {
-                    const int slot = cls.cslot[(int64_t)(tile.first + sp) * cls.n_t + tpos];
-                    if (slot >= 0) {
-                        double *dst = cb + (int64_t)slot * 4 + off;
-                        if (accumulate)
-                            *dst += acc[reg];
-                        else
-                            *dst = acc[reg];
-                    }
+        for (int rg = 0; rg < 4; ++rg) {
+            double mine = 0.0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const double v = add_row_ror<8>(add_row_ror<4>(acc[rg][g]));
+                if (g == db) mine = v;
+            }
+            const int row = 16 * jt + 4 * rg + di;
+            const int tpos = cls.row_tpos[row];
+            const int sp = wave * 16 + 4 * db + j;
+            if (tpos >= 0 && sp < tile.count) {
+                const int slot = cls.cslot[(int64_t)(tile.first + sp) * cls.n_t + tpos];
+                if (slot >= 0) {
+                    double *dst = cb + (int64_t)slot * 4 + cls.row_off[row];
+                    if (accumulate)
+                        *dst += mine;
+                    else
+                        *dst = mine;
                 }
             }
         }
+        wait_dma_and_barrier(); // the next tile has landed for everyone and `cur` is free again
     }
 }
 
-// Stage 2.  Workgroup = 4 waves = 64 target cells of one (level, class); every wave keeps
-// NT 16x16 accumulator tiles (its 16 targets x 16*NT output nodes) in registers and streams
-// the stacked operator UAll through LDS in blocks of 16 k.
-template <int NT, int MINW>
-__global__ __launch_bounds__(256, MINW) void m2l_stage2_kernel(const M2lClass *__restrict__ classes,
-                                                              const M2lTileDesc *__restrict__ tiles, int n_pad,
-                                                              int jt0, int nt, int64_t C,
-                                                              const double *__restrict__ cbuf, int64_t cbuf_len,
-                                                              double *__restrict__ L) {
-    extern __shared__ double lds[]; // 4 * nt * 64 doubles
+// Stage 2 uses the blocks as four groups of four targets: A_b = C values of targets 4b..4b+3,
+// B_b = the same 4x4 operator fragment for every block (broadcast LDS read), D_b = 4 targets x 4
+// output nodes.  NG = 4-node groups kept in registers (exact, even).  Node groups are paired so
+// that one 16-byte LDS read feeds two MFMAs: group 2G+h, column j <-> node 8G + 2j + h.
+template <int NG>
+__global__ __launch_bounds__(512) void m2l_stage2_k4(const M2lClass *__restrict__ classes,
+                                                    const M2lTileDesc *__restrict__ tiles, int n_pad, int g0,
+                                                    int64_t C, const double *__restrict__ cbuf, int64_t cbuf_len,
+                                                    double *__restrict__ L) {
+    extern __shared__ double lds[]; // 2 buffers of [e][G][ak*4 + ai] 16-byte units
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
     const int k = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, col16 = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ak = lane >> 4, ab = (lane >> 2) & 3, ai = lane & 3; // A layout: k, b, i
 
-    const int mypos = wave * 16 + col16;
+    const int mypos = wave * 16 + 4 * ab + ai;
     const bool valid = mypos < tile.count;
     const int64_t cbase = valid ? cls.cbase[tile.first + mypos] : 0;
-    const double *Cp = cbuf + (int64_t)k * cbuf_len + cbase + 4 * g;
+    const double *Cp = cbuf + (int64_t)k * cbuf_len + cbase + 4 * ak;
 
-    v4f64 acc[NT];
+    double acc[NG];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < NG; ++g) acc[g] = 0.0;
 
     const int nq = cls.k_pad / 16;
-    const int width = nt * 16; // output nodes handled by this launch chunk
-    for (int q = 0; q < nq; ++q) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-        if (valid) {
-            const double2 v0 = *reinterpret_cast<const double2 *>(Cp + 16 * q);
-            const double2 v1 = *reinterpret_cast<const double2 *>(Cp + 16 * q + 2);
-            a0 = v0.x;
-            a1 = v0.y;
-            a2 = v1.x;
-            a3 = v1.y;
-        }
-        __syncthreads();
-        // stage UAll rows [16q, 16q+16) x [16 jt0, 16 jt0 + width) in fragment order
-        for (int e = tid; e < 16 * (width / 2); e += 256) {
-            const int kl = e / (width / 2), c2 = (e % (width / 2)) * 2;
-            const double2 v =
-                *reinterpret_cast<const double2 *>(cls.u_all + (int64_t)(16 * q + kl) * n_pad + 16 * jt0 + c2);
-            const int gg = kl >> 2, s = kl & 3, jt = c2 >> 4, jj = c2 & 15;
-            *reinterpret_cast<double2 *>(lds + (s * nt + jt) * 64 + gg * 16 + jj) = v;
-        }
-        __syncthreads();
+    constexpr int NGH = NG / 2;
+    constexpr int N_CHUNKS = NGH;          // 32 NG units of 16 B = NG/2 DMA instructions
+    constexpr int NCH = (N_CHUNKS + 7) / 8;
+    constexpr int BUF = N_CHUNKS * 128;    // doubles per buffer
+    const double *dsrc[NCH];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            if (t < nt) {
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, lds[(0 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, lds[(1 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, lds[(2 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, lds[(3 * nt + t) * 64 + lane], acc[t], 0, 0, 0);
+    for (int i = 0; i < NCH; ++i) {
+        const int U = (wave + 8 * i) * 64 + lane;
+        const int r = U & 15, eg = U >> 4, kk = r >> 2, jj = r & 3;
+        const int e = eg / NGH, G = eg - e * NGH;
+        dsrc[i] = cls.u_all + (int64_t)(4 * kk + e) * n_pad + 4 * g0 + 8 * G + 2 * jj;
+    }
+    const unsigned lds0 = lds_offset(lds);
+    const int64_t qstride = (int64_t)16 * n_pad;
+    auto stage = [&](int q, int buf) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+            if (wave + 8 * i < N_CHUNKS) dma16(dsrc[i] + q * qstride, lds0 + (unsigned)(buf * BUF + (wave + 8 * i) * 128) * 8u);
+    };
+    double2 an0 = make_double2(0.0, 0.0), an1 = an0;
+    if (valid) {
+        an0 = *reinterpret_cast<const double2 *>(Cp);
+        an1 = *reinterpret_cast<const double2 *>(Cp + 2);
+    }
+    stage(0, 0);
+    wait_dma_and_barrier();
+    for (int q = 0; q < nq; ++q) {
+        const double *bfrag = lds + (q & 1) * BUF + (ak * 4 + ai) * 2; // + ((e * NGH + G) * 16) * 2
+        const double a[4] = {an0.x, an0.y, an1.x, an1.y};
+        if (q + 1 < nq) {
+            stage(q + 1, (q + 1) & 1); // streams in under the MFMAs below
+            if (valid) {               // next block of C values for this target
+                an0 = *reinterpret_cast<const double2 *>(Cp + 16 * (q + 1));
+                an1 = *reinterpret_cast<const double2 *>(Cp + 16 * (q + 1) + 2);
             }
         }
-    }
-    // epilogue: rows = targets g + 4 reg, column = node 16 (jt0 + t) + col16
 #pragma unroll
-    for (int reg = 0; reg < 4; ++reg) {
-        const int tp = wave * 16 + g + 4 * reg;
-        if (tp < tile.count) {
-            const int cell = cls.cells[tile.first + tp];
-            double *Lc = L + ((int64_t)k * C + cell) * n_pad + 16 * jt0 + col16;
+        for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (t < nt) Lc[16 * t] = acc[t][reg];
+            for (int G = 0; G < NGH; ++G) {
+                const double2 b2 = *reinterpret_cast<const double2 *>(bfrag + ((e * NGH + G) * 16) * 2);
+                acc[2 * G] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[e], b2.x, acc[2 * G], 0, 0, 0);
+                acc[2 * G + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[e], b2.y, acc[2 * G + 1], 0, 0, 0);
+            }
         }
+        wait_dma_and_barrier();
+    }
+    // epilogue: D[b][i][j] at lane 16 i + 4 b + j = L[target 4b + i][node 4 g0 + 8 G + 2 j + h]
+    const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
+    const int tp = wave * 16 + 4 * db + di;
+    if (tp < tile.count) {
+        const int cell = cls.cells[tile.first + tp];
+        double *Lc = L + ((int64_t)k * C + cell) * n_pad + 4 * g0 + 2 * dj;
+#pragma unroll
+        for (int G = 0; G < NGH; ++G) *reinterpret_cast<double2 *>(Lc + 8 * G) = make_double2(acc[2 * G], acc[2 * G + 1]);
     }
 }
 
@@ -917,93 +990,98 @@ void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
     });
 }
 
-// Stage-1 instantiations: k-steps held in registers per launch chunk.
-template <int NKS, int MINW>
-static void stage1_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int ks0, int nks,
-                          int accumulate, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
-                          hipStream_t s) {
-    const size_t lds = sizeof(double) * 64 * (size_t)nks;
+template <int NU>
+static void stage1_k4_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int u0,
+                             int accumulate, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
+                             hipStream_t s) {
+    const size_t lds = 2 * sizeof(double) * 512 * (size_t)NU;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage1_kernel<NKS, MINW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage1_k4<NU>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((m2l_stage1_kernel<NKS, MINW>), dim3(n_tiles, K), dim3(256), lds, s, classes, tiles, n_pad,
-                       ks0, nks, accumulate, C, M, cbuf, cbuf_len);
+    hipLaunchKernelGGL((m2l_stage1_k4<NU>), dim3(n_tiles, K), dim3(512), lds, s, classes, tiles, n_pad, u0,
+                       accumulate, C, M, cbuf, cbuf_len);
 }
 
+// The contraction index (n_pad, in units of 32) is processed in chunks whose X fragments live in
+// registers (exact instantiations 11, 8, 4, 2, 1); later chunks accumulate into cbuf.
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
                        const double *M, double *cbuf, int64_t cbuf_len, hipStream_t s) {
     if (n_tiles == 0) return;
-    const int total = n_pad / 4; // k-steps
-    // chunk size: the smallest instantiation that covers the rest, at most 184 per launch
+    const int total = n_pad / 32;
     int done = 0;
     while (done < total) {
         const int left = total - done;
         const int acc = done > 0 ? 1 : 0;
-        if (left <= 16) { stage1_launch<16, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
-        else if (left <= 32) { stage1_launch<32, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
-        else if (left <= 64) { stage1_launch<64, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
-        else if (left <= 88) { stage1_launch<88, 2>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
-        else if (left <= 128) { stage1_launch<128, 1>(classes, tiles, n_tiles, n_pad, done, left, acc, K, C, M, cbuf, cbuf_len, s); done += left; }
-        else { const int take = std::min(left, 184); stage1_launch<184, 1>(classes, tiles, n_tiles, n_pad, done, take, acc, K, C, M, cbuf, cbuf_len, s); done += take; }
+        int take;
+        if (left >= 11) { take = 11; stage1_k4_launch<11>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
+        else if (left >= 8) { take = 8; stage1_k4_launch<8>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
+        else if (left >= 4) { take = 4; stage1_k4_launch<4>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
+        else if (left >= 2) { take = 2; stage1_k4_launch<2>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
+        else { take = 1; stage1_k4_launch<1>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
+        done += take;
     }
 }
 
-template <int NT, int MINW>
-static void stage2_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int jt0, int nt,
-                          int K, int64_t C, const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
-    const size_t lds = sizeof(double) * 64 * 4 * (size_t)nt;
+template <int NG>
+static void stage2_k4_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g0, int K,
+                             int64_t C, const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
+    const size_t lds = 2 * sizeof(double) * 128 * (size_t)(NG / 2);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage2_kernel<NT, MINW>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage2_k4<NG>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((m2l_stage2_kernel<NT, MINW>), dim3(n_tiles, K), dim3(256), lds, s, classes, tiles, n_pad, jt0,
-                       nt, C, cbuf, cbuf_len, L);
+    hipLaunchKernelGGL((m2l_stage2_k4<NG>), dim3(n_tiles, K), dim3(512), lds, s, classes, tiles, n_pad, g0, C, cbuf,
+                       cbuf_len, L);
 }
 
+// The output nodes (n_pad, in groups of 4; a multiple of 8 groups) are processed in chunks whose
+// accumulators live in registers (exact instantiations 88, 64, 32, 16, 8).
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
                        const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    const int total = n_pad / 16; // 16-node output tiles
+    const int total = n_pad / 4;
     int done = 0;
     while (done < total) {
         const int left = total - done;
-        if (left <= 4) { stage2_launch<4, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
-        else if (left <= 8) { stage2_launch<8, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
-        else if (left <= 16) { stage2_launch<16, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
-        else if (left <= 22) { stage2_launch<22, 2>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
-        else if (left <= 32) { stage2_launch<32, 1>(classes, tiles, n_tiles, n_pad, done, left, K, C, cbuf, cbuf_len, L, s); done += left; }
-        else { const int take = std::min(left, 46); stage2_launch<46, 1>(classes, tiles, n_tiles, n_pad, done, take, K, C, cbuf, cbuf_len, L, s); done += take; }
+        int take;
+        if (left >= 88) { take = 88; stage2_k4_launch<88>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
+        else if (left >= 64) { take = 64; stage2_k4_launch<64>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
+        else if (left >= 32) { take = 32; stage2_k4_launch<32>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
+        else if (left >= 16) { take = 16; stage2_k4_launch<16>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
+        else { take = 8; stage2_k4_launch<8>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
+        done += take;
     }
 }
 
 // ------------------------------------------------------------------ MFMA self test
+// Four independent 4x4x4 products: A[b][i][k], B[b][k][j], D[b][i][j] (row-major per block).
 __global__ void mfma_layout_kernel(const double *A, const double *B, double *D) {
-    // A: 16x4 row-major, B: 4x16 row-major, D: 16x16 row-major
     const int lane = threadIdx.x & 63;
-    const double a = A[(lane & 15) * 4 + (lane >> 4)];
-    const double b = B[(lane >> 4) * 16 + (lane & 15)];
-    v4f64 c = {0.0, 0.0, 0.0, 0.0};
-    c = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    for (int reg = 0; reg < 4; ++reg) D[((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = c[reg];
+    const int hi = lane >> 4, b = (lane >> 2) & 3, lo = lane & 3;
+    const double a = A[(b * 4 + lo) * 4 + hi];  // A: lane = 16k + 4b + i
+    const double bb = B[(b * 4 + hi) * 4 + lo]; // B: lane = 16k + 4b + j
+    double c = 0.0;
+    c = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bb, c, 0, 0, 0);
+    D[(b * 4 + hi) * 4 + lo] = c;               // D: lane = 16i + 4b + j
 }
 
 __global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters, unsigned long long *stamps) {
     const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
-    v4f64 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0}, c2 = {0, 0, 0, 0}, c3 = {0, 0, 0, 0};
+    double c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int i = 0; i < iters; ++i) {
-        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c1, 0, 0, 0);
-        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c2, 0, 0, 0);
-        c3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c3, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c[q], 0, 0, 0);
     }
-    const v4f64 c = c0 + c1 + c2 + c3;
-    if (c[0] == 12345.678) sink[0] = c[1] + c[2] + c[3];
+    double sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += c[q];
+    if (sum == 12345.678) sink[0] = sum;
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     if (stamps && (threadIdx.x & 63) == 0) {
         const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -1014,16 +1092,20 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(double *sink, int iters,
 
 int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
     double hA[64], hB[64], hD[256], ref[256];
-    for (int i = 0; i < 16; ++i)
-        for (int k = 0; k < 4; ++k) hA[i * 4 + k] = (double)(1 + i * 5 + k * 3);
-    for (int k = 0; k < 4; ++k)
-        for (int j = 0; j < 16; ++j) hB[k * 16 + j] = (double)(2 + k * 7 + j * j); // asymmetric
-    for (int i = 0; i < 16; ++i)
-        for (int j = 0; j < 16; ++j) {
-            double s = 0;
-            for (int k = 0; k < 4; ++k) s += hA[i * 4 + k] * hB[k * 16 + j];
-            ref[i * 16 + j] = s;
-        }
+    // exact small integers, asymmetric B (catches a transposed or block-swapped map)
+    for (int b = 0; b < 4; ++b)
+        for (int i = 0; i < 4; ++i)
+            for (int k = 0; k < 4; ++k) {
+                hA[(b * 4 + i) * 4 + k] = (double)(1 + b * 17 + i * 5 + k * 3);
+                hB[(b * 4 + i) * 4 + k] = (double)(2 + b * 11 + i * 7 + k * k); // B[b][k=i][j=k]
+            }
+    for (int b = 0; b < 4; ++b)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0;
+                for (int k = 0; k < 4; ++k) s += hA[(b * 4 + i) * 4 + k] * hB[(b * 4 + k) * 4 + j];
+                ref[(b * 4 + i) * 4 + j] = s;
+            }
     double *dA = nullptr, *dB = nullptr, *dD = nullptr;
     if (hipMalloc(&dA, sizeof hA) != hipSuccess) return 1;
     if (hipMalloc(&dB, sizeof hB) != hipSuccess) return 1;
@@ -1033,10 +1115,10 @@ int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
     hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dD);
     if (hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     int errs = 0;
-    for (int i = 0; i < 256; ++i)
+    for (int i = 0; i < 64; ++i)
         if (hD[i] != ref[i]) ++errs;
     *layout_errors = errs;
-    // peak: `blocks` x 4 waves, 4 independent accumulators per wave.  info[0..5]:
+    // peak of v_mfma_f64_4x4x4 (512 flop): `blocks` x 4 waves, 8 independent accumulators per wave.  info[0..5]:
     //   [0] cycles per MFMA, one wave alone on a CU        [1] its shader clock (MHz)
     //   [2] cycles per MFMA per SIMD, 1 wave/SIMD, all CUs [3] clock under that load (MHz)
     //   [4] TFLOP/s at 1 wave/SIMD                          [5] TFLOP/s at 2 waves/SIMD
@@ -1064,9 +1146,9 @@ int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
                 sc += (double)hS[2 * (b * 4 + w)];
                 sr += (double)hS[2 * (b * 4 + w) + 1];
             }
-        if (cyc) *cyc = sc / waves / (4.0 * iters);
+        if (cyc) *cyc = sc / waves / (8.0 * iters);
         if (mhz) *mhz = sr > 0 ? sc / sr * 100.0 : 0.0;
-        return (double)waves * iters * 4.0 * (2.0 * 16 * 16 * 4) / (ms * 1e-3) / 1e12;
+        return (double)waves * iters * 8.0 * 512.0 / (ms * 1e-3) / 1e12;
     };
     double i0 = 0, i1 = 0, i2 = 0, i3 = 0;
     run(1, 64, &i0, &i1);

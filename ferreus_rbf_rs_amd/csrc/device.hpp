@@ -5,7 +5,7 @@
 //   src_xyz      d arrays of N sorted source coordinates (SoA -> coalesced loads)
 //   w_sorted     K x N   sorted weights, rhs-major
 //   M, L         K x C x n_pad   multipole / local coefficients, cell-major,
-//                n_pad = n rounded up to 16 (rows >= n stay zero) so that one
+//                n_pad = n rounded up to 32 (rows >= n stay zero) so that one
 //                cell's column is a whole number of 128-B lines and of MFMA tiles
 //   cbuf         K x cbuf_len   compressed M2L intermediates c = Vt * M (per target,
 //                per transfer vector; see M2lLevel)
@@ -19,7 +19,7 @@
 namespace bbfmm {
 
 constexpr int kMaxOrder = 16;      // Chebyshev nodes per axis supported on device
-constexpr int kM2lTile = 64;       // cells (GEMM columns) per M2L workgroup: 4 waves x 16
+constexpr int kM2lTile = 128;      // cells (GEMM columns) per M2L workgroup: up to 8 waves x 16
 
 struct DevCheb { // lives in device memory; kernels take a pointer
     int p, d, n, n_pad;

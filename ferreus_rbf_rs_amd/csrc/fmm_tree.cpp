@@ -245,7 +245,7 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
 // Stacked operators of one (level, class): VtAll (n_pad x r_pad16) and UAll (k_pad x n_pad).
 void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<double> *vt_all,
                                        std::vector<double> *u_all) const {
-    const int n = ops_.n, n_pad = round_up(n, 16);
+    const int n = ops_.n, n_pad = round_up(n, 32);
     const bool compressed = ops_.compression != kCompressionNone;
     const auto &lops = ops_.m2l[hc.level];
     vt_all->assign(static_cast<size_t>(n_pad) * hc.r_pad16, 0.0);
@@ -294,7 +294,7 @@ void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<doubl
 // per-octant-class operators; see device.hip "M2L".
 int FmmTree::build_m2l_tables() {
     const HostTree &t = tree_;
-    const int d = d_, n = ops_.n, n_pad = round_up(n, 16);
+    const int d = d_, n = ops_.n, n_pad = round_up(n, 32);
     const int ncls = 1 << d, nvec = ops_.n_vec;
     const bool compressed = ops_.compression != kCompressionNone;
     m2l_host_.clear();
@@ -446,7 +446,7 @@ int FmmTree::upload() {
     hc.p = order_;
     hc.d = d;
     hc.n = ops_.n;
-    hc.n_pad = round_up(ops_.n, 16);
+    hc.n_pad = round_up(ops_.n, 32);
     std::copy(ops_.polyn.begin(), ops_.polyn.end(), hc.polyn);
     std::copy(ops_.nodes.begin(), ops_.nodes.end(), hc.nodes);
     std::copy(ops_.xfer.begin(), ops_.xfer.end(), hc.xfer);
@@ -1066,7 +1066,7 @@ int FmmTree::debug_get_coefficients(char which, int k, double *out) {
 // Test hook: apply the stacked M2L tables on the host (plain loops).  Validates the table
 // construction without a GPU; never reached from a compute entry point.
 int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
-    const int n = ops_.n, n_pad = round_up(n, 16);
+    const int n = ops_.n, n_pad = round_up(n, 32);
     std::vector<double> cbuf(static_cast<size_t>(std::max<int64_t>(cbuf_len_, 1)), 0.0);
     for (const HostM2lClass &hc : m2l_host_) {
         if (hc.cells.empty()) continue;
