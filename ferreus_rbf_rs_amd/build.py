@@ -46,6 +46,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                 cmd += ["-x", "hip"] if False else []
             if verbose:
                 print(" ".join(cmd), flush=True)
+            if os.path.exists(obj):
+                os.remove(obj)  # never link a stale object after a failed compile
             subprocess.check_call(cmd)
     if force or _newer(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread"]

@@ -661,11 +661,19 @@ typedef __attribute__((address_space(3))) void *lptr_t;
 __device__ inline unsigned lds_offset(const double *p) {
     return static_cast<unsigned>(reinterpret_cast<uintptr_t>((lptr_t)p));
 }
+// Wave-uniform values the compiler cannot prove uniform (derived from threadIdx.x >> 6).
+__device__ inline unsigned uniform_u32(unsigned v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ inline const double *uniform_ptr(const double *p) {
+    const uintptr_t v = reinterpret_cast<uintptr_t>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v));
+    const unsigned hi = __builtin_amdgcn_readfirstlane(static_cast<unsigned>(v >> 32));
+    return reinterpret_cast<const double *>((static_cast<uintptr_t>(hi) << 32) | lo);
+}
 // 64 lanes x 16 B land at LDS byte offset m0 + lane * 16 (destination = wave-uniform base + lane*16).
 __device__ inline void dma16(const double *g, unsigned lds_wave_byte_offset) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g),
-                 "s"(lds_wave_byte_offset)
-                 : "memory", "m0");
+                 "s"(uniform_u32(lds_wave_byte_offset))
+                 : "memory");
 }
 __device__ inline void wait_dma_and_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -679,193 +687,156 @@ template <int N> __device__ inline double add_row_ror(double v) {
     return v + __hiloint2double(rhi, rlo);
 }
 
-// Stage 1.  Workgroup = 8 waves = 128 source cells of one (level, class).  NU = 32-m units of the
-// contraction index held in registers (exact).
-template <int NU>
-__global__ __launch_bounds__(512) void m2l_stage1_k4(const M2lClass *__restrict__ classes,
-                                                    const M2lTileDesc *__restrict__ tiles, int n_pad, int u0,
-                                                    int accumulate, int64_t C, const double *__restrict__ M,
-                                                    double *__restrict__ cbuf, int64_t cbuf_len) {
-    extern __shared__ double lds[]; // 2 buffers of NU * 8 fragments of 64 doubles: [(u*2+e)*4 + rg][lane]
-    const M2lTileDesc tile = tiles[blockIdx.x];
-    const M2lClass cls = classes[tile.level_class];
-    const int k = blockIdx.y;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, t = lane >> 2, j = lane & 3;
-
-    // X fragments: x[g][u][e] = M[cell(4g + j)][32 (u0+u) + 2t + e]
-    double x[4][NU][2];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int pos = wave * 16 + 4 * g + j;
-        const bool valid = pos < tile.count;
-        const int cell = valid ? cls.cells[tile.first + pos] : 0;
-        const double *Mc = M + ((int64_t)k * C + cell) * n_pad + (int64_t)u0 * 32 + 2 * t;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            double2 v = make_double2(0.0, 0.0);
-            if (valid) v = *reinterpret_cast<const double2 *>(Mc + 32 * u);
-            x[g][u][0] = v.x;
-            x[g][u][1] = v.y;
-        }
-    }
-
-    double *cb = cbuf + (int64_t)k * cbuf_len;
-    const int n_ntiles = cls.r_pad16 / 16;
-    const int di = lane >> 4, db = (lane >> 2) & 3; // D layout: i, b (j as above)
-    // DMA plan.  Fragment f = (u*2+e)*4 + rg holds lanes (tt, i) -> Op[m = 32u + 2tt + e][row 4rg + i];
-    // 16-byte unit U = 32 f + 2 tt + ih covers rows 4rg + 2ih, +1 of that m-row.  One DMA
-    // instruction moves 64 consecutive units (two fragments); chunk c = wave + 8 i.
-    constexpr int N_CHUNKS = NU * 4;
-    constexpr int NCH = (N_CHUNKS + 7) / 8;
-    constexpr int BUF = NU * 512; // doubles per buffer
-    const double *dsrc[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int U = (wave + 8 * i) * 64 + lane;
-        const int f = U >> 5, r = U & 31, tt = r >> 1, ih = r & 1;
-        const int rg = f & 3, ue = f >> 2, u = ue >> 1, e = ue & 1;
-        dsrc[i] = cls.vt_all + (int64_t)(u0 * 32 + 32 * u + 2 * tt + e) * cls.r_pad16 + 4 * rg + 2 * ih;
-    }
-    const unsigned lds0 = lds_offset(lds);
-    auto stage = [&](int jt, int buf) {
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-            if (wave + 8 * i < N_CHUNKS) dma16(dsrc[i] + 16 * jt, lds0 + (unsigned)(buf * BUF + (wave + 8 * i) * 128) * 8u);
-    };
-    stage(0, 0);
-    wait_dma_and_barrier();
-    for (int jt = 0; jt < n_ntiles; ++jt) {
-        const double *cur = lds + (jt & 1) * BUF + lane;
-        if (jt + 1 < n_ntiles) stage(jt + 1, (jt + 1) & 1); // streams in under the MFMAs below
-        double acc[4][4];
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[rg][g] = 0.0;
-#pragma unroll
-        for (int u = 0; u < NU; ++u) {
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const double *ap = cur + ((u * 2 + e) * 4) * 64;
-                const double a0 = ap[0], a1 = ap[64], a2 = ap[128], a3 = ap[192];
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[0][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, x[g][u][e], acc[0][g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[1][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, x[g][u][e], acc[1][g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[2][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, x[g][u][e], acc[2][g], 0, 0, 0);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[3][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a3, x[g][u][e], acc[3][g], 0, 0, 0);
-            }
-        }
-        // add the four block partials (lanes 4b + j of each row of 16), then lane (i, b, j) writes g = b
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            double mine = 0.0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const double v = add_row_ror<8>(add_row_ror<4>(acc[rg][g]));
-                if (g == db) mine = v;
-            }
-            const int row = 16 * jt + 4 * rg + di;
-            const int tpos = cls.row_tpos[row];
-            const int sp = wave * 16 + 4 * db + j;
-            if (tpos >= 0 && sp < tile.count) {
-                const int slot = cls.cslot[(int64_t)(tile.first + sp) * cls.n_t + tpos];
-                if (slot >= 0) {
-                    double *dst = cb + (int64_t)slot * 4 + cls.row_off[row];
-                    if (accumulate)
-                        *dst += mine;
-                    else
-                        *dst = mine;
-                }
-            }
-        }
-        wait_dma_and_barrier(); // the next tile has landed for everyone and `cur` is free again
-    }
+// Same with a uniform (SGPR) base and a 32-bit per-lane byte offset: saves address VGPRs.
+__device__ inline void dma16s(const double *sbase, unsigned voff_bytes, unsigned lds_wave_byte_offset) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff_bytes),
+                 "s"(uniform_ptr(sbase)), "s"(uniform_u32(lds_wave_byte_offset))
+                 : "memory");
 }
 
-// Stage 2 uses the blocks as four groups of four targets: A_b = C values of targets 4b..4b+3,
-// B_b = the same 4x4 operator fragment for every block (broadcast LDS read), D_b = 4 targets x 4
-// output nodes.  NG = 4-node groups kept in registers (exact, even).  Node groups are paired so
-// that one 16-byte LDS read feeds two MFMAs: group 2G+h, column j <-> node 8G + 2j + h.
-template <int NG>
-__global__ __launch_bounds__(512) void m2l_stage2_k4(const M2lClass *__restrict__ classes,
-                                                    const M2lTileDesc *__restrict__ tiles, int n_pad, int g0,
-                                                    int64_t C, const double *__restrict__ cbuf, int64_t cbuf_len,
-                                                    double *__restrict__ L) {
-    extern __shared__ double lds[]; // 2 buffers of [e][G][ak*4 + ai] 16-byte units
+// One kernel serves both stages: OUT[cell][col] = sum_k IN[cell][k] * OP[k][col] for the 128
+// cells of a workgroup and a block of 16*NG16 output columns.
+//   stage 1: IN = multipoles M (k = Chebyshev node m, n_pad of them), OP = VtAll (n_pad x r_pad),
+//            col = stacked operator row (t, kk); the result is scattered into the target slots.
+//   stage 2: IN = slot contents (k over the slot, k_pad), OP = UAll (k_pad x n_pad), col = node;
+//            the result is the local expansion L.
+// The four MFMA blocks are four groups of four output columns: A_b = operator fragment
+// OP[k][col 4b + i] (one lane-linear ds_read_b64 per 16 columns, feeding four MFMAs), B_b = the
+// IN values of four cells (the same for every block), D_b[i][j] = OUT[cell j][col 4b + i].  A wave
+// owns 16 cells (four groups tg) and keeps 4 x NG16 accumulators; the operator tile and the
+// cells' IN values of step q+1 stream into LDS by DMA while step q is multiplied.
+template <int NG16, int STAGE>
+__global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ classes,
+                                                  const M2lTileDesc *__restrict__ tiles, int n_pad, int g16_0,
+                                                  int64_t C, const double *__restrict__ in, int64_t in_len,
+                                                  double *__restrict__ out, int64_t out_len) {
+    extern __shared__ double lds[]; // 2 x { operator [e][ng][k*16 + col], IN tile [wave][tg][eh][k][j] x 2 }
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
-    const int k = blockIdx.y;
+    const int kr = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int ak = lane >> 4, ab = (lane >> 2) & 3, ai = lane & 3; // A layout: k, b, i
+    // stage 1: blockIdx.z selects a block of 16*NG16 stacked rows; stage 2: g16_0 selects the nodes
+    const int col0 = STAGE == 1 ? (int)blockIdx.z * 16 * NG16 : 16 * g16_0;
+    const int ld = STAGE == 1 ? cls.r_pad16 : n_pad;            // operator leading dimension
+    const int nq = STAGE == 1 ? n_pad / 16 : cls.k_pad / 16;    // contraction steps of 16
+    if (STAGE == 1 && col0 >= cls.r_pad16) return;
+    const double *opbase = (STAGE == 1 ? cls.vt_all : cls.u_all) + col0;
 
-    const int mypos = wave * 16 + 4 * ab + ai;
-    const bool valid = mypos < tile.count;
-    const int64_t cbase = valid ? cls.cbase[tile.first + mypos] : 0;
-    const double *Cp = cbuf + (int64_t)k * cbuf_len + cbase + 4 * ak;
+    constexpr int OP_CHUNKS = 2 * NG16;
+    constexpr int NCH = (OP_CHUNKS + 7) / 8;
+    constexpr int OP_DOUBLES = OP_CHUNKS * 128;
+    constexpr int BUF = OP_DOUBLES + 2048;
 
-    double acc[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) acc[g] = 0.0;
-
-    const int nq = cls.k_pad / 16;
-    constexpr int NGH = NG / 2;
-    constexpr int N_CHUNKS = NGH;          // 32 NG units of 16 B = NG/2 DMA instructions
-    constexpr int NCH = (N_CHUNKS + 7) / 8;
-    constexpr int BUF = N_CHUNKS * 128;    // doubles per buffer
-    const double *dsrc[NCH];
+    unsigned voff[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int U = (wave + 8 * i) * 64 + lane;
-        const int r = U & 15, eg = U >> 4, kk = r >> 2, jj = r & 3;
-        const int e = eg / NGH, G = eg - e * NGH;
-        dsrc[i] = cls.u_all + (int64_t)(4 * kk + e) * n_pad + 4 * g0 + 8 * G + 2 * jj;
+        const int c = wave + 8 * i;
+        const int f = 2 * c + (lane >> 5), r = lane & 31, k = r >> 3, pair = r & 7;
+        const int e = f / NG16, ng = f - e * NG16;
+        voff[i] = (unsigned)(((4 * k + e) * ld + 16 * ng + 2 * pair) * 8);
+    }
+    // IN tile: chunk h of this wave covers tg = 2h + (lane>>5), eh = (lane>>4)&1, k = (lane>>2)&3, j = lane&3
+    const double *cptr[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int tg = 2 * h + (lane >> 5), eh = (lane >> 4) & 1, k = (lane >> 2) & 3, j = lane & 3;
+        const int pos = wave * 16 + 4 * tg + j;
+        const int p = tile.first + (pos < tile.count ? pos : 0);
+        const int64_t base = STAGE == 1 ? ((int64_t)kr * C + cls.cells[p]) * n_pad : (int64_t)kr * in_len + cls.cbase[p];
+        cptr[h] = in + base + 4 * k + 2 * eh;
     }
     const unsigned lds0 = lds_offset(lds);
-    const int64_t qstride = (int64_t)16 * n_pad;
+    const int64_t qstride = (int64_t)16 * ld;
     auto stage = [&](int q, int buf) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
-            if (wave + 8 * i < N_CHUNKS) dma16(dsrc[i] + q * qstride, lds0 + (unsigned)(buf * BUF + (wave + 8 * i) * 128) * 8u);
+            if (wave + 8 * i < OP_CHUNKS)
+                dma16s(opbase + q * qstride, voff[i], lds0 + (unsigned)(buf * BUF + (wave + 8 * i) * 128) * 8u);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            dma16(cptr[h] + 16 * q, lds0 + (unsigned)(buf * BUF + OP_DOUBLES + (2 * wave + h) * 128) * 8u);
     };
-    double2 an0 = make_double2(0.0, 0.0), an1 = an0;
-    if (valid) {
-        an0 = *reinterpret_cast<const double2 *>(Cp);
-        an1 = *reinterpret_cast<const double2 *>(Cp + 2);
-    }
+
+    double acc[4][NG16];
+#pragma unroll
+    for (int tg = 0; tg < 4; ++tg)
+#pragma unroll
+        for (int g = 0; g < NG16; ++g) acc[tg][g] = 0.0;
+
+    const int bk = lane >> 4, bj = lane & 3; // B layout (k, j); the block index is broadcast
     stage(0, 0);
     wait_dma_and_barrier();
     for (int q = 0; q < nq; ++q) {
-        const double *bfrag = lds + (q & 1) * BUF + (ak * 4 + ai) * 2; // + ((e * NGH + G) * 16) * 2
-        const double a[4] = {an0.x, an0.y, an1.x, an1.y};
-        if (q + 1 < nq) {
-            stage(q + 1, (q + 1) & 1); // streams in under the MFMAs below
-            if (valid) {               // next block of C values for this target
-                an0 = *reinterpret_cast<const double2 *>(Cp + 16 * (q + 1));
-                an1 = *reinterpret_cast<const double2 *>(Cp + 16 * (q + 1) + 2);
+        const double *op = lds + (q & 1) * BUF + lane;
+        const double *ct = lds + (q & 1) * BUF + OP_DOUBLES + wave * 256 + (bk * 4 + bj) * 2;
+        if (q + 1 < nq) stage(q + 1, (q + 1) & 1); // streams in under the MFMAs below
+        double bq[4][4];
+#pragma unroll
+        for (int tg = 0; tg < 4; ++tg)
+#pragma unroll
+            for (int eh = 0; eh < 2; ++eh) {
+                const double2 v = *reinterpret_cast<const double2 *>(ct + ((tg * 2 + eh) * 16) * 2);
+                bq[tg][2 * eh] = v.x;
+                bq[tg][2 * eh + 1] = v.y;
             }
-        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int G = 0; G < NGH; ++G) {
-                const double2 b2 = *reinterpret_cast<const double2 *>(bfrag + ((e * NGH + G) * 16) * 2);
-                acc[2 * G] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[e], b2.x, acc[2 * G], 0, 0, 0);
-                acc[2 * G + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[e], b2.y, acc[2 * G + 1], 0, 0, 0);
+            for (int g = 0; g < NG16; ++g) {
+                const double a = op[(e * NG16 + g) * 64];
+#pragma unroll
+                for (int tg = 0; tg < 4; ++tg) acc[tg][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bq[tg][e], acc[tg][g], 0, 0, 0);
             }
         }
         wait_dma_and_barrier();
     }
-    // epilogue: D[b][i][j] at lane 16 i + 4 b + j = L[target 4b + i][node 4 g0 + 8 G + 2 j + h]
+    // epilogue: D[b][i][j] at lane 16 i + 4 b + j = OUT[cell 4 tg + j][col0 + 16 g + 4 b + i]
     const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
-    const int tp = wave * 16 + 4 * db + di;
-    if (tp < tile.count) {
-        const int cell = cls.cells[tile.first + tp];
-        double *Lc = L + ((int64_t)k * C + cell) * n_pad + 4 * g0 + 2 * dj;
+    if (STAGE == 1) {
+        // Scatter into the target slots.  Branch-free and batched so that the table lookups of a
+        // batch are all in flight together: entries without a destination (padding rows, absent
+        // targets, cells beyond the tile) are written to a dump area behind the slot buffer.
+        double *cb = out + (int64_t)kr * out_len;
+        double *dump = cb + (out_len - 64) + lane;
+        constexpr int HALF = (NG16 + 1) / 2;
 #pragma unroll
-        for (int G = 0; G < NGH; ++G) *reinterpret_cast<double2 *>(Lc + 8 * G) = make_double2(acc[2 * G], acc[2 * G + 1]);
+        for (int h0 = 0; h0 < NG16; h0 += HALF) {
+            int tpos[HALF], off[HALF];
+#pragma unroll
+            for (int g = 0; g < HALF; ++g) {
+                const int col = col0 + 16 * min(h0 + g, NG16 - 1) + 4 * db + di;
+                tpos[g] = cls.row_tpos[col];
+                off[g] = cls.row_off[col];
+            }
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg) {
+                const int sp = wave * 16 + 4 * tg + dj;
+                const bool spv = sp < tile.count;
+                const int32_t *csrow = cls.cslot + (int64_t)(tile.first + (spv ? sp : 0)) * cls.n_t;
+                int slot[HALF];
+#pragma unroll
+                for (int g = 0; g < HALF; ++g) slot[g] = csrow[max(tpos[g], 0)];
+#pragma unroll
+                for (int g = 0; g < HALF; ++g) {
+                    if (h0 + g < NG16) {
+                        const bool ok = spv && tpos[g] >= 0 && slot[g] >= 0;
+                        double *dst = ok ? cb + (int64_t)slot[g] * 4 + off[g] : dump;
+                        *dst = acc[tg][h0 + g];
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int tg = 0; tg < 4; ++tg) {
+            const int tp = wave * 16 + 4 * tg + dj;
+            if (tp < tile.count) {
+                const int cell = cls.cells[tile.first + tp];
+                double *Lc = out + ((int64_t)kr * C + cell) * n_pad + col0 + 4 * db + di;
+#pragma unroll
+                for (int g = 0; g < NG16; ++g) Lc[16 * g] = acc[tg][g];
+            }
+        }
     }
 }
 
@@ -990,70 +961,45 @@ void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
     });
 }
 
-template <int NU>
-static void stage1_k4_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int u0,
-                             int accumulate, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
-                             hipStream_t s) {
-    const size_t lds = 2 * sizeof(double) * 512 * (size_t)NU;
+template <int NG16, int STAGE>
+static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g16_0,
+                            int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
+                            int64_t out_len, hipStream_t s) {
+    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage1_k4<NU>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_gemm_k4<NG16, STAGE>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((m2l_stage1_k4<NU>), dim3(n_tiles, K), dim3(512), lds, s, classes, tiles, n_pad, u0,
-                       accumulate, C, M, cbuf, cbuf_len);
+    hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE>), dim3(n_tiles, K, n_colblocks), dim3(512), lds, s, classes, tiles,
+                       n_pad, g16_0, C, in, in_len, out, out_len);
 }
 
-// The contraction index (n_pad, in units of 32) is processed in chunks whose X fragments live in
-// registers (exact instantiations 11, 8, 4, 2, 1); later chunks accumulate into cbuf.
-void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
-                       const double *M, double *cbuf, int64_t cbuf_len, hipStream_t s) {
+// Stage 1: every class's stacked operator is padded to a whole number of kM2lS1Block columns, so
+// one instantiation covers all orders; blockIdx.z walks the column blocks.
+void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int max_r_pad,
+                       int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len, hipStream_t s) {
     if (n_tiles == 0) return;
-    const int total = n_pad / 32;
-    int done = 0;
-    while (done < total) {
-        const int left = total - done;
-        const int acc = done > 0 ? 1 : 0;
-        int take;
-        if (left >= 11) { take = 11; stage1_k4_launch<11>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
-        else if (left >= 8) { take = 8; stage1_k4_launch<8>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
-        else if (left >= 4) { take = 4; stage1_k4_launch<4>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
-        else if (left >= 2) { take = 2; stage1_k4_launch<2>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
-        else { take = 1; stage1_k4_launch<1>(classes, tiles, n_tiles, n_pad, done, acc, K, C, M, cbuf, cbuf_len, s); }
-        done += take;
-    }
+    const int n_colblocks = (max_r_pad + kM2lS1Block - 1) / kM2lS1Block;
+    m2l_gemm_launch<kM2lS1Block / 16, 1>(classes, tiles, n_tiles, n_pad, 0, n_colblocks, K, C, M, 0, cbuf, cbuf_len, s);
 }
 
-template <int NG>
-static void stage2_k4_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g0, int K,
-                             int64_t C, const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
-    const size_t lds = 2 * sizeof(double) * 128 * (size_t)(NG / 2);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_stage2_k4<NG>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL((m2l_stage2_k4<NG>), dim3(n_tiles, K), dim3(512), lds, s, classes, tiles, n_pad, g0, C, cbuf,
-                       cbuf_len, L);
-}
-
-// The output nodes (n_pad, in groups of 4; a multiple of 8 groups) are processed in chunks whose
-// accumulators live in registers (exact instantiations 88, 64, 32, 16, 8).
+// Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) are processed in
+// chunks whose accumulators live in registers (exact instantiations 22, 16, 8, 4, 2).
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
                        const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    const int total = n_pad / 4;
+    const int total = n_pad / 16;
     int done = 0;
     while (done < total) {
         const int left = total - done;
         int take;
-        if (left >= 88) { take = 88; stage2_k4_launch<88>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
-        else if (left >= 64) { take = 64; stage2_k4_launch<64>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
-        else if (left >= 32) { take = 32; stage2_k4_launch<32>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
-        else if (left >= 16) { take = 16; stage2_k4_launch<16>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
-        else { take = 8; stage2_k4_launch<8>(classes, tiles, n_tiles, n_pad, done, K, C, cbuf, cbuf_len, L, s); }
+        if (left >= 22) { take = 22; m2l_gemm_launch<22, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
+        else if (left >= 16) { take = 16; m2l_gemm_launch<16, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
+        else if (left >= 8) { take = 8; m2l_gemm_launch<8, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
+        else if (left >= 4) { take = 4; m2l_gemm_launch<4, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
+        else { take = 2; m2l_gemm_launch<2, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
         done += take;
     }
 }

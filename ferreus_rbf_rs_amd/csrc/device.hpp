@@ -19,7 +19,8 @@
 namespace bbfmm {
 
 constexpr int kMaxOrder = 16;      // Chebyshev nodes per axis supported on device
-constexpr int kM2lTile = 128;      // cells (GEMM columns) per M2L workgroup: up to 8 waves x 16
+constexpr int kM2lTile = 128;      // cells per M2L workgroup: 8 waves x 16
+constexpr int kM2lS1Block = 352;   // stacked-operator rows per stage-1 workgroup (22 groups of 16)
 
 struct DevCheb { // lives in device memory; kernels take a pointer
     int p, d, n, n_pad;
@@ -42,7 +43,7 @@ struct M2lClass {
     const int32_t *row_tpos; // r_pad16: position of the row's transfer vector in the class list (or -1)
     const int32_t *row_off;  // r_pad16: offset of the row inside the target's slot (= off_target_class[t] + kk)
     int32_t n_rows;          // exact number of tall rows
-    int32_t r_pad16;
+    int32_t r_pad16;         // n_rows rounded up to a multiple of kM2lS1Block
     int32_t n_t;             // number of transfer vectors of this class (189 in 3-D)
     // stage 2 (target side): L_B[i] = sum_k UAllT[k][i] * ccat_B[k]
     const double *u_all;     // k_pad x n_pad
@@ -81,8 +82,8 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
                 hipStream_t s);
 
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
-                       int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
-                       hipStream_t s);
+                       int max_r_pad, int K, int64_t C, const double *M, double *cbuf,
+                       int64_t cbuf_len, hipStream_t s);
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
                        int K, int64_t C, const double *cbuf, int64_t cbuf_len, double *L,
                        hipStream_t s);

@@ -373,7 +373,7 @@ int FmmTree::build_m2l_tables() {
             // stage 1 tall operator rows
             hc.n_rows = 0;
             for (int tv : src_list[o]) hc.n_rows += rank_of(tv);
-            hc.r_pad16 = round_up(std::max(hc.n_rows, 16), 16);
+            hc.r_pad16 = round_up(std::max(hc.n_rows, 1), kM2lS1Block);
             hc.row_tpos.assign(hc.r_pad16, -1);
             hc.row_off.assign(hc.r_pad16, 0);
             if (hc.cells.empty()) continue;
@@ -431,7 +431,7 @@ int FmmTree::build_m2l_tables() {
     if (bad_pairs > 0)
         return fail(BBFMM_UNSUPPORTED,
                     "V-list pairs outside the admissible transfer-vector set (source points outside the root box?)");
-    cbuf_len_ = cbuf_cursor;
+    cbuf_len_ = cbuf_cursor + 128; // + dump area for the branch-free stage-1 scatter (never read)
     if (cbuf_len_ / 4 >= (int64_t(1) << 31)) return fail(BBFMM_UNSUPPORTED, "M2L intermediate buffer too large");
     return BBFMM_OK;
 }
@@ -729,7 +729,11 @@ int FmmTree::downward(int k) {
     const M2lTileDesc *tiles = have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles_.p;
     const int n_tiles = have_part_ ? n_m2l_tiles_part_ : static_cast<int>(m2l_tiles_h_.size());
     phase_begin();
-    launch_m2l_stage1(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
+    int max_r_pad = 0;
+    for (const HostM2lClass &hc : m2l_host_)
+        if (!hc.cells.empty()) max_r_pad = std::max(max_r_pad, hc.r_pad16);
+    launch_m2l_stage1(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, max_r_pad, k, C, d_M_.p, d_cbuf_.p, cbuf_len_,
+                      stream_);
     phase_end(kPhM2L1);
     phase_begin();
     launch_m2l_stage2(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_L_.p, stream_);
