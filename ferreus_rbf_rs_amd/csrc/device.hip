@@ -121,22 +121,23 @@ __device__ inline void cheb_S_to(int p, double x, const double *__restrict__ pol
 // chunk live in LDS; each thread owns output nodes tid, tid+256, ...
 constexpr int P2M_PTS = 64;
 constexpr int P2M_KB = 4;
+constexpr int P2M_THREADS = 384; // 6 waves: one pass over the 343 nodes of an order-7 cell
 
-__global__ __launch_bounds__(256) void p2m_kernel(const DevCheb *__restrict__ chp, Xyz src,
-                                                  const double *__restrict__ ws, int64_t N, int K, int64_t C,
-                                                  const int32_t *__restrict__ leaf_cells,
-                                                  const int32_t *__restrict__ pt_begin,
-                                                  const int32_t *__restrict__ pt_end,
-                                                  const double *__restrict__ centers,
-                                                  const double *__restrict__ lengths, double *__restrict__ M) {
+__global__ __launch_bounds__(P2M_THREADS) void p2m_kernel(const DevCheb *__restrict__ chp, Xyz src,
+                                                          const double *__restrict__ ws, int64_t N, int K, int64_t C,
+                                                          const int32_t *__restrict__ leaf_cells,
+                                                          const int32_t *__restrict__ pt_begin,
+                                                          const int32_t *__restrict__ pt_end,
+                                                          const double *__restrict__ centers,
+                                                          const double *__restrict__ lengths, double *__restrict__ M) {
     __shared__ double s_polyn[kMaxOrder * kMaxOrder];
-    __shared__ double s_S[3][kMaxOrder][P2M_PTS];
+    __shared__ double s_S[3][P2M_PTS][kMaxOrder + 1]; // node index fastest: the 7..16 values a wave reads sit in distinct banks
     __shared__ double s_w[P2M_KB][P2M_PTS];
     const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
     int P0, P1, P2;
     axis_sizes(p, d, P0, P1, P2);
     const int tid = threadIdx.x;
-    for (int i = tid; i < p * p; i += 256) s_polyn[i] = chp->polyn[i];
+    for (int i = tid; i < p * p; i += P2M_THREADS) s_polyn[i] = chp->polyn[i];
     const int cell = leaf_cells[blockIdx.x];
     const int b = pt_begin[cell], e = pt_end[cell];
     const double len = lengths[cell];
@@ -152,9 +153,9 @@ __global__ __launch_bounds__(256) void p2m_kernel(const DevCheb *__restrict__ ch
                     const double *co = axis == 0 ? src.x : (axis == 1 ? src.y : src.z);
                     const double c0 = axis == 0 ? cx : (axis == 1 ? cy : cz);
                     const double x = (co[base + pt] - c0) / (len * 0.5); // chebyshev.rs:841-845
-                    cheb_S_to<false>(p, x, s_polyn, &s_S[axis][0][pt], nullptr, P2M_PTS);
+                    cheb_S_to<false>(p, x, s_polyn, &s_S[axis][pt][0], nullptr, 1);
                 } else {
-                    s_S[axis][0][pt] = 1.0;
+                    s_S[axis][pt][0] = 1.0;
                 }
             }
         }
@@ -165,11 +166,11 @@ __global__ __launch_bounds__(256) void p2m_kernel(const DevCheb *__restrict__ ch
                 for (int kk = 0; kk < kb; ++kk)
                     if (tid < npts) s_w[kk][tid] = ws[(int64_t)(k0 + kk) * N + base + tid];
             __syncthreads();
-            for (int I = tid; I < n; I += 256) {
+            for (int I = tid; I < n; I += P2M_THREADS) {
                 const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1);
                 double acc[P2M_KB] = {0.0, 0.0, 0.0, 0.0};
                 for (int pt = 0; pt < npts; ++pt) {
-                    const double v = s_S[0][i0][pt] * s_S[1][i1][pt] * s_S[2][i2][pt];
+                    const double v = s_S[0][pt][i0] * s_S[1][pt][i1] * s_S[2][pt][i2];
 #pragma unroll
                     for (int kk = 0; kk < P2M_KB; ++kk)
                         if (kk < kb) acc[kk] += v * s_w[kk][pt];
@@ -284,97 +285,131 @@ __global__ __launch_bounds__(256) void l2l_kernel(const DevCheb *__restrict__ ch
 
 // ------------------------------------------------------------------ L2P
 // local_to_particle (bbfmm.rs:1358-1440): y[t] += S(x_t) . L_leaf, optionally gradients
-// (dS scaled by 2/length, chebyshev.rs:862-869).  Thread per target; per-thread factor
-// columns in LDS (index [axis][j][tid]); L_leaf broadcast from LDS.
-constexpr int L2P_THREADS = 128;
+// (dS scaled by 2/length, chebyshev.rs:862-869).  One wave per leaf, one lane per target; the
+// 1-D factors live in registers (order P is a template parameter), L_leaf is broadcast from LDS.
+constexpr int L2P_WAVES = 4;
 
-template <bool GRAD>
-__global__ __launch_bounds__(L2P_THREADS) void l2p_kernel(const DevCheb *__restrict__ chp,
-                                                          const int32_t *__restrict__ leaf_cells,
-                                                          const int32_t *__restrict__ tgt_begin,
-                                                          const int32_t *__restrict__ tgt_end,
-                                                          const double *__restrict__ centers,
-                                                          const double *__restrict__ lengths, Xyz tgt, int64_t n_tgt,
-                                                          int K, int64_t C, const double *__restrict__ L,
-                                                          double *__restrict__ out, double *__restrict__ grad) {
-    extern __shared__ double lds[];
-    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
-    int P0, P1, P2;
-    axis_sizes(p, d, P0, P1, P2);
-    const int tid = threadIdx.x;
-    double *s_polyn = lds;                          // p*p
-    double *s_L = s_polyn + kMaxOrder * kMaxOrder;  // n
-    double *s_S = s_L + n;                          // 3 * p * L2P_THREADS
-    double *s_dS = s_S + 3 * p * L2P_THREADS;       // 3 * p * L2P_THREADS (GRAD)
-    for (int i = tid; i < p * p; i += L2P_THREADS) s_polyn[i] = chp->polyn[i];
-    const int cell = leaf_cells[blockIdx.x];
-    const int b = tgt_begin[blockIdx.x], e = tgt_end[blockIdx.x];
+template <int P, bool GRAD>
+__device__ inline void cheb_S_reg(double x, const double *__restrict__ polyn, double (&S)[P], double (&dS)[P]) {
+    double T[P], dT[P];
+    T[0] = 1.0;
+    dT[0] = 0.0;
+    if (P > 1) {
+        T[1] = x;
+        dT[1] = 1.0;
+    }
+#pragma unroll
+    for (int j = 2; j < P; ++j) {
+        T[j] = 2.0 * x * T[j - 1] - T[j - 2];
+        if (GRAD) dT[j] = 2.0 * T[j - 1] + 2.0 * x * dT[j - 1] - dT[j - 2];
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double s = 0.0, ds = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const double pk = polyn[j * P + k];
+            s += T[k] * pk;
+            if (GRAD) ds += dT[k] * pk;
+        }
+        S[j] = (s * 2.0 - 1.0) / (double)P;
+        dS[j] = GRAD ? ds * (2.0 / (double)P) : 0.0;
+    }
+}
+
+template <int P, int D, bool GRAD>
+__global__ __launch_bounds__(64 * L2P_WAVES) void l2p_kernel(const DevCheb *__restrict__ chp, int n_jobs,
+                                                             const int32_t *__restrict__ leaf_cells,
+                                                             const int32_t *__restrict__ tgt_begin,
+                                                             const int32_t *__restrict__ tgt_end,
+                                                             const double *__restrict__ centers,
+                                                             const double *__restrict__ lengths, Xyz tgt,
+                                                             int64_t n_tgt, int K, int64_t C,
+                                                             const double *__restrict__ L,
+                                                             double *__restrict__ out, double *__restrict__ grad) {
+    constexpr int P1 = D > 1 ? P : 1, P2 = D > 2 ? P : 1, N = P * P1 * P2;
+    __shared__ double s_polyn[P * P];
+    __shared__ double s_L[L2P_WAVES][N];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < P * P; i += 64 * L2P_WAVES) s_polyn[i] = chp->polyn[i];
+    __syncthreads();
+    const int job = blockIdx.x * L2P_WAVES + wave;
+    if (job >= n_jobs) return; // whole wave; no block barrier below
+    const int n_pad = chp->n_pad;
+    const int cell = leaf_cells[job];
+    const int b = tgt_begin[job], e = tgt_end[job];
     const double len = lengths[cell];
     const double cc[3] = {centers[cell * 3 + 0], centers[cell * 3 + 1], centers[cell * 3 + 2]};
-    __syncthreads();
-    for (int base = b; base < e; base += L2P_THREADS) {
-        const int t = base + tid;
+    double *Lw = s_L[wave];
+    for (int base = b; base < e; base += 64) {
+        const int t = base + lane;
         const bool valid = t < e;
-        if (valid) {
-            for (int axis = 0; axis < 3; ++axis) {
-                double *S = s_S + (axis * p) * L2P_THREADS + tid;
-                double *dS = s_dS + (axis * p) * L2P_THREADS + tid;
-                if (axis < d) {
-                    const double *co = axis == 0 ? tgt.x : (axis == 1 ? tgt.y : tgt.z);
-                    const double x = (co[t] - cc[axis]) / (len * 0.5);
-                    cheb_S_to<GRAD>(p, x, s_polyn, S, dS, L2P_THREADS);
-                    if (GRAD)
-                        for (int j = 0; j < p; ++j) dS[j * L2P_THREADS] *= 2.0 / len;
-                } else {
-                    S[0] = 1.0;
-                    if (GRAD) dS[0] = 0.0;
-                }
+        double S0[P], S1[P1], S2[P2], D0[P], D1[P1], D2[P2];
+        {
+            const double x0 = valid ? (tgt.x[t] - cc[0]) / (len * 0.5) : 0.0; // chebyshev.rs:841-845
+            cheb_S_reg<P, GRAD>(x0, s_polyn, S0, D0);
+            if (D > 1) {
+                const double x1 = valid ? (tgt.y[t] - cc[1]) / (len * 0.5) : 0.0;
+                double s[P], d[P];
+                cheb_S_reg<P, GRAD>(x1, s_polyn, s, d);
+#pragma unroll
+                for (int j = 0; j < P1; ++j) { S1[j] = s[j]; D1[j] = d[j]; }
+            } else {
+                S1[0] = 1.0;
+                D1[0] = 0.0;
+            }
+            if (D > 2) {
+                const double x2 = valid ? (tgt.z[t] - cc[2]) / (len * 0.5) : 0.0;
+                double s[P], d[P];
+                cheb_S_reg<P, GRAD>(x2, s_polyn, s, d);
+#pragma unroll
+                for (int j = 0; j < P2; ++j) { S2[j] = s[j]; D2[j] = d[j]; }
+            } else {
+                S2[0] = 1.0;
+                D2[0] = 0.0;
             }
         }
+        const double gs = 2.0 / len;
         for (int k = 0; k < K; ++k) {
-            __syncthreads();
             const double *Lc = L + ((int64_t)k * C + cell) * n_pad;
-            for (int I = tid; I < n; I += L2P_THREADS) s_L[I] = Lc[I];
-            __syncthreads();
-            if (valid) {
-                const double *S0 = s_S + tid, *S1 = s_S + p * L2P_THREADS + tid, *S2 = s_S + 2 * p * L2P_THREADS + tid;
-                const double *D0 = s_dS + tid, *D1 = s_dS + p * L2P_THREADS + tid,
-                             *D2 = s_dS + 2 * p * L2P_THREADS + tid;
-                double y = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
-                for (int a = 0; a < P0; ++a) {
-                    double ua = 0.0, uay = 0.0, uaz = 0.0;
-                    for (int bb = 0; bb < P1; ++bb) {
-                        double t0 = 0.0, t0z = 0.0;
-                        const double *Lr = s_L + (a * P1 + bb) * P2;
-                        for (int c = 0; c < P2; ++c) {
-                            const double lv = Lr[c];
-                            t0 += S2[c * L2P_THREADS] * lv;
-                            if (GRAD) t0z += D2[c * L2P_THREADS] * lv;
-                        }
-                        const double s1 = S1[bb * L2P_THREADS];
-                        ua += s1 * t0;
-                        if (GRAD) {
-                            uay += D1[bb * L2P_THREADS] * t0;
-                            uaz += s1 * t0z;
-                        }
+            // wave-private LDS slice: in-order LDS ops of one wave need no barrier, only the wait
+            for (int I = lane; I < N; I += 64) Lw[I] = Lc[I];
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0)
+            double y = 0.0, gx = 0.0, gy = 0.0, gz = 0.0;
+#pragma unroll
+            for (int a = 0; a < P; ++a) {
+                double ua = 0.0, uay = 0.0, uaz = 0.0;
+#pragma unroll
+                for (int bb = 0; bb < P1; ++bb) {
+                    double t0 = 0.0, t0z = 0.0;
+#pragma unroll
+                    for (int c = 0; c < P2; ++c) {
+                        const double lv = Lw[(a * P1 + bb) * P2 + c];
+                        t0 += S2[c] * lv;
+                        if (GRAD) t0z += D2[c] * lv;
                     }
-                    const double s0 = S0[a * L2P_THREADS];
-                    y += s0 * ua;
+                    ua += S1[bb] * t0;
                     if (GRAD) {
-                        gx += D0[a * L2P_THREADS] * ua;
-                        gy += s0 * uay;
-                        gz += s0 * uaz;
+                        uay += D1[bb] * t0;
+                        uaz += S1[bb] * t0z;
                     }
                 }
+                y += S0[a] * ua;
+                if (GRAD) {
+                    gx += D0[a] * ua;
+                    gy += S0[a] * uay;
+                    gz += S0[a] * uaz;
+                }
+            }
+            if (valid) {
                 out[(int64_t)k * n_tgt + t] += y;
                 if (GRAD) {
-                    grad[((int64_t)k * d + 0) * n_tgt + t] += gx;
-                    if (d > 1) grad[((int64_t)k * d + 1) * n_tgt + t] += gy;
-                    if (d > 2) grad[((int64_t)k * d + 2) * n_tgt + t] += gz;
+                    grad[((int64_t)k * D + 0) * n_tgt + t] += gx * gs;
+                    if (D > 1) grad[((int64_t)k * D + 1) * n_tgt + t] += gy * gs;
+                    if (D > 2) grad[((int64_t)k * D + 2) * n_tgt + t] += gz * gs;
                 }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -503,13 +538,14 @@ __device__ inline void stage_nodes(SrcTile &tile, const DevCheb *chp, int P1, in
     }
 }
 
-// multipole_to_particle (bbfmm.rs:1254-1355).  One workgroup per target leaf with a W list.
+// multipole_to_particle (bbfmm.rs:1254-1355).  One workgroup per (target leaf, chunk of its W
+// list); chunks of one leaf add into the same targets with hardware f64 atomics.
 template <int KID, bool GRAD, int KB>
 __global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *__restrict__ chp,
-                                                  const int32_t *__restrict__ job_cell,
                                                   const int32_t *__restrict__ tgt_begin,
                                                   const int32_t *__restrict__ tgt_end,
-                                                  const int64_t *__restrict__ w_ptr,
+                                                  const int64_t *__restrict__ w_begin,
+                                                  const int64_t *__restrict__ w_end,
                                                   const int32_t *__restrict__ w_cells,
                                                   const double *__restrict__ centers,
                                                   const double *__restrict__ lengths, Xyz tgt, int64_t n_tgt, int k0,
@@ -523,8 +559,7 @@ __global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *
     const int tid = threadIdx.x;
     const int job = blockIdx.x;
     const int t0 = tgt_begin[job], t1 = tgt_end[job];
-    const int jcell = job_cell[job];
-    const int64_t r0 = w_ptr[jcell], r1 = w_ptr[jcell + 1];
+    const int64_t r0 = w_begin[job], r1 = w_end[job]; // a chunk of the leaf's W list
     for (int tc = t0; tc < t1; tc += 256) {
         const int nt = min(256, t1 - tc);
         const int S = 256 / nt;
@@ -556,11 +591,11 @@ __global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *
         for (int kk = 0; kk < KB; ++kk) {
             if (kk >= kb) break;
             const double v = slice_reduce(acc[kk], red, ti, sl, S, nt, part);
-            if (part && sl == 0) out[(int64_t)(k0 + kk) * n_tgt + tc + ti] += v;
+            if (part && sl == 0) unsafeAtomicAdd(&out[(int64_t)(k0 + kk) * n_tgt + tc + ti], v);
             if (GRAD) {
                 for (int a = 0; a < d; ++a) {
                     const double g = slice_reduce(gacc[kk][a], red, ti, sl, S, nt, part);
-                    if (part && sl == 0) grad[((int64_t)(k0 + kk) * d + a) * n_tgt + tc + ti] += g;
+                    if (part && sl == 0) unsafeAtomicAdd(&grad[((int64_t)(k0 + kk) * d + a) * n_tgt + tc + ti], g);
                 }
             }
         }
@@ -847,7 +882,7 @@ void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w
                 const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin, const int32_t *pt_end,
                 const double *centers, const double *lengths, double *M, hipStream_t s) {
     if (n_leaves == 0) return;
-    hipLaunchKernelGGL(p2m_kernel, dim3(n_leaves), dim3(256), 0, s, ch.dev, make_xyz(src_xyz), w_sorted, N, K, C,
+    hipLaunchKernelGGL(p2m_kernel, dim3(n_leaves), dim3(P2M_THREADS), 0, s, ch.dev, make_xyz(src_xyz), w_sorted, N, K, C,
                        leaf_cells, pt_begin, pt_end, centers, lengths, M);
 }
 
@@ -866,19 +901,55 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
     hipLaunchKernelGGL(l2l_kernel, dim3(n_cells), dim3(256), lds, s, ch.dev, K, C, cells, parent, octant, active, L);
 }
 
+template <int P, int D>
+static void l2p_launch_pd(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const int32_t *tgt_begin,
+                          const int32_t *tgt_end, const double *centers, const double *lengths, Xyz tgt,
+                          int64_t n_tgt, int K, int64_t C, const double *L, double *out_sorted, double *grad_sorted,
+                          hipStream_t s) {
+    const int blocks = (n_jobs + L2P_WAVES - 1) / L2P_WAVES;
+    if (grad_sorted)
+        hipLaunchKernelGGL((l2p_kernel<P, D, true>), dim3(blocks), dim3(64 * L2P_WAVES), 0, s, ch.dev, n_jobs,
+                           leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted,
+                           grad_sorted);
+    else
+        hipLaunchKernelGGL((l2p_kernel<P, D, false>), dim3(blocks), dim3(64 * L2P_WAVES), 0, s, ch.dev, n_jobs,
+                           leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted,
+                           grad_sorted);
+}
+
+template <int P>
+static void l2p_launch_p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const int32_t *tgt_begin,
+                         const int32_t *tgt_end, const double *centers, const double *lengths, Xyz tgt, int64_t n_tgt,
+                         int K, int64_t C, const double *L, double *out_sorted, double *grad_sorted, hipStream_t s) {
+    if (ch.d == 3) {
+        if constexpr (P <= 12) // P^3 doubles per wave must fit the static LDS budget
+            l2p_launch_pd<P, 3>(ch, n_jobs, leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted, grad_sorted, s);
+    } else if (ch.d == 2) {
+        l2p_launch_pd<P, 2>(ch, n_jobs, leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted, grad_sorted, s);
+    } else {
+        l2p_launch_pd<P, 1>(ch, n_jobs, leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted, grad_sorted, s);
+    }
+}
+
+bool l2p_order_supported(int p, int d) { return p >= 2 && p <= kMaxOrder && (d < 3 || p <= 12); }
+
 void launch_l2p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const int32_t *tgt_begin,
                 const int32_t *tgt_end, const double *centers, const double *lengths, const double *const *tgt_xyz,
                 int64_t n_tgt, int K, int64_t C, const double *L, double *out_sorted, double *grad_sorted,
                 hipStream_t s) {
     if (n_jobs == 0) return;
-    const size_t lds =
-        sizeof(double) * (kMaxOrder * kMaxOrder + (size_t)ch.n + 2 * 3 * (size_t)ch.p * L2P_THREADS);
-    if (grad_sorted)
-        hipLaunchKernelGGL(l2p_kernel<true>, dim3(n_jobs), dim3(L2P_THREADS), lds, s, ch.dev, leaf_cells, tgt_begin,
-                           tgt_end, centers, lengths, make_xyz(tgt_xyz), n_tgt, K, C, L, out_sorted, grad_sorted);
-    else
-        hipLaunchKernelGGL(l2p_kernel<false>, dim3(n_jobs), dim3(L2P_THREADS), lds, s, ch.dev, leaf_cells, tgt_begin,
-                           tgt_end, centers, lengths, make_xyz(tgt_xyz), n_tgt, K, C, L, out_sorted, grad_sorted);
+    const Xyz tgt = make_xyz(tgt_xyz);
+#define L2P_CASE(PP)                                                                                            \
+    case PP:                                                                                                    \
+        l2p_launch_p<PP>(ch, n_jobs, leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L,    \
+                         out_sorted, grad_sorted, s);                                                           \
+        break;
+    switch (ch.p) {
+        L2P_CASE(2) L2P_CASE(3) L2P_CASE(4) L2P_CASE(5) L2P_CASE(6) L2P_CASE(7) L2P_CASE(8) L2P_CASE(9)
+        L2P_CASE(10) L2P_CASE(11) L2P_CASE(12) L2P_CASE(13) L2P_CASE(14) L2P_CASE(15) L2P_CASE(16)
+    default: break;
+    }
+#undef L2P_CASE
 }
 
 // Kernel-id dispatch: F is a generic lambda taking std::integral_constant<int, ID>.
@@ -925,8 +996,8 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
     });
 }
 
-void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *job_cell,
-                const int32_t *tgt_begin, const int32_t *tgt_end, const int64_t *w_ptr,
+void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin,
+                const int32_t *tgt_end, const int64_t *w_begin, const int64_t *w_end,
                 const int32_t *w_cells, const double *centers,
                 const double *lengths, const double *const *tgt_xyz, int64_t n_tgt, int K, int64_t C,
                 const double *M, double *out_sorted, double *grad_sorted, hipStream_t s) {
@@ -937,11 +1008,11 @@ void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
             const int kb = std::min(DIRECT_KB, K - k0);
             if (grad_sorted)
                 hipLaunchKernelGGL((m2p_kernel<ID, true, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev,
-                                   job_cell, tgt_begin, tgt_end, w_ptr, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
+                                   tgt_begin, tgt_end, w_begin, w_end, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
                                    kb, C, M, out_sorted, grad_sorted);
             else
                 hipLaunchKernelGGL((m2p_kernel<ID, false, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev,
-                                   job_cell, tgt_begin, tgt_end, w_ptr, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
+                                   tgt_begin, tgt_end, w_begin, w_end, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
                                    kb, C, M, out_sorted, grad_sorted);
         }
     });

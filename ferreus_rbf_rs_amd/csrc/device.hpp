@@ -102,9 +102,10 @@ struct DirectJobs {
 void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const double *const *tgt_xyz,
                 int64_t n_tgt, const double *const *src_xyz, const double *w_sorted, int64_t N, int K,
                 double *out_sorted, double *grad_sorted, hipStream_t s);
-// M2P: sources are the Chebyshev nodes of the W-list cells, weights their multipoles.
-void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *job_cell,
-                const int32_t *tgt_begin, const int32_t *tgt_end, const int64_t *w_ptr,
+// M2P: sources are the Chebyshev nodes of the W-list cells, weights their multipoles.  Job i
+// covers targets [tgt_begin[i], tgt_end[i]) and the W cells w_cells[w_begin[i] .. w_end[i]).
+void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin,
+                const int32_t *tgt_end, const int64_t *w_begin, const int64_t *w_end,
                 const int32_t *w_cells,
                 const double *centers, const double *lengths, const double *const *tgt_xyz,
                 int64_t n_tgt, int K, int64_t C, const double *M, double *out_sorted,
@@ -118,6 +119,9 @@ void launch_l2p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const 
                 const int32_t *tgt_end, const double *centers, const double *lengths,
                 const double *const *tgt_xyz, int64_t n_tgt, int K, int64_t C, const double *L,
                 double *out_sorted, double *grad_sorted, hipStream_t s);
+
+// Orders the device Chebyshev kernels are instantiated for (3-D: p <= 12).
+bool l2p_order_supported(int p, int d);
 
 // FP64 MFMA lane-layout check + peak microbenchmark.
 int mfma_f64_selftest(double *tflops, int *layout_errors, double *info);

@@ -160,6 +160,8 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
     if (order < 2 || order > kMaxOrder)
         return fail(BBFMM_BAD_ARGUMENT, "interpolation_order must be in [2, " + std::to_string(kMaxOrder) + "]");
     if (!(base_range > 0.0)) return fail(BBFMM_BAD_ARGUMENT, "base_range must be positive"); // kernel_helpers.rs:69
+    if (!l2p_order_supported(order, d))
+        return fail(BBFMM_UNSUPPORTED, "interpolation_order > 12 is not instantiated for 3-D trees");
     host_only_ = (flags & BBFMM_FLAG_HOST_ONLY) != 0;
     order_ = order;
     d_ = d;
@@ -578,6 +580,18 @@ int FmmTree::ensure_rhs_capacity(int k) {
     return BBFMM_OK;
 }
 
+// M2P jobs of one leaf: its W list cut into chunks so that a few big leaves still fill the chip.
+static void add_w_jobs(const HostTree &t, int32_t c, int32_t tb, int32_t te, std::vector<int32_t> *wtb,
+                       std::vector<int32_t> *wte, std::vector<int64_t> *wb, std::vector<int64_t> *we) {
+    constexpr int64_t kChunk = 8;
+    for (int64_t q = t.w.ptr[c]; q < t.w.ptr[c + 1]; q += kChunk) {
+        wtb->push_back(tb);
+        wte->push_back(te);
+        wb->push_back(q);
+        we->push_back(std::min(q + kChunk, t.w.ptr[c + 1]));
+    }
+}
+
 // targets = sources: jobs and ranges come straight from the tree
 int FmmTree::build_source_target_set() {
     const HostTree &t = tree_;
@@ -585,25 +599,23 @@ int FmmTree::build_source_target_set() {
     ts.m = t.n_points;
     for (int a = 0; a < 3; ++a) ts.xyz_ptr[a] = src_ptr_[a];
     ts.perm = d_order_;
-    std::vector<int32_t> jc, tb, te, wjc, wtb, wte;
+    std::vector<int32_t> jc, tb, te, wtb, wte;
+    std::vector<int64_t> wb, we;
     for (int32_t c : src_leaves_) {
         jc.push_back(c);
         tb.push_back(static_cast<int32_t>(t.pt_begin[c]));
         te.push_back(static_cast<int32_t>(t.pt_end[c]));
-        if (t.w.ptr[c + 1] > t.w.ptr[c]) {
-            wjc.push_back(c);
-            wtb.push_back(tb.back());
-            wte.push_back(te.back());
-        }
+        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
     }
     ts.n_jobs = static_cast<int>(jc.size());
-    ts.n_w_jobs = static_cast<int>(wjc.size());
+    ts.n_w_jobs = static_cast<int>(wtb.size());
     CHK(dupload(&ts.job_cell, jc));
     CHK(dupload(&ts.tgt_begin, tb));
     CHK(dupload(&ts.tgt_end, te));
-    CHK(dupload(&ts.w_job_cell, wjc));
     CHK(dupload(&ts.w_tgt_begin, wtb));
     CHK(dupload(&ts.w_tgt_end, wte));
+    CHK(dupload(&ts.w_begin, wb));
+    CHK(dupload(&ts.w_end, we));
     return BBFMM_OK;
 }
 
@@ -626,18 +638,15 @@ int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet
         if (cnt[c + 1] > 0) leaves.push_back(static_cast<int32_t>(c));
     std::vector<int64_t> start(static_cast<size_t>(C), 0);
     int64_t cur = 0;
-    std::vector<int32_t> jc, tb, te, wjc, wtb, wte;
+    std::vector<int32_t> jc, tb, te, wtb, wte;
+    std::vector<int64_t> wb, we;
     for (int32_t c : leaves) {
         start[c] = cur;
         jc.push_back(c);
         tb.push_back(static_cast<int32_t>(cur));
         cur += cnt[c + 1];
         te.push_back(static_cast<int32_t>(cur));
-        if (t.w.ptr[c + 1] > t.w.ptr[c]) {
-            wjc.push_back(c);
-            wtb.push_back(tb.back());
-            wte.push_back(te.back());
-        }
+        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
     }
     std::vector<int32_t> perm(static_cast<size_t>(m));
     {
@@ -662,13 +671,14 @@ int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet
     }
     CHK(dupload(&ts->perm, perm));
     ts->n_jobs = static_cast<int>(jc.size());
-    ts->n_w_jobs = static_cast<int>(wjc.size());
+    ts->n_w_jobs = static_cast<int>(wtb.size());
     CHK(dupload(&ts->job_cell, jc));
     CHK(dupload(&ts->tgt_begin, tb));
     CHK(dupload(&ts->tgt_end, te));
-    CHK(dupload(&ts->w_job_cell, wjc));
     CHK(dupload(&ts->w_tgt_begin, wtb));
     CHK(dupload(&ts->w_tgt_end, wte));
+    CHK(dupload(&ts->w_begin, wb));
+    CHK(dupload(&ts->w_end, we));
     return BBFMM_OK;
 }
 
@@ -678,9 +688,10 @@ void FmmTree::free_target_set(TargetSet *ts) {
     dfree(&ts->job_cell);
     dfree(&ts->tgt_begin);
     dfree(&ts->tgt_end);
-    dfree(&ts->w_job_cell);
     dfree(&ts->w_tgt_begin);
     dfree(&ts->w_tgt_end);
+    dfree(&ts->w_begin);
+    dfree(&ts->w_end);
     dfree(&ts->out);
     dfree(&ts->grad);
 }
@@ -769,7 +780,7 @@ int FmmTree::leaf_pass(const TargetSet &ts, int k, bool with_grads) {
     phase_end(kPhP2P);
     phase_begin();
     if (t.adaptive)
-        launch_m2p(kernel_, cheb_, ts.n_w_jobs, ts.w_job_cell.p, ts.w_tgt_begin.p, ts.w_tgt_end.p, d_w_ptr_.p,
+        launch_m2p(kernel_, cheb_, ts.n_w_jobs, ts.w_tgt_begin.p, ts.w_tgt_end.p, ts.w_begin.p, ts.w_end.p,
                    d_w_idx_.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr, ts.m, k, C, d_M_.p, ts.out.p, grad, stream_);
     phase_end(kPhM2P);
     phase_begin();
@@ -994,7 +1005,8 @@ int FmmTree::set_partition(int rank, int world) {
     const int64_t pe = lb < le ? t.pt_end[src_leaves_[le - 1]] : 0;
     ts.m = pe - pb;
     for (int a = 0; a < 3; ++a) ts.xyz_ptr[a] = src_ptr_[a] + pb;
-    std::vector<int32_t> perm(static_cast<size_t>(ts.m)), jc, tb, te, wjc, wtb, wte;
+    std::vector<int32_t> perm(static_cast<size_t>(ts.m)), jc, tb, te, wtb, wte;
+    std::vector<int64_t> wb, we;
     part_rows_.resize(static_cast<size_t>(ts.m));
     for (int64_t i = 0; i < ts.m; ++i) {
         perm[i] = static_cast<int32_t>(t.order[pb + i]);
@@ -1005,21 +1017,18 @@ int FmmTree::set_partition(int rank, int world) {
         jc.push_back(c);
         tb.push_back(static_cast<int32_t>(t.pt_begin[c] - pb));
         te.push_back(static_cast<int32_t>(t.pt_end[c] - pb));
-        if (t.w.ptr[c + 1] > t.w.ptr[c]) {
-            wjc.push_back(c);
-            wtb.push_back(tb.back());
-            wte.push_back(te.back());
-        }
+        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
     }
     ts.n_jobs = static_cast<int>(jc.size());
-    ts.n_w_jobs = static_cast<int>(wjc.size());
+    ts.n_w_jobs = static_cast<int>(wtb.size());
     CHK(dupload(&ts.perm, perm));
     CHK(dupload(&ts.job_cell, jc));
     CHK(dupload(&ts.tgt_begin, tb));
     CHK(dupload(&ts.tgt_end, te));
-    CHK(dupload(&ts.w_job_cell, wjc));
     CHK(dupload(&ts.w_tgt_begin, wtb));
     CHK(dupload(&ts.w_tgt_end, wte));
+    CHK(dupload(&ts.w_begin, wb));
+    CHK(dupload(&ts.w_end, we));
     CHK(dalloc(&ts.out, static_cast<size_t>(std::max(k_cap_, 1)) * std::max<int64_t>(ts.m, 1)));
     have_part_ = true;
     return BBFMM_OK;

@@ -45,7 +45,8 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     DevBuf<int32_t> perm;      // sorted position -> caller's row
     DevBuf<int32_t> job_cell, tgt_begin, tgt_end; // leaves with targets
     int n_jobs = 0;
-    DevBuf<int32_t> w_job_cell, w_tgt_begin, w_tgt_end; // ... that also have a W list
+    DevBuf<int32_t> w_tgt_begin, w_tgt_end;          // M2P jobs: (leaf, chunk of its W list)
+    DevBuf<int64_t> w_begin, w_end;
     int n_w_jobs = 0;
     DevBuf<double> out, grad;  // K x m, K*d x m (sorted order)
 };

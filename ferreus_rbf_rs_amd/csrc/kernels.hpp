@@ -67,7 +67,23 @@ inline KernelSpec make_kernel_spec(int id, double base_range, double total_sill)
     return k;
 }
 
-BBFMM_HD inline double bb_sqrt(double x) { return sqrt(x); }
+// sqrt for the pair loops.  Host: libm.  Device: v_rsq_f64 seed + one Goldschmidt step + one
+// residual correction (about 1 ulp; 9 instructions instead of the ~24 of the correctly rounded
+// library sqrt, measured 96 -> ~56 cycles per wave on MI355X).  x >= 0 always (sum of squares).
+BBFMM_HD inline double bb_sqrt(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);
+    return x > 0.0 ? g : 0.0; // rsq(0) = inf would give NaN
+#else
+    return sqrt(x);
+#endif
+}
 
 // Value from r^2 = distance_sq (utils.rs:230-237).
 template <int ID> BBFMM_HD inline double kernel_value_r2(const KernelSpec &k, double r2) {
