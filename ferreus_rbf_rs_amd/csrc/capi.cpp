@@ -149,15 +149,15 @@ int bbfmm_set_partition(bbfmm_handle *h, int32_t rank, int32_t world) {
 int64_t bbfmm_partition_row_count(const bbfmm_handle *h) {
     if (!h) return -1;
     const auto &r = h->tree.partition_rows();
-    return r.empty() ? h->tree.tree().n_points : static_cast<int64_t>(r.size());
+    return h->tree.partitioned() ? static_cast<int64_t>(r.size()) : h->tree.tree().n_points;
 }
 
 int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out) {
     if (!h || !rows_out) return BBFMM_BAD_ARGUMENT;
     const auto &r = h->tree.partition_rows();
-    if (r.empty()) {
+    if (!h->tree.partitioned()) {
         for (int64_t i = 0; i < h->tree.tree().n_points; ++i) rows_out[i] = i;
-    } else {
+    } else if (!r.empty()) {
         std::memcpy(rows_out, r.data(), r.size() * sizeof(int64_t));
     }
     return BBFMM_OK;

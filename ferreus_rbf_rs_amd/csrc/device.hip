@@ -115,72 +115,138 @@ __device__ inline void cheb_S_to(int p, double x, const double *__restrict__ pol
     }
 }
 
+// ------------------------------------------------------------------ Chebyshev factors in registers
+template <int P, bool GRAD>
+__device__ inline void cheb_S_reg(double x, const double *__restrict__ polyn, double (&S)[P], double (&dS)[P]) {
+    double T[P], dT[P];
+    T[0] = 1.0;
+    dT[0] = 0.0;
+    if (P > 1) {
+        T[1] = x;
+        dT[1] = 1.0;
+    }
+#pragma unroll
+    for (int j = 2; j < P; ++j) {
+        T[j] = 2.0 * x * T[j - 1] - T[j - 2];
+        if (GRAD) dT[j] = 2.0 * T[j - 1] + 2.0 * x * dT[j - 1] - dT[j - 2];
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double s = 0.0, ds = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            const double pk = polyn[j * P + k];
+            s += T[k] * pk;
+            if (GRAD) ds += dT[k] * pk;
+        }
+        S[j] = (s * 2.0 - 1.0) / (double)P;
+        dS[j] = GRAD ? ds * (2.0 / (double)P) : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------ P2M
 // particle_to_multipole (bbfmm.rs:691-739): M_c[:, k] += S(x_leaf)^T w_leaf[:, k].
-// One workgroup per leaf; points in chunks of P2M_PTS; the three 1-D factor tables of a
-// chunk live in LDS; each thread owns output nodes tid, tid+256, ...
-constexpr int P2M_PTS = 64;
-constexpr int P2M_KB = 4;
-constexpr int P2M_THREADS = 384; // 6 waves: one pass over the 343 nodes of an order-7 cell
+// One wave per leaf.  Points are taken 32 at a time: lanes compute the three 1-D factor rows
+// of their point (registers, order P is a template parameter) and park them in a wave-private
+// LDS slice; then lane q owns the node pairs (i1, i2) = q and keeps the P sums over i0 in
+// registers, so a point costs two private LDS reads plus P broadcast reads per lane.
+constexpr int P2M_WAVES = 4;
+constexpr int P2M_PTS = 32;
+constexpr int P2M_KB = 2;
 
-__global__ __launch_bounds__(P2M_THREADS) void p2m_kernel(const DevCheb *__restrict__ chp, Xyz src,
-                                                          const double *__restrict__ ws, int64_t N, int K, int64_t C,
-                                                          const int32_t *__restrict__ leaf_cells,
-                                                          const int32_t *__restrict__ pt_begin,
-                                                          const int32_t *__restrict__ pt_end,
-                                                          const double *__restrict__ centers,
-                                                          const double *__restrict__ lengths, double *__restrict__ M) {
-    __shared__ double s_polyn[kMaxOrder * kMaxOrder];
-    __shared__ double s_S[3][P2M_PTS][kMaxOrder + 1]; // node index fastest: the 7..16 values a wave reads sit in distinct banks
-    __shared__ double s_w[P2M_KB][P2M_PTS];
-    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
-    int P0, P1, P2;
-    axis_sizes(p, d, P0, P1, P2);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < p * p; i += P2M_THREADS) s_polyn[i] = chp->polyn[i];
-    const int cell = leaf_cells[blockIdx.x];
+template <int P, int D>
+__global__ __launch_bounds__(64 * P2M_WAVES) void p2m_kernel(const DevCheb *__restrict__ chp, int n_leaves, Xyz src,
+                                                             const double *__restrict__ ws, int64_t N, int K,
+                                                             int64_t C, const int32_t *__restrict__ leaf_cells,
+                                                             const int32_t *__restrict__ pt_begin,
+                                                             const int32_t *__restrict__ pt_end,
+                                                             const double *__restrict__ centers,
+                                                             const double *__restrict__ lengths,
+                                                             double *__restrict__ M) {
+    constexpr int P1 = D > 1 ? P : 1, P2 = D > 2 ? P : 1, NPAIR = P1 * P2;
+    constexpr int NPASS = (NPAIR + 63) / 64;
+    constexpr int SROW = 3 * P + P2M_KB; // per point: S0[P], S1[P], S2[P], w[KB]
+    __shared__ double s_polyn[P * P];
+    __shared__ double s_pts[P2M_WAVES][P2M_PTS][SROW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int i = tid; i < P * P; i += 64 * P2M_WAVES) s_polyn[i] = chp->polyn[i];
+    __syncthreads();
+    const int job = blockIdx.x * P2M_WAVES + wave;
+    if (job >= n_leaves) return; // whole wave; no block barrier below
+    const int n_pad = chp->n_pad;
+    const int cell = leaf_cells[job];
     const int b = pt_begin[cell], e = pt_end[cell];
     const double len = lengths[cell];
-    const double cx = centers[cell * 3 + 0], cy = centers[cell * 3 + 1], cz = centers[cell * 3 + 2];
-    __syncthreads();
-    for (int base = b; base < e; base += P2M_PTS) {
-        const int npts = min(P2M_PTS, e - base);
-        // 1-D factors: thread -> (axis, point)
-        if (tid < 3 * P2M_PTS) {
-            const int axis = tid / P2M_PTS, pt = tid % P2M_PTS;
-            if (pt < npts) {
-                if (axis < d) {
-                    const double *co = axis == 0 ? src.x : (axis == 1 ? src.y : src.z);
-                    const double c0 = axis == 0 ? cx : (axis == 1 ? cy : cz);
-                    const double x = (co[base + pt] - c0) / (len * 0.5); // chebyshev.rs:841-845
-                    cheb_S_to<false>(p, x, s_polyn, &s_S[axis][pt][0], nullptr, 1);
-                } else {
-                    s_S[axis][pt][0] = 1.0;
-                }
-            }
-        }
-        for (int k0 = 0; k0 < K; k0 += P2M_KB) {
-            const int kb = min(P2M_KB, K - k0);
-            __syncthreads();
-            if (tid < P2M_PTS)
-                for (int kk = 0; kk < kb; ++kk)
-                    if (tid < npts) s_w[kk][tid] = ws[(int64_t)(k0 + kk) * N + base + tid];
-            __syncthreads();
-            for (int I = tid; I < n; I += P2M_THREADS) {
-                const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1);
-                double acc[P2M_KB] = {0.0, 0.0, 0.0, 0.0};
-                for (int pt = 0; pt < npts; ++pt) {
-                    const double v = s_S[0][pt][i0] * s_S[1][pt][i1] * s_S[2][pt][i2];
+    const double cc[3] = {centers[cell * 3 + 0], centers[cell * 3 + 1], centers[cell * 3 + 2]};
+    double(*sp)[SROW] = s_pts[wave];
+    for (int k0 = 0; k0 < K; k0 += P2M_KB) {
+        double acc[NPASS][P2M_KB][P];
 #pragma unroll
-                    for (int kk = 0; kk < P2M_KB; ++kk)
-                        if (kk < kb) acc[kk] += v * s_w[kk][pt];
+        for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+            for (int kk = 0; kk < P2M_KB; ++kk)
+#pragma unroll
+                for (int i0 = 0; i0 < P; ++i0) acc[ps][kk][i0] = 0.0;
+        for (int base = b; base < e; base += P2M_PTS) {
+            const int npts = min(P2M_PTS, e - base);
+            if (lane < npts) {
+                const int pt = base + lane;
+                double S[P], dS[P];
+                cheb_S_reg<P, false>((src.x[pt] - cc[0]) / (len * 0.5), s_polyn, S, dS); // chebyshev.rs:841-845
+#pragma unroll
+                for (int jx = 0; jx < P; ++jx) sp[lane][jx] = S[jx];
+                if (D > 1) {
+                    cheb_S_reg<P, false>((src.y[pt] - cc[1]) / (len * 0.5), s_polyn, S, dS);
+#pragma unroll
+                    for (int jx = 0; jx < P; ++jx) sp[lane][P + jx] = S[jx];
+                } else {
+                    sp[lane][P] = 1.0;
+                }
+                if (D > 2) {
+                    cheb_S_reg<P, false>((src.z[pt] - cc[2]) / (len * 0.5), s_polyn, S, dS);
+#pragma unroll
+                    for (int jx = 0; jx < P; ++jx) sp[lane][2 * P + jx] = S[jx];
+                } else {
+                    sp[lane][2 * P] = 1.0;
                 }
 #pragma unroll
                 for (int kk = 0; kk < P2M_KB; ++kk)
-                    if (kk < kb) M[((int64_t)(k0 + kk) * C + cell) * n_pad + I] += acc[kk];
+                    sp[lane][3 * P + kk] = (k0 + kk < K) ? ws[(int64_t)(k0 + kk) * N + pt] : 0.0;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): wave-private slice, in-order LDS
+#pragma unroll
+            for (int ps = 0; ps < NPASS; ++ps) {
+                const int q = lane + 64 * ps;
+                if (q < NPAIR) {
+                    const int i1 = q / P2, i2 = q - i1 * P2;
+                    for (int pt = 0; pt < npts; ++pt) {
+                        const double *row = sp[pt];
+                        const double s12 = row[P + i1] * row[2 * P + i2];
+#pragma unroll
+                        for (int kk = 0; kk < P2M_KB; ++kk) {
+                            const double v = s12 * row[3 * P + kk];
+#pragma unroll
+                            for (int i0 = 0; i0 < P; ++i0) acc[ps][kk][i0] += v * row[i0];
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // reads done before the slice is rewritten
+        }
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+            const int q = lane + 64 * ps;
+            if (q < NPAIR) {
+#pragma unroll
+                for (int kk = 0; kk < P2M_KB; ++kk) {
+                    if (k0 + kk < K) {
+                        double *Mc = M + ((int64_t)(k0 + kk) * C + cell) * n_pad + q;
+#pragma unroll
+                        for (int i0 = 0; i0 < P; ++i0) Mc[i0 * NPAIR] += acc[ps][kk][i0];
+                    }
+                }
             }
         }
-        __syncthreads();
     }
 }
 
@@ -288,34 +354,6 @@ __global__ __launch_bounds__(256) void l2l_kernel(const DevCheb *__restrict__ ch
 // (dS scaled by 2/length, chebyshev.rs:862-869).  One wave per leaf, one lane per target; the
 // 1-D factors live in registers (order P is a template parameter), L_leaf is broadcast from LDS.
 constexpr int L2P_WAVES = 4;
-
-template <int P, bool GRAD>
-__device__ inline void cheb_S_reg(double x, const double *__restrict__ polyn, double (&S)[P], double (&dS)[P]) {
-    double T[P], dT[P];
-    T[0] = 1.0;
-    dT[0] = 0.0;
-    if (P > 1) {
-        T[1] = x;
-        dT[1] = 1.0;
-    }
-#pragma unroll
-    for (int j = 2; j < P; ++j) {
-        T[j] = 2.0 * x * T[j - 1] - T[j - 2];
-        if (GRAD) dT[j] = 2.0 * T[j - 1] + 2.0 * x * dT[j - 1] - dT[j - 2];
-    }
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        double s = 0.0, ds = 0.0;
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const double pk = polyn[j * P + k];
-            s += T[k] * pk;
-            if (GRAD) ds += dT[k] * pk;
-        }
-        S[j] = (s * 2.0 - 1.0) / (double)P;
-        dS[j] = GRAD ? ds * (2.0 / (double)P) : 0.0;
-    }
-}
 
 template <int P, int D, bool GRAD>
 __global__ __launch_bounds__(64 * L2P_WAVES) void l2p_kernel(const DevCheb *__restrict__ chp, int n_jobs,
@@ -878,12 +916,40 @@ __global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ 
 // ------------------------------------------------------------------ launch helpers
 static Xyz make_xyz(const double *const *p) { return Xyz{p[0], p[1], p[2]}; }
 
+template <int P, int D>
+static void p2m_launch_pd(const ChebRef &ch, Xyz src, const double *w_sorted, int64_t N, int K, int64_t C,
+                          const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin, const int32_t *pt_end,
+                          const double *centers, const double *lengths, double *M, hipStream_t s) {
+    const int blocks = (n_leaves + P2M_WAVES - 1) / P2M_WAVES;
+    hipLaunchKernelGGL((p2m_kernel<P, D>), dim3(blocks), dim3(64 * P2M_WAVES), 0, s, ch.dev, n_leaves, src, w_sorted, N,
+                       K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
+}
+
 void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w_sorted, int64_t N, int K, int64_t C,
                 const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin, const int32_t *pt_end,
                 const double *centers, const double *lengths, double *M, hipStream_t s) {
     if (n_leaves == 0) return;
-    hipLaunchKernelGGL(p2m_kernel, dim3(n_leaves), dim3(P2M_THREADS), 0, s, ch.dev, make_xyz(src_xyz), w_sorted, N, K, C,
-                       leaf_cells, pt_begin, pt_end, centers, lengths, M);
+    const Xyz src = make_xyz(src_xyz);
+#define P2M_CASE(PP)                                                                                               \
+    case PP:                                                                                                       \
+        if (ch.d == 3) {                                                                                           \
+            if constexpr (PP <= 12)                                                                                \
+                p2m_launch_pd<PP, 3>(ch, src, w_sorted, N, K, C, leaf_cells, n_leaves, pt_begin, pt_end, centers,  \
+                                     lengths, M, s);                                                               \
+        } else if (ch.d == 2) {                                                                                    \
+            p2m_launch_pd<PP, 2>(ch, src, w_sorted, N, K, C, leaf_cells, n_leaves, pt_begin, pt_end, centers,      \
+                                 lengths, M, s);                                                                   \
+        } else {                                                                                                   \
+            p2m_launch_pd<PP, 1>(ch, src, w_sorted, N, K, C, leaf_cells, n_leaves, pt_begin, pt_end, centers,      \
+                                 lengths, M, s);                                                                   \
+        }                                                                                                          \
+        break;
+    switch (ch.p) {
+        P2M_CASE(2) P2M_CASE(3) P2M_CASE(4) P2M_CASE(5) P2M_CASE(6) P2M_CASE(7) P2M_CASE(8) P2M_CASE(9)
+        P2M_CASE(10) P2M_CASE(11) P2M_CASE(12) P2M_CASE(13) P2M_CASE(14) P2M_CASE(15) P2M_CASE(16)
+    default: break;
+    }
+#undef P2M_CASE
 }
 
 void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents, const int64_t *child_ptr,

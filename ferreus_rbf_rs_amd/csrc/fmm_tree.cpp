@@ -934,9 +934,10 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
     return BBFMM_OK;
 }
 
-// Multi-GPU: own a contiguous range of the leaves in sorted-point (Morton DFS) order.
+// Multi-GPU: own a contiguous range of the leaves in sorted-point (Morton DFS) order.  The
+// host part (owned rows, active cells, M2L tiles) also runs on BBFMM_FLAG_HOST_ONLY handles so
+// that the N > 1 bookkeeping is testable without a device.
 int FmmTree::set_partition(int rank, int world) {
-    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     if (world < 1 || rank < 0 || rank >= world) return fail(BBFMM_BAD_ARGUMENT, "bad rank/world");
     const HostTree &t = tree_;
     const int64_t N = t.n_points, C = t.n_cells();
@@ -950,7 +951,7 @@ int FmmTree::set_partition(int rank, int world) {
     part_rows_.clear();
     std::vector<uint8_t> active(static_cast<size_t>(C), 1);
     if (world == 1) {
-        HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
+        if (!host_only_) HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
         return BBFMM_OK;
     }
     // balance the leaf-pass + M2L work proxy: P2P pair count + a per-point share of the far field
@@ -982,7 +983,6 @@ int FmmTree::set_partition(int rank, int world) {
             c = t.parent[c];
         }
     }
-    HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
     // M2L tiles that contain an active target (stage 2) or a source of one (stage 1)
     std::vector<uint8_t> needed(static_cast<size_t>(C), 0);
     for (int64_t B = 0; B < C; ++B) {
@@ -998,20 +998,22 @@ int FmmTree::set_partition(int rank, int world) {
         if (any) m2l_tiles_part_h_.push_back(td);
     }
     n_m2l_tiles_part_ = static_cast<int>(m2l_tiles_part_h_.size());
-    CHK(dupload(&d_m2l_tiles_part_, m2l_tiles_part_h_));
     // owned targets: one contiguous range of the sorted sources
-    TargetSet &ts = part_targets_;
     const int64_t pb = lb < le ? t.pt_begin[src_leaves_[lb]] : 0;
     const int64_t pe = lb < le ? t.pt_end[src_leaves_[le - 1]] : 0;
+    part_rows_.resize(static_cast<size_t>(pe - pb));
+    for (int64_t i = 0; i < pe - pb; ++i) part_rows_[i] = t.order[pb + i];
+    part_empty_ = pe == pb;
+    if (host_only_) return BBFMM_OK;
+
+    HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
+    CHK(dupload(&d_m2l_tiles_part_, m2l_tiles_part_h_));
+    TargetSet &ts = part_targets_;
     ts.m = pe - pb;
     for (int a = 0; a < 3; ++a) ts.xyz_ptr[a] = src_ptr_[a] + pb;
     std::vector<int32_t> perm(static_cast<size_t>(ts.m)), jc, tb, te, wtb, wte;
     std::vector<int64_t> wb, we;
-    part_rows_.resize(static_cast<size_t>(ts.m));
-    for (int64_t i = 0; i < ts.m; ++i) {
-        perm[i] = static_cast<int32_t>(t.order[pb + i]);
-        part_rows_[i] = t.order[pb + i];
-    }
+    for (int64_t i = 0; i < ts.m; ++i) perm[i] = static_cast<int32_t>(t.order[pb + i]);
     for (size_t i = lb; i < le; ++i) {
         const int32_t c = src_leaves_[i];
         jc.push_back(c);

@@ -91,6 +91,7 @@ class FmmTree {
         for (int64_t &v : phase_count_) v = 0;
     }
     const std::vector<int64_t> &partition_rows() const { return part_rows_; }
+    bool partitioned() const { return part_world_ > 1; }
     const std::vector<HostM2lClass> &m2l_host() const { return m2l_host_; }
     // Test hook (host loops over the stacked M2L tables; needs BBFMM_FLAG_HOST_ONLY).
     // M, L: n_cells x n (cell-major, one rhs).  L is accumulated into.
@@ -144,6 +145,7 @@ class FmmTree {
     // partition
     int part_rank_ = 0, part_world_ = 1;
     std::vector<int64_t> part_rows_;
+    bool part_empty_ = false;
     std::vector<M2lTileDesc> m2l_tiles_part_h_;
 
     // ---- device state

@@ -1,0 +1,43 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build the HIP library (cross-compiles without a GPU) and the oracle's C passes once."""
+    from ferreus_rbf_rs_amd import build as b
+    lib = os.path.join(ROOT, "ferreus_rbf_rs_amd", "libferreus_bbfmm_hip.so")
+    if not os.path.exists(lib):      # the driver's build() normally did this already
+        b.build()
+    from oracle import bbfmm_oracle as O
+    O.build_passes()
+    return True
+
+
+def relerr(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+def inject_product_operators(tree, oracle_tree):
+    """Run the oracle's passes on the product's host-computed M2L operators so that only the
+    summation order differs between the two."""
+    ranks = tree.m2l_ranks()
+    oracle_tree.set_m2l_operators({lvl: [tree.m2l_factors(lvl, r) for r in range(ranks.shape[1])]
+                                   for lvl in range(2, oracle_tree.depth + 1)})
+
+
+def clustered_points(rng, n, d):
+    return np.clip(rng.normal(size=(n, d)) * 0.07 + 0.5, 0.0, 0.999)

@@ -1,0 +1,220 @@
+"""Parity of the HIP path (through the C ABI) with the CPU oracle, on a real MI355X.
+
+Tolerances (floating point, f64 throughout):
+  * 1e-11 relative (max norm) against the oracle running the SAME host-computed M2L operators:
+    only the summation order differs;
+  * the BBFMM accuracy (~10^-order * O(10)) against the oracle with its own operators and against
+    the dense direct sum.
+Tree indexing is compared for exact equality in tests/test_host_structure.py (no GPU needed)."""
+import numpy as np
+import pytest
+
+import ferreus_rbf_rs_amd as F
+from conftest import clustered_points, inject_product_operators, relerr
+from oracle import bbfmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+def make(pts, kid=0, order=7, adaptive=True, sparse=True, extents=None, params=None, br=1.0, sill=1.0, inject=True):
+    fp = None if params is None else F.FmmParams(*params)
+    op = None if params is None else O.FmmParams(*params)
+    t = F.FmmTree(pts, order, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill), adaptive, sparse,
+                  extents=extents, params=fp)
+    r = O.FmmTree(pts, order, kid, adaptive, sparse, extents, op, base_range=br, total_sill=sill)
+    if inject:
+        inject_product_operators(t, r)
+    return t, r
+
+
+def check(pts, nrhs=1, targets=None, grads=False, dense_tol=1e-6, seed=0, **kw):
+    rng = np.random.default_rng(seed)
+    t, r = make(pts, **kw)
+    w = rng.random((pts.shape[0], nrhs))
+    t.set_weights(w)
+    r.set_weights(w)
+    assert relerr(t.debug_get_coefficients("M", nrhs), r.M) < TOL           # P2M + M2M
+    tp = pts if targets is None else targets
+    if grads:
+        y, g = t.evaluate_with_gradients(w, tp)
+        yr, gr = r.evaluate_with_gradients(w, tp)
+        assert relerr(g, gr) < 1e-9
+    else:
+        y, yr = t.evaluate(w, tp), r.evaluate(w, tp)
+    if targets is None:                                                      # all cells carry targets
+        assert relerr(t.debug_get_coefficients("L", nrhs), r.L) < TOL       # M2L + P2L + L2L
+    assert relerr(y, yr) < TOL                                               # + P2P + M2P + L2P
+    kid = kw.get("kid", 0)
+    idx = rng.choice(len(tp), min(len(tp), 300), replace=False)
+    yd = O.dense_sum(kid, kw.get("br", 1.0), kw.get("sill", 1.0), tp[idx], pts, w)
+    assert relerr(y[idx], yd) < dense_tol
+    return t, r, w
+
+
+def test_mfma_lane_layout_and_peak():
+    tf, errs = F.mfma_f64_selftest()
+    assert errs == 0                       # the v_mfma_f64_4x4x4 lane maps the M2L kernels assume
+    assert tf > 20.0                       # sanity: a bare MFMA loop reaches tens of TFLOP/s
+
+
+def test_config1_50k_linear():
+    # BASELINE.json configs[0]: 50k random points, single rhs (reference-native kernel)
+    check(np.random.default_rng(1).random((50000, 3)))
+
+
+def test_mixed_levels_two_rhs():
+    t, r, _ = check(np.random.default_rng(2).random((130000, 3)), nrhs=2)
+    assert t.stats().n_w > 0 and t.stats().n_x == t.stats().n_w
+
+
+def test_gradients_cubic_mixed_levels():
+    check(np.random.default_rng(3).random((130000, 3)), kid=2, grads=True)
+
+
+def test_clustered_tps_order9():
+    check(clustered_points(np.random.default_rng(4), 60000, 3), kid=1, order=9, dense_tol=1e-8)
+
+
+@pytest.mark.parametrize("kid,br,sill,tol", [(3, 0.5, 0.4, 5e-6), (4, 0.5, 0.4, 5e-6), (5, 0.5, 0.4, 5e-6),
+                                             (6, 0.5, 0.4, 5e-6), (7, 1, 1, 1e-6), (8, 1, 1, 5e-6), (9, 1, 1, 5e-5),
+                                             (100, 1.0, 1.0, 1e-5), (101, 0.3, 0.3, 1e-6)])
+def test_every_kernel(kid, br, sill, tol):
+    check(np.random.default_rng(5).random((20000, 3)), kid=kid, br=br, sill=sill, dense_tol=tol)
+
+
+def test_two_and_one_dimensions():
+    check(np.random.default_rng(6).random((30000, 2)))
+    check(np.random.default_rng(7).random((5000, 1)), dense_tol=1e-10)
+
+
+def test_evaluator_flow_non_sparse_extents_arbitrary_targets():
+    # ferreus_bbfmm/src/lib.rs:236-293
+    rng = np.random.default_rng(8)
+    pts = rng.random((20000, 3)) * 2 - 1
+    tg = rng.random((3000, 3)) * 4 - 2
+    t, r, w = check(pts, nrhs=2, targets=tg, sparse=False, extents=[-2, -2, -2, 2, 2, 2])
+    t.set_local_coefficients(w)
+    r.set_local_coefficients(w)
+    assert relerr(t.debug_get_coefficients("L", 2), r.L) < TOL
+    for m in (100, 1000):
+        x = rng.random((m, 3)) * 4 - 2
+        assert relerr(t.evaluate_leaves(w, x), r.evaluate_leaves(w, x)) < TOL
+    y, g = t.evaluate_leaves_with_gradients(w, x)
+    yr, gr = r.evaluate_leaves_with_gradients(w, x)
+    assert relerr(y, yr) < TOL and relerr(g, gr) < 1e-9 and g.shape == (1000, 6)
+    assert t.evaluate(w, np.zeros((0, 3))).shape == (0, 2)                   # empty target set
+
+
+def test_regular_tree_and_compression_modes():
+    pts = np.random.default_rng(9).random((20000, 3))
+    check(pts, adaptive=False)
+    check(pts, adaptive=False, sparse=False)
+    check(pts, kid=2, params=(256, 1, 1e-7, 1024))      # SVD
+    check(pts[:8000], kid=2, params=(64, 0, 1e-7, 1024))  # uncompressed
+
+
+def test_other_orders():
+    pts = np.random.default_rng(10).random((20000, 3))
+    check(pts, order=5, dense_tol=1e-4)
+    check(pts, order=6, dense_tol=1e-4)
+    check(pts, order=8, dense_tol=1e-6)
+    check(pts, kid=2, order=11, params=(400, 2, 1e-9, 1024), dense_tol=1e-8)
+
+
+def test_independent_operators_agree_to_bbfmm_accuracy():
+    """Oracle with its OWN ACA/SVD operators (no injection): agreement to the compression tolerance."""
+    pts = np.random.default_rng(11).random((30000, 3))
+    t, r = make(pts, inject=False)
+    w = np.random.default_rng(12).random((30000, 1))
+    t.set_weights(w)
+    r.set_weights(w)
+    assert relerr(t.evaluate(w, pts), r.evaluate(w, pts)) < 1e-6
+
+
+def test_errors_match_the_reference():
+    # ferreus_bbfmm/src/bbfmm.rs:1464-1500 through the whole ABI (set_weights included)
+    t = F.FmmTree(np.array([[0.5]]), 3, F.KernelParams(F.FmmKernelType.LinearRbf), True, False, extents=[0.0, 1.0])
+    t.set_weights(np.array([[1.0]]))
+    with pytest.raises(F.PointOutsideTree) as e:
+        t.evaluate(np.array([[1.0]]), np.array([[0.5], [10.0]]))
+    assert e.value.point_index == 1 and isinstance(e.value, ValueError)
+    assert "target point at row 1 lies outside the tree extents" in str(e.value)
+    y = t.evaluate(np.array([[1.0]]), np.array([[0.5], [0.25]]))
+    assert y[0, 0] == 0.0 and y[1, 0] == pytest.approx(-0.25, abs=1e-15)
+    with pytest.raises(F.PointOutsideTree):
+        t.evaluate_leaves(np.array([[1.0]]), np.array([[7.0]])) if t.set_local_coefficients(np.array([[1.0]])) is None else None
+    t2 = F.FmmTree(np.random.rand(100, 3), 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True)
+    with pytest.raises(ValueError):
+        t2.evaluate(np.ones((100, 1)), np.random.rand(5, 3))                 # set_weights not called yet
+
+
+def test_fast_matrix_vector_product_semantics():
+    # ferreus_rbf/src/rbf.rs:1338-1379: subset rows, nugget, polynomial tail, zero elsewhere
+    rng = np.random.default_rng(13)
+    n = 20000
+    pts = rng.random((n, 3))
+    t, r = make(pts)
+    wf = rng.random(n + 4)
+    P = np.hstack([np.ones((n, 1)), pts])
+    full = t.fast_matrix_vector_product(wf, 4, None, P, 0.01)
+    assert relerr(full, O.fast_matrix_vector_product(r, wf, 4, None, P, 0.01)) < TOL
+    assert np.all(full[n:] == 0.0)
+    sub = rng.choice(n, 3000, replace=False)
+    part = t.fast_matrix_vector_product(wf, 4, sub, P, 0.01)
+    assert relerr(part, O.fast_matrix_vector_product(r, wf, 4, sub, P, 0.01)) < TOL
+    mask = np.ones(n + 4, bool)
+    mask[sub] = False
+    assert np.all(part[mask] == 0.0) and relerr(part[sub], full[sub]) < TOL
+
+
+def test_device_resident_matvec_and_partition_union():
+    """bbfmm_matvec_device on torch tensors; the owned rows of a 4-way partition reassemble it."""
+    import torch
+    rng = np.random.default_rng(14)
+    n, k = 60000, 2
+    pts = rng.random((n, 3))
+    t, r = make(pts)
+    w = rng.random((n, k))
+    dw = torch.from_numpy(np.ascontiguousarray(w.T)).cuda()
+    out = torch.zeros((k, n), dtype=torch.float64, device="cuda")
+    t.matvec_device(dw.data_ptr(), n, k, out.data_ptr(), n, True)
+    r.set_weights(w)
+    yr = r.evaluate(w, pts)
+    assert relerr(out.cpu().numpy().T, yr) < TOL
+    acc = torch.full((k, n), float("nan"), dtype=torch.float64, device="cuda")
+    total = 0
+    for rank in range(4):
+        t.set_partition(rank, 4)
+        rows = torch.from_numpy(t.partition_rows()).cuda()
+        tmp = torch.full((k, n), float("nan"), dtype=torch.float64, device="cuda")
+        t.matvec_device(dw.data_ptr(), n, k, tmp.data_ptr(), n, True)
+        acc[:, rows] = tmp[:, rows]
+        total += rows.numel()
+    t.set_partition(0, 1)
+    assert total == n and relerr(acc.cpu().numpy().T, yr) < TOL
+
+
+def test_full_size_10m_properties():
+    """BASELINE.json's 10M-point size: linearity, symmetry of the kernel matrix, sampled dense rows."""
+    import torch
+    n = 10_000_000
+    pts = np.random.default_rng(42).random((n, 3))
+    t = F.FmmTree(pts, 7, F.KernelParams(F.FmmKernelType.LinearRbf), True, True)
+    s = t.stats()
+    assert s.depth == 6 and s.n_points == n
+    g = torch.Generator(device="cuda").manual_seed(1)
+    w = torch.rand((2, n), dtype=torch.float64, device="cuda", generator=g)
+    y = torch.zeros_like(w)
+    t.matvec_device(w.data_ptr(), n, 2, y.data_ptr(), n, True)
+    a, b = 0.75, -1.5
+    wc = (a * w[0] + b * w[1]).reshape(1, n).contiguous()
+    yc = torch.zeros_like(wc)
+    t.matvec_device(wc.data_ptr(), n, 1, yc.data_ptr(), n, True)
+    lin = (yc[0] - (a * y[0] + b * y[1])).abs().max() / yc.abs().max()
+    assert float(lin) < 1e-12                                   # linearity of the whole pipeline
+    sym = abs(float(torch.dot(w[1], y[0]) - torch.dot(w[0], y[1]))) / abs(float(torch.dot(w[1], y[0])))
+    assert sym < 1e-7                                           # K = K^T up to the far-field approximation
+    idx = np.random.default_rng(2).choice(n, 64, replace=False)
+    yd = O.dense_sum(0, 1.0, 1.0, pts[idx], pts, w[0].cpu().numpy()[:, None])
+    assert relerr(y[0].cpu().numpy()[idx][:, None], yd) < 1e-6
