@@ -778,22 +778,29 @@ __device__ inline void dma16s(const double *sbase, unsigned voff_bytes, unsigned
 // IN values of four cells (the same for every block), D_b[i][j] = OUT[cell j][col 4b + i].  A wave
 // owns 16 cells (four groups tg) and keeps 4 x NG16 accumulators; the operator tile and the
 // cells' IN values of step q+1 stream into LDS by DMA while step q is multiplied.
-template <int NG16, int STAGE>
-__global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ classes,
+template <int NG16, int STAGE, int MINW>
+__global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restrict__ classes,
                                                   const M2lTileDesc *__restrict__ tiles, int n_pad, int g16_0,
                                                   int64_t C, const double *__restrict__ in, int64_t in_len,
-                                                  double *__restrict__ out, int64_t out_len) {
+                                                  double *__restrict__ out, int64_t out_len,
+                                                  const uint16_t *__restrict__ qlist) {
     extern __shared__ double lds[]; // 2 x { operator [e][ng][k*16 + col], IN tile [wave][tg][eh][k][j] x 2 }
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
     const int kr = blockIdx.y;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // stage 1: blockIdx.z selects a block of 16*NG16 stacked rows; stage 2: g16_0 selects the nodes
-    const int col0 = STAGE == 1 ? (int)blockIdx.z * 16 * NG16 : 16 * g16_0;
+    // stage 1: the workgroup walks the column blocks zb0 .. zb1 of kM2lS1Block stacked rows (g16_0
+    // selects a chunk inside a block); stage 2: one block, g16_0 selects the nodes
+    const int n_zb = STAGE == 1 ? cls.r_pad16 / kM2lS1Block : 1;
+    const int zb0 = STAGE == 1 ? (int)((int64_t)n_zb * blockIdx.z / gridDim.z) : 0;
+    const int zb1 = STAGE == 1 ? (int)((int64_t)n_zb * (blockIdx.z + 1) / gridDim.z) : 1;
     const int ld = STAGE == 1 ? cls.r_pad16 : n_pad;            // operator leading dimension
-    const int nq = STAGE == 1 ? n_pad / 16 : cls.k_pad / 16;    // contraction steps of 16
-    if (STAGE == 1 && col0 >= cls.r_pad16) return;
-    const double *opbase = (STAGE == 1 ? cls.vt_all : cls.u_all) + col0;
+    // contraction steps of 16: all of them in stage 1; in stage 2 only those for which some cell
+    // of the tile has a V-list entry (tile.q_first/q_count index the compact list qlist)
+    const int nq = STAGE == 1 ? n_pad / 16 : tile.q_count;
+    const uint16_t *ql = qlist + tile.q_first;
+    if (zb0 >= zb1) return;
+    const double *opbase = (STAGE == 1 ? cls.vt_all : cls.u_all) + 16 * g16_0;
 
     constexpr int OP_CHUNKS = 2 * NG16;
     constexpr int NCH = (OP_CHUNKS + 7) / 8;
@@ -820,11 +827,15 @@ __global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ 
     }
     const unsigned lds0 = lds_offset(lds);
     const int64_t qstride = (int64_t)16 * ld;
-    auto stage = [&](int q, int buf) {
+    // step s of the flattened (column block, contraction step) loop
+    auto stage = [&](int sidx, int buf) {
+        const int zb = zb0 + sidx / nq, qi = sidx - (sidx / nq) * nq;
+        const int q = STAGE == 1 ? qi : (int)ql[qi];
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
             if (wave + 8 * i < OP_CHUNKS)
-                dma16s(opbase + q * qstride, voff[i], lds0 + (unsigned)(buf * BUF + (wave + 8 * i) * 128) * 8u);
+                dma16s(opbase + (int64_t)zb * kM2lS1Block + q * qstride, voff[i],
+                       lds0 + (unsigned)(buf * BUF + (wave + 8 * i) * 128) * 8u);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
             dma16(cptr[h] + 16 * q, lds0 + (unsigned)(buf * BUF + OP_DOUBLES + (2 * wave + h) * 128) * 8u);
@@ -837,12 +848,14 @@ __global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ 
         for (int g = 0; g < NG16; ++g) acc[tg][g] = 0.0;
 
     const int bk = lane >> 4, bj = lane & 3; // B layout (k, j); the block index is broadcast
-    stage(0, 0);
+    const int n_steps = (zb1 - zb0) * nq;
+    if (n_steps > 0) stage(0, 0);
     wait_dma_and_barrier();
-    for (int q = 0; q < nq; ++q) {
-        const double *op = lds + (q & 1) * BUF + lane;
-        const double *ct = lds + (q & 1) * BUF + OP_DOUBLES + wave * 256 + (bk * 4 + bj) * 2;
-        if (q + 1 < nq) stage(q + 1, (q + 1) & 1); // streams in under the MFMAs below
+    int qcnt = 0, zb = zb0;
+    for (int sidx = 0; sidx < n_steps; ++sidx) {
+        const double *op = lds + (sidx & 1) * BUF + lane;
+        const double *ct = lds + (sidx & 1) * BUF + OP_DOUBLES + wave * 256 + (bk * 4 + bj) * 2;
+        if (sidx + 1 < n_steps) stage(sidx + 1, (sidx + 1) & 1); // streams in under the MFMAs below
         double bq[4][4];
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg)
@@ -861,8 +874,10 @@ __global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ 
                 for (int tg = 0; tg < 4; ++tg) acc[tg][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bq[tg][e], acc[tg][g], 0, 0, 0);
             }
         }
-        wait_dma_and_barrier();
-    }
+        if (++qcnt == nq) { // a column block is complete: write it out, start the next one
+            qcnt = 0;
+            const int col0 = zb * kM2lS1Block + 16 * g16_0;
+            ++zb;
     // epilogue: D[b][i][j] at lane 16 i + 4 b + j = OUT[cell 4 tg + j][col0 + 16 g + 4 b + i]
     const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
     if (STAGE == 1) {
@@ -893,7 +908,7 @@ __global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ 
                 for (int g = 0; g < HALF; ++g) {
                     if (h0 + g < NG16) {
                         const bool ok = spv && tpos[g] >= 0 && slot[g] >= 0;
-                        double *dst = ok ? cb + (int64_t)slot[g] * 4 + off[g] : dump;
+                        double *dst = ok ? cb + (int64_t)slot[g] * 2 + off[g] : dump;
                         *dst = acc[tg][h0 + g];
                     }
                 }
@@ -910,6 +925,13 @@ __global__ __launch_bounds__(512) void m2l_gemm_k4(const M2lClass *__restrict__ 
                 for (int g = 0; g < NG16; ++g) Lc[16 * g] = acc[tg][g];
             }
         }
+    }
+#pragma unroll
+            for (int tg = 0; tg < 4; ++tg)
+#pragma unroll
+                for (int g = 0; g < NG16; ++g) acc[tg][g] = 0.0;
+        }
+        wait_dma_and_barrier();
     }
 }
 
@@ -1098,47 +1120,83 @@ void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
     });
 }
 
-template <int NG16, int STAGE>
+template <int NG16, int STAGE, int MINW>
 static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g16_0,
                             int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
-                            int64_t out_len, hipStream_t s) {
+                            int64_t out_len, const uint16_t *qlist, hipStream_t s) {
     const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048);
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_gemm_k4<NG16, STAGE>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_gemm_k4<NG16, STAGE, MINW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE>), dim3(n_tiles, K, n_colblocks), dim3(512), lds, s, classes, tiles,
-                       n_pad, g16_0, C, in, in_len, out, out_len);
+    hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, n_colblocks), dim3(512), lds, s, classes,
+                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist);
 }
 
-// Stage 1: every class's stacked operator is padded to a whole number of kM2lS1Block columns, so
-// one instantiation covers all orders; blockIdx.z walks the column blocks.
+// Column-chunk plan: 16-column groups per workgroup.  22 (88 accumulators per lane), 11 (44, no
+// spills in the persistent stage-1 walk) or 8 (two workgroups per CU).  Measured best on MI355X:
+// 11 for stage 1, 22 for stage 2; BBFMM_M2L_NG16_S1 / _S2 override for experiments.
+template <int STAGE> static int m2l_chunk_pref() {
+    static const int v = [] {
+        const char *e = std::getenv(STAGE == 1 ? "BBFMM_M2L_NG16_S1" : "BBFMM_M2L_NG16_S2");
+        const int dflt = STAGE == 1 ? 11 : 22;
+        const int x = e ? std::atoi(e) : dflt;
+        return (x == 8 || x == 11 || x == 22) ? x : dflt;
+    }();
+    return v;
+}
+
+template <int STAGE>
+static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
+                                int n_pad, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
+                                double *out, int64_t out_len, const uint16_t *qlist, hipStream_t s) {
+    int done = 0;
+    const int pref = m2l_chunk_pref<STAGE>();
+    while (done < total_groups) {
+        const int left = total_groups - done;
+        int take;
+#define M2L_GO(NG, MW)                                                                                              \
+    {                                                                                                               \
+        take = NG;                                                                                                  \
+        m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done, n_colblocks, K, C, in, in_len, out,    \
+                                       out_len, qlist, s);                                                          \
+    }
+        if (pref == 22 && left >= 22) M2L_GO(22, 1)
+        else if (pref == 22 && left >= 16) M2L_GO(16, 1)
+        else if (pref == 11 && left >= 11) M2L_GO(11, 1)
+        else if (left >= 8) M2L_GO(8, 4)
+        else if (left >= 6) M2L_GO(6, 4)
+        else if (left >= 4) M2L_GO(4, 4)
+        else M2L_GO(2, 4)
+#undef M2L_GO
+        done += take;
+    }
+}
+
+// Stage 1: every class's stacked operator is padded to a whole number of kM2lS1Block columns;
+// blockIdx.z walks the column blocks, the chunk plan splits a block.
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int max_r_pad,
                        int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len, hipStream_t s) {
     if (n_tiles == 0) return;
-    const int n_colblocks = (max_r_pad + kM2lS1Block - 1) / kM2lS1Block;
-    m2l_gemm_launch<kM2lS1Block / 16, 1>(classes, tiles, n_tiles, n_pad, 0, n_colblocks, K, C, M, 0, cbuf, cbuf_len, s);
+    (void)max_r_pad;
+    // every workgroup walks its share of the column blocks; splitting the walk over gridDim.z
+    // workgroups shortens the last, partially filled round of the launch
+    static const int zsplit = [] {
+        const char *e = std::getenv("BBFMM_M2L_ZSPLIT");
+        const int v = e ? std::atoi(e) : 2;
+        return v >= 1 && v <= 16 ? v : 2;
+    }();
+    const int n_colblocks = zsplit;
+    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, s);
 }
 
-// Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) are processed in
-// chunks whose accumulators live in registers (exact instantiations 22, 16, 8, 4, 2).
+// Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
-                       const double *cbuf, int64_t cbuf_len, double *L, hipStream_t s) {
+                       const double *cbuf, int64_t cbuf_len, const uint16_t *qlist, double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    const int total = n_pad / 16;
-    int done = 0;
-    while (done < total) {
-        const int left = total - done;
-        int take;
-        if (left >= 22) { take = 22; m2l_gemm_launch<22, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
-        else if (left >= 16) { take = 16; m2l_gemm_launch<16, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
-        else if (left >= 8) { take = 8; m2l_gemm_launch<8, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
-        else if (left >= 4) { take = 4; m2l_gemm_launch<4, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
-        else { take = 2; m2l_gemm_launch<2, 2>(classes, tiles, n_tiles, n_pad, done, 1, K, C, cbuf, cbuf_len, L, 0, s); }
-        done += take;
-    }
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, s);
 }
 
 // ------------------------------------------------------------------ MFMA self test

@@ -51,7 +51,7 @@ struct M2lClass {
     // cells of this class at this level
     const int32_t *cells;    // cell indices
     int32_t n_cells;
-    const int32_t *cslot;    // n_cells x n_t: slot base (units of 4 doubles) of target V+t, -1 if absent
+    const int32_t *cslot;    // n_cells x n_t: slot base (units of 2 doubles) of target V+t, -1 if absent
     const int64_t *cbase;    // n_cells: slot base of the cell itself as a target (units of doubles)
 };
 
@@ -59,6 +59,8 @@ struct M2lTileDesc { // one workgroup of stage 1 or stage 2
     int32_t level_class; // index into the M2lClass table
     int32_t first;       // first cell (position inside the class list)
     int32_t count;       // <= kM2lTile
+    int32_t q_first;     // stage 2: first entry / number of entries of the tile's active-step list
+    int32_t q_count;
     int32_t pad;
 };
 
@@ -85,8 +87,8 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_
                        int max_r_pad, int K, int64_t C, const double *M, double *cbuf,
                        int64_t cbuf_len, hipStream_t s);
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
-                       int K, int64_t C, const double *cbuf, int64_t cbuf_len, double *L,
-                       hipStream_t s);
+                       int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
+                       double *L, hipStream_t s);
 
 // Direct (kernel-evaluating) interactions.  Targets are sorted by leaf; job i handles
 // the targets [tgt_begin[i], tgt_end[i]) of leaf job_cell[i] against the source runs

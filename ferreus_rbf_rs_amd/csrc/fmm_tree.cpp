@@ -85,6 +85,9 @@ FmmTree::~FmmTree() {
         (void)hipEventDestroy(pp.e1);
     }
     for (hipEvent_t e : event_pool_) (void)hipEventDestroy(e);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (stream2_) (void)hipStreamDestroy(stream2_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -232,6 +235,9 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
             return fail(BBFMM_DEVICE_ERROR, "no HIP device available (the BBFMM passes have no CPU fallback)");
         HIPCHK(hipStreamCreate(&stream_));
+        HIPCHK(hipStreamCreate(&stream2_));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
     }
     CHK(build_m2l_tables());
     timer.lap("stacked M2L tables");
@@ -302,6 +308,7 @@ int FmmTree::build_m2l_tables() {
     m2l_host_.clear();
     m2l_classes_h_.clear();
     m2l_tiles_h_.clear();
+    m2l_qlist_h_.clear();
     cbuf_len_ = 0;
     m2l_flops_k1_ = 0;
     if (t.depth < 2) return BBFMM_OK;
@@ -355,7 +362,7 @@ int FmmTree::build_m2l_tables() {
             int off = 0;
             for (int tv : tgt_list[o]) {
                 off_tgt[o].push_back(off);
-                off += round_up(rank_of(tv), 4);
+                off += round_up(rank_of(tv), 2); // 16-byte aligned segments
             }
             k_pad[o] = round_up(std::max(off, 16), 16);
         }
@@ -413,19 +420,36 @@ int FmmTree::build_m2l_tables() {
                     ++bad_pairs;
                     continue;
                 }
-                hv.cslot[static_cast<size_t>(pos_in_class[V]) * hv.n_t + ps] = static_cast<int32_t>(base / 4);
+                hv.cslot[static_cast<size_t>(pos_in_class[V]) * hv.n_t + ps] = static_cast<int32_t>(base / 2);
                 const int r = rank_of(tv);
                 m2l_flops_k1_ += compressed ? 4.0 * n * r : 2.0 * n * static_cast<double>(n);
             }
         }
         for (int o = 0; o < ncls; ++o) {
             const HostM2lClass &hc = m2l_host_[first_class + o];
+            const int nq = hc.k_pad / 16;
             for (int32_t first = 0; first < static_cast<int32_t>(hc.cells.size()); first += kM2lTile) {
                 M2lTileDesc td;
                 td.level_class = static_cast<int32_t>(first_class + o);
                 td.first = first;
                 td.count = std::min<int32_t>(kM2lTile, static_cast<int32_t>(hc.cells.size()) - first);
                 td.pad = 0;
+                // contraction steps (16 slot entries each) that hold at least one V-list entry of the tile
+                std::vector<uint8_t> act(static_cast<size_t>(nq), 0);
+                for (int32_t i = 0; i < td.count; ++i) {
+                    const int64_t B = hc.cells[first + i];
+                    for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
+                        const int tv = t.v_tidx[q];
+                        const int pos = tpos_tgt[o][tv];
+                        if (pos < 0) continue;
+                        const int a = off_tgt[o][pos], b = a + rank_of(tv);
+                        for (int s = a / 16; s <= (b - 1) / 16; ++s) act[s] = 1;
+                    }
+                }
+                td.q_first = static_cast<int32_t>(m2l_qlist_h_.size());
+                for (int s = 0; s < nq; ++s)
+                    if (act[s]) m2l_qlist_h_.push_back(static_cast<uint16_t>(s));
+                td.q_count = static_cast<int32_t>(m2l_qlist_h_.size()) - td.q_first;
                 m2l_tiles_h_.push_back(td);
             }
         }
@@ -434,7 +458,7 @@ int FmmTree::build_m2l_tables() {
         return fail(BBFMM_UNSUPPORTED,
                     "V-list pairs outside the admissible transfer-vector set (source points outside the root box?)");
     cbuf_len_ = cbuf_cursor + 128; // + dump area for the branch-free stage-1 scatter (never read)
-    if (cbuf_len_ / 4 >= (int64_t(1) << 31)) return fail(BBFMM_UNSUPPORTED, "M2L intermediate buffer too large");
+    if (cbuf_len_ / 2 >= (int64_t(1) << 31)) return fail(BBFMM_UNSUPPORTED, "M2L intermediate buffer too large");
     return BBFMM_OK;
 }
 
@@ -554,6 +578,7 @@ int FmmTree::upload() {
     }
     CHK(dupload(&d_m2l_classes_, m2l_classes_h_));
     CHK(dupload(&d_m2l_tiles_, m2l_tiles_h_));
+    CHK(dupload(&d_m2l_qlist_, m2l_qlist_h_));
     std::vector<uint8_t> act(static_cast<size_t>(C), 1);
     CHK(dupload(&d_active_, act));
     return BBFMM_OK;
@@ -747,7 +772,8 @@ int FmmTree::downward(int k) {
                       stream_);
     phase_end(kPhM2L1);
     phase_begin();
-    launch_m2l_stage2(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_L_.p, stream_);
+    launch_m2l_stage2(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, d_L_.p,
+                      stream_);
     phase_end(kPhM2L2);
     phase_begin();
     if (t.adaptive)
@@ -766,23 +792,38 @@ int FmmTree::downward(int k) {
 
 // leaf_pass (bbfmm.rs:1089-1159) into ts.out / ts.grad (sorted order)
 int FmmTree::leaf_pass(const TargetSet &ts, int k, bool with_grads) {
+    CHK(leaf_pass_near(ts, k, with_grads, stream_));
+    return leaf_pass_far(ts, k, with_grads);
+}
+
+// P2P + M2P: need the weights and the multipoles only (can run beside the downward pass)
+int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
-    HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), stream_));
+    HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), st));
     double *grad = nullptr;
     if (with_grads) {
         grad = ts.grad.p;
-        HIPCHK(hipMemsetAsync(grad, 0, static_cast<size_t>(k) * d_ * ts.m * sizeof(double), stream_));
+        HIPCHK(hipMemsetAsync(grad, 0, static_cast<size_t>(k) * d_ * ts.m * sizeof(double), st));
     }
     DirectJobs jobs{ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_u_run_ptr_.p, d_u_runs_.p};
-    phase_begin();
-    launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, stream_);
-    phase_end(kPhP2P);
-    phase_begin();
+    const bool timed = st == stream_;
+    if (timed) phase_begin();
+    launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
+    if (timed) phase_end(kPhP2P);
+    if (timed) phase_begin();
     if (t.adaptive)
         launch_m2p(kernel_, cheb_, ts.n_w_jobs, ts.w_tgt_begin.p, ts.w_tgt_end.p, ts.w_begin.p, ts.w_end.p,
-                   d_w_idx_.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr, ts.m, k, C, d_M_.p, ts.out.p, grad, stream_);
-    phase_end(kPhM2P);
+                   d_w_idx_.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr, ts.m, k, C, d_M_.p, ts.out.p, grad, st);
+    if (timed) phase_end(kPhM2P);
+    HIPCHK(hipGetLastError());
+    return BBFMM_OK;
+}
+
+// L2P: needs the finished local expansions
+int FmmTree::leaf_pass_far(const TargetSet &ts, int k, bool with_grads) {
+    const int64_t C = tree_.n_cells();
+    double *grad = with_grads ? ts.grad.p : nullptr;
     phase_begin();
     launch_l2p(cheb_, ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr,
                ts.m, k, C, d_L_.p, ts.out.p, grad, stream_);
@@ -872,13 +913,28 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
     launch_gather_weights(d_w, ldw, k, d_order_.p, N, d_w_sorted_.p, stream_);
     phase_end(kPhGather);
     CHK(upward(k));
-    CHK(downward(k));
     if (have_part_ && part_targets_.out.n < static_cast<size_t>(k) * part_targets_.m) {
         dfree(&part_targets_.out);
         CHK(dalloc(&part_targets_.out, static_cast<size_t>(k) * part_targets_.m));
     }
     const TargetSet &ts = have_part_ ? part_targets_ : src_targets_;
-    CHK(leaf_pass(ts, k, false));
+    static const bool overlap = [] {
+        const char *e = std::getenv("BBFMM_OVERLAP");
+        return e ? std::atoi(e) != 0 : false;
+    }();
+    if (overlap) {
+        // near field (FP64 VALU) on a second stream beside the far field (FP64 MFMA)
+        HIPCHK(hipEventRecord(ev_fork_, stream_));
+        HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+        CHK(leaf_pass_near(ts, k, false, stream2_));
+        HIPCHK(hipEventRecord(ev_join_, stream2_));
+        CHK(downward(k));
+        HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
+        CHK(leaf_pass_far(ts, k, false));
+    } else {
+        CHK(downward(k));
+        CHK(leaf_pass(ts, k, false));
+    }
     phase_begin();
     launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);
     phase_end(kPhScatter);
@@ -1093,7 +1149,7 @@ int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
                 if (slot < 0) continue;
                 double s = 0.0;
                 for (int m = 0; m < n; ++m) s += hc.vt_all[static_cast<size_t>(m) * hc.r_pad16 + row] * Mv[m];
-                cbuf[static_cast<size_t>(slot) * 4 + hc.row_off[row]] = s;
+                cbuf[static_cast<size_t>(slot) * 2 + hc.row_off[row]] = s;
             }
         }
     }

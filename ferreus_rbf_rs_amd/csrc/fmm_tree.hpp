@@ -109,6 +109,8 @@ class FmmTree {
     int upward(int k);                                  // P2M + M2M from w_sorted_
     int downward(int k);                                // M2L + P2L + L2L into L_
     int leaf_pass(const TargetSet &ts, int k, bool with_grads);
+    int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st);
+    int leaf_pass_far(const TargetSet &ts, int k, bool with_grads);
     int build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index);
     int build_source_target_set();
     void free_target_set(TargetSet *ts);
@@ -140,6 +142,7 @@ class FmmTree {
     std::vector<HostM2lClass> m2l_host_;
     std::vector<M2lClass> m2l_classes_h_;
     std::vector<M2lTileDesc> m2l_tiles_h_;
+    std::vector<uint16_t> m2l_qlist_h_;
     int64_t cbuf_len_ = 0;
     double m2l_flops_k1_ = 0;
     // partition
@@ -149,7 +152,8 @@ class FmmTree {
     std::vector<M2lTileDesc> m2l_tiles_part_h_;
 
     // ---- device state
-    hipStream_t stream_ = nullptr;
+    hipStream_t stream_ = nullptr, stream2_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     struct PendingPhase {
         int phase;
         hipEvent_t e0, e1;
@@ -182,6 +186,7 @@ class FmmTree {
     DevBuf<int64_t> d_x_job_run_ptr_;
     DevBuf<M2lClass> d_m2l_classes_;
     DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles_part_;
+    DevBuf<uint16_t> d_m2l_qlist_;
     int n_m2l_tiles_part_ = 0;
     DevBuf<uint8_t> d_active_;
     // per-rhs-capacity buffers
