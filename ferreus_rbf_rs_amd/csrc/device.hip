@@ -748,8 +748,21 @@ __device__ inline void dma16(const double *g, unsigned lds_wave_byte_offset) {
                  "s"(uniform_u32(lds_wave_byte_offset))
                  : "memory");
 }
+// 64 lanes x 4 B (a gather of table entries) land at LDS byte offset m0 + lane * 4.
+__device__ inline void dma4(const int32_t *g, unsigned lds_wave_byte_offset) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(g),
+                 "s"(uniform_u32(lds_wave_byte_offset))
+                 : "memory");
+}
 __device__ inline void wait_dma_and_barrier() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+// Same, but lets the N most recent vector-memory operations of the wave stay in flight.  gfx9
+// retires loads and stores in issue order on one counter, so when N stores were issued after the
+// DMA the DMA has landed once at most N operations are outstanding (the field holds 0..63).
+template <int N> __device__ inline void wait_dma_keep_stores_and_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N < 63 ? N : 63) : "memory");
     __syncthreads();
 }
 // v + (v rotated right by N lanes inside each row of 16 lanes), via DPP row_ror
@@ -783,8 +796,10 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                                                   const M2lTileDesc *__restrict__ tiles, int n_pad, int g16_0,
                                                   int64_t C, const double *__restrict__ in, int64_t in_len,
                                                   double *__restrict__ out, int64_t out_len,
-                                                  const uint16_t *__restrict__ qlist) {
-    extern __shared__ double lds[]; // 2 x { operator [e][ng][k*16 + col], IN tile [wave][tg][eh][k][j] x 2 }
+                                                  const uint16_t *__restrict__ qlist, int slot_t) {
+    // 2 x { operator [e][ng][k*16 + col], IN tile [wave][tg][eh][k][j] x 2 }; stage 1 adds the slot
+    // lookups of the current column block, [wave][cell 0..15][slot_t] int32
+    extern __shared__ double lds[];
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
     const int kr = blockIdx.y;
@@ -849,13 +864,54 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
 
     const int bk = lane >> 4, bj = lane & 3; // B layout (k, j); the block index is broadcast
     const int n_steps = (zb1 - zb0) * nq;
-    if (n_steps > 0) stage(0, 0);
+    // epilogue coordinates: D[b][i][j] at lane 16 i + 4 b + j = OUT[cell 4 tg + j][col0 + 16 g + 4 b + i]
+    const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
+    // Stage-1 scatter tables.  gfx9 retires vector-memory operations in issue order on one counter,
+    // and the compiler cannot see the DMA in its wait counting: a wait for any ordinary load in this
+    // loop would be vmcnt(0) and drain the DMA in flight and the scatter stores with it.  The loop
+    // therefore issues no ordinary loads at all.  All lookups come in by DMA and are read from LDS:
+    //   aux[parity][0 .. 16 NG16)  packed row entries of a column block, aux[parity][16 NG16] its first
+    //                              transfer-vector position (requested during the previous block)
+    //   slots[wave][cell][slot_t]  slot bases of the wave's 16 cells for the block's transfer vectors
+    //                              (requested two steps before the block ends)
+    // and the stores of a block leave together and drain under the next block.
+    constexpr int AUX = 192;
+    const int32_t *aux = reinterpret_cast<const int32_t *>(lds + 2 * BUF);
+    const int32_t *slds = aux + 2 * AUX + wave * 16 * slot_t;
+    const unsigned aux0 = lds0 + (unsigned)(2 * BUF) * 8u;
+    auto stage_cols = [&](int zb_, int par) {
+        if (STAGE == 1 && 64 * wave <= 16 * NG16) {
+            const int e = 64 * wave + lane;
+            const int32_t *src = e < 16 * NG16 ? cls.row_dst + zb_ * kM2lS1Block + 16 * g16_0 + e : cls.blk_t0 + zb_;
+            dma4(src, aux0 + (unsigned)(par * AUX + 64 * wave) * 4u);
+        }
+    };
+    const int slot_sh = 31 - __builtin_clz(slot_t | 1); // slot_t is a power of two >= 16 in stage 1
+    auto stage_slots = [&](int par) {
+        const int t0 = __builtin_amdgcn_readfirstlane(aux[par * AUX + 16 * NG16]);
+        const unsigned dst0 = aux0 + (unsigned)(2 * AUX + wave * 16 * slot_t) * 4u;
+        for (int i = 0; i < slot_t / 4; ++i) {
+            const int e = i * 64 + lane, cl = e >> slot_sh, tl = e & (slot_t - 1);
+            const int sp = wave * 16 + cl;
+            const int32_t *src = cls.cslot + (int64_t)(tile.first + (sp < tile.count ? sp : 0)) * cls.n_t +
+                                 min(t0 + tl, cls.n_t - 1);
+            dma4(src, dst0 + (unsigned)i * 256u);
+        }
+    };
+    if (n_steps > 0) {
+        stage(0, 0);
+        stage_cols(zb0, 0);
+    }
     wait_dma_and_barrier();
     int qcnt = 0, zb = zb0;
     for (int sidx = 0; sidx < n_steps; ++sidx) {
         const double *op = lds + (sidx & 1) * BUF + lane;
         const double *ct = lds + (sidx & 1) * BUF + OP_DOUBLES + wave * 256 + (bk * 4 + bj) * 2;
         if (sidx + 1 < n_steps) stage(sidx + 1, (sidx + 1) & 1); // streams in under the MFMAs below
+        if (STAGE == 1) {
+            if (qcnt == 0 && zb + 1 < zb1) stage_cols(zb + 1, (zb + 1 - zb0) & 1);
+            if (qcnt == nq - 2) stage_slots((zb - zb0) & 1);
+        }
         double bq[4][4];
 #pragma unroll
         for (int tg = 0; tg < 4; ++tg)
@@ -878,58 +934,50 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
             qcnt = 0;
             const int col0 = zb * kM2lS1Block + 16 * g16_0;
             ++zb;
-    // epilogue: D[b][i][j] at lane 16 i + 4 b + j = OUT[cell 4 tg + j][col0 + 16 g + 4 b + i]
-    const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
-    if (STAGE == 1) {
-        // Scatter into the target slots.  Branch-free and batched so that the table lookups of a
-        // batch are all in flight together: entries without a destination (padding rows, absent
-        // targets, cells beyond the tile) are written to a dump area behind the slot buffer.
-        double *cb = out + (int64_t)kr * out_len;
-        double *dump = cb + (out_len - 64) + lane;
-        constexpr int HALF = (NG16 + 1) / 2;
+            if (STAGE == 1) {
+                // Scatter into the target slots, branch-free: entries without a destination (padding
+                // rows, absent targets, cells beyond the tile) go to a dump area behind the slot buffer.
+                // Measured: the epilogue is store-issue bound (about 75 cycles per dwordx2 store
+                // instruction and CU, 2.7 of the 18 ms of stage 1 at 10M points), whatever the address
+                // pattern and however the wait after it is relaxed.
+                double *cb = out + (int64_t)kr * out_len;
+                double *dump = cb + (out_len - 64) + lane;
+                int pk[NG16];
 #pragma unroll
-        for (int h0 = 0; h0 < NG16; h0 += HALF) {
-            int tpos[HALF], off[HALF];
+                for (int g = 0; g < NG16; ++g) pk[g] = aux[((zb - 1 - zb0) & 1) * AUX + 16 * g + 4 * db + di];
 #pragma unroll
-            for (int g = 0; g < HALF; ++g) {
-                const int col = col0 + 16 * min(h0 + g, NG16 - 1) + 4 * db + di;
-                tpos[g] = cls.row_tpos[col];
-                off[g] = cls.row_off[col];
-            }
+                for (int tg = 0; tg < 4; ++tg) {
+                    const bool spv = wave * 16 + 4 * tg + dj < tile.count;
+                    const int32_t *srow = slds + (4 * tg + dj) * slot_t;
 #pragma unroll
-            for (int tg = 0; tg < 4; ++tg) {
-                const int sp = wave * 16 + 4 * tg + dj;
-                const bool spv = sp < tile.count;
-                const int32_t *csrow = cls.cslot + (int64_t)(tile.first + (spv ? sp : 0)) * cls.n_t;
-                int slot[HALF];
+                    for (int g = 0; g < NG16; ++g) {
+                        const int sl = srow[max(pk[g] >> 24, 0)];
+                        const int okm = (spv ? -1 : 0) & ~(pk[g] | sl); // sign bit set: valid cell, row, slot
+                        double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[g] & 0xffffff) : dump;
+                        *dst = acc[tg][g];
+                    }
+                }
+            } else {
 #pragma unroll
-                for (int g = 0; g < HALF; ++g) slot[g] = csrow[max(tpos[g], 0)];
+                for (int tg = 0; tg < 4; ++tg) {
+                    const int tp = wave * 16 + 4 * tg + dj;
+                    if (tp < tile.count) {
+                        const int cell = cls.cells[tile.first + tp];
+                        double *Lc = out + ((int64_t)kr * C + cell) * n_pad + col0 + 4 * db + di;
 #pragma unroll
-                for (int g = 0; g < HALF; ++g) {
-                    if (h0 + g < NG16) {
-                        const bool ok = spv && tpos[g] >= 0 && slot[g] >= 0;
-                        double *dst = ok ? cb + (int64_t)slot[g] * 2 + off[g] : dump;
-                        *dst = acc[tg][h0 + g];
+                        for (int g = 0; g < NG16; ++g) Lc[16 * g] = acc[tg][g];
                     }
                 }
             }
-        }
-    } else {
-#pragma unroll
-        for (int tg = 0; tg < 4; ++tg) {
-            const int tp = wave * 16 + 4 * tg + dj;
-            if (tp < tile.count) {
-                const int cell = cls.cells[tile.first + tp];
-                double *Lc = out + ((int64_t)kr * C + cell) * n_pad + col0 + 4 * db + di;
-#pragma unroll
-                for (int g = 0; g < NG16; ++g) Lc[16 * g] = acc[tg][g];
-            }
-        }
-    }
 #pragma unroll
             for (int tg = 0; tg < 4; ++tg)
 #pragma unroll
                 for (int g = 0; g < NG16; ++g) acc[tg][g] = 0.0;
+            // the 4 * NG16 scatter stores issued after this step's DMA drain under the next block
+            if (STAGE == 1) {
+                wait_dma_keep_stores_and_barrier<4 * NG16>();
+                continue;
+            }
         }
         wait_dma_and_barrier();
     }
@@ -1123,8 +1171,8 @@ void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
 template <int NG16, int STAGE, int MINW>
 static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g16_0,
                             int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
-                            int64_t out_len, const uint16_t *qlist, hipStream_t s) {
-    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048);
+                            int64_t out_len, const uint16_t *qlist, int slot_t, hipStream_t s) {
+    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 8 * 16 * slot_t) * 4 : 0); // + aux and slot tables
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_gemm_k4<NG16, STAGE, MINW>),
@@ -1132,18 +1180,19 @@ static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, i
         attr_set = true;
     }
     hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, n_colblocks), dim3(512), lds, s, classes,
-                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist);
+                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t);
 }
 
-// Column-chunk plan: 16-column groups per workgroup.  22 (88 accumulators per lane), 11 (44, no
-// spills in the persistent stage-1 walk) or 8 (two workgroups per CU).  Measured best on MI355X:
-// 11 for stage 1, 22 for stage 2; BBFMM_M2L_NG16_S1 / _S2 override for experiments.
+// Column-chunk plan: 16-column groups per workgroup.  Stage 1 walks column blocks of kM2lS1Block =
+// 11 groups (44 accumulators per lane; 22 spills in the persistent walk).  Stage 2 covers the n_pad
+// output nodes with 22-group chunks (88 accumulators, one workgroup per CU), measured faster there
+// than 11 or 8; BBFMM_M2L_NG16_S2 overrides for experiments.
 template <int STAGE> static int m2l_chunk_pref() {
+    if (STAGE == 1) return kM2lS1Block / 16;
     static const int v = [] {
-        const char *e = std::getenv(STAGE == 1 ? "BBFMM_M2L_NG16_S1" : "BBFMM_M2L_NG16_S2");
-        const int dflt = STAGE == 1 ? 11 : 22;
-        const int x = e ? std::atoi(e) : dflt;
-        return (x == 8 || x == 11 || x == 22) ? x : dflt;
+        const char *e = std::getenv("BBFMM_M2L_NG16_S2");
+        const int x = e ? std::atoi(e) : 22;
+        return (x == 8 || x == 11 || x == 22) ? x : 22;
     }();
     return v;
 }
@@ -1151,7 +1200,7 @@ template <int STAGE> static int m2l_chunk_pref() {
 template <int STAGE>
 static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
                                 int n_pad, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
-                                double *out, int64_t out_len, const uint16_t *qlist, hipStream_t s) {
+                                double *out, int64_t out_len, const uint16_t *qlist, int slot_t, hipStream_t s) {
     int done = 0;
     const int pref = m2l_chunk_pref<STAGE>();
     while (done < total_groups) {
@@ -1161,7 +1210,7 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
     {                                                                                                               \
         take = NG;                                                                                                  \
         m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done, n_colblocks, K, C, in, in_len, out,    \
-                                       out_len, qlist, s);                                                          \
+                                       out_len, qlist, slot_t, s);                                                  \
     }
         if (pref == 22 && left >= 22) M2L_GO(22, 1)
         else if (pref == 22 && left >= 16) M2L_GO(16, 1)
@@ -1177,10 +1226,11 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
 
 // Stage 1: every class's stacked operator is padded to a whole number of kM2lS1Block columns;
 // blockIdx.z walks the column blocks, the chunk plan splits a block.
-void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int max_r_pad,
+void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int max_slot_t,
                        int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len, hipStream_t s) {
     if (n_tiles == 0) return;
-    (void)max_r_pad;
+    int slot_t = 16; // LDS slot-table width: power of two covering the transfer vectors of any block
+    while (slot_t < max_slot_t) slot_t *= 2;
     // every workgroup walks its share of the column blocks; splitting the walk over gridDim.z
     // workgroups shortens the last, partially filled round of the launch
     static const int zsplit = [] {
@@ -1189,14 +1239,14 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_
         return v >= 1 && v <= 16 ? v : 2;
     }();
     const int n_colblocks = zsplit;
-    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, s);
+    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, slot_t, s);
 }
 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
                        const double *cbuf, int64_t cbuf_len, const uint16_t *qlist, double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, s);
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, s);
 }
 
 // ------------------------------------------------------------------ MFMA self test

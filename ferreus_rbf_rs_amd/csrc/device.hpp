@@ -20,7 +20,7 @@ namespace bbfmm {
 
 constexpr int kMaxOrder = 16;      // Chebyshev nodes per axis supported on device
 constexpr int kM2lTile = 128;      // cells per M2L workgroup: 8 waves x 16
-constexpr int kM2lS1Block = 352;   // stacked-operator rows per stage-1 workgroup (22 groups of 16)
+constexpr int kM2lS1Block = 176;   // stacked-operator rows per stage-1 column block (11 groups of 16)
 
 struct DevCheb { // lives in device memory; kernels take a pointer
     int p, d, n, n_pad;
@@ -40,8 +40,10 @@ struct ChebRef { // device pointer + the host copies the launchers size their gr
 struct M2lClass {
     // stage 1 (source side): c[(t,kk)] = sum_m VtAllT[m][row] * M_V[m]
     const double *vt_all;   // n_pad x r_pad16 (row m contiguous over tall rows)
-    const int32_t *row_tpos; // r_pad16: position of the row's transfer vector in the class list (or -1)
-    const int32_t *row_off;  // r_pad16: offset of the row inside the target's slot (= off_target_class[t] + kk)
+    const int32_t *row_dst;  // r_pad16: -1 (padding row) or ((tpos - blk_t0[block]) << 24) | off, with tpos the
+                             // position of the row's transfer vector in the class list and off the offset of
+                             // the row inside the target's slot (= off_target_class[t] + kk)
+    const int32_t *blk_t0;   // r_pad16 / kM2lS1Block: first tpos of each column block
     int32_t n_rows;          // exact number of tall rows
     int32_t r_pad16;         // n_rows rounded up to a multiple of kM2lS1Block
     int32_t n_t;             // number of transfer vectors of this class (189 in 3-D)
@@ -84,7 +86,7 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
                 hipStream_t s);
 
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
-                       int max_r_pad, int K, int64_t C, const double *M, double *cbuf,
+                       int max_slot_t, int K, int64_t C, const double *M, double *cbuf,
                        int64_t cbuf_len, hipStream_t s);
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
                        int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,

@@ -399,6 +399,26 @@ int FmmTree::build_m2l_tables() {
                     hc.row_off[row] = base_off + kk;
                 }
             }
+            // per column block: first transfer-vector position, and the packed row table
+            const int n_blk = hc.r_pad16 / kM2lS1Block;
+            hc.blk_t0.assign(n_blk, 0);
+            hc.row_dst.assign(hc.r_pad16, -1);
+            for (int b = 0; b < n_blk; ++b) {
+                int t0 = -1, t1 = -1;
+                for (int r = b * kM2lS1Block; r < (b + 1) * kM2lS1Block; ++r) {
+                    if (hc.row_tpos[r] < 0) continue;
+                    if (t0 < 0) t0 = hc.row_tpos[r];
+                    t1 = hc.row_tpos[r];
+                }
+                if (t0 < 0) continue;
+                hc.blk_t0[b] = t0;
+                m2l_slot_t_ = std::max(m2l_slot_t_, t1 - t0 + 1);
+                for (int r = b * kM2lS1Block; r < (b + 1) * kM2lS1Block; ++r) {
+                    if (hc.row_tpos[r] < 0) continue;
+                    if (hc.row_off[r] >= (1 << 24)) return fail(BBFMM_BAD_ARGUMENT, "M2L slot too long for the packed row table");
+                    hc.row_dst[r] = ((hc.row_tpos[r] - t0) << 24) | hc.row_off[r];
+                }
+            }
             if (host_only_) fill_m2l_operator_arrays(hc, &hc.vt_all, &hc.u_all);
             hc.cbase.resize(hc.cells.size());
             for (size_t i = 0; i < hc.cells.size(); ++i) {
@@ -562,15 +582,15 @@ int FmmTree::upload() {
         fill_m2l_operator_arrays(h, &vt_scratch, &u_scratch);
         CHK(dupload(&vt, vt_scratch));
         CHK(dupload(&ua, u_scratch));
-        CHK(dupload(&rt, h.row_tpos));
-        CHK(dupload(&ro, h.row_off));
+        CHK(dupload(&rt, h.row_dst));
+        CHK(dupload(&ro, h.blk_t0));
         CHK(dupload(&ce, h.cells));
         CHK(dupload(&cs, h.cslot));
         CHK(dupload(&cb, h.cbase));
         c.vt_all = vt.p;
         c.u_all = ua.p;
-        c.row_tpos = rt.p;
-        c.row_off = ro.p;
+        c.row_dst = rt.p;
+        c.blk_t0 = ro.p;
         c.cells = ce.p;
         c.cslot = cs.p;
         c.cbase = cb.p;
@@ -765,10 +785,7 @@ int FmmTree::downward(int k) {
     const M2lTileDesc *tiles = have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles_.p;
     const int n_tiles = have_part_ ? n_m2l_tiles_part_ : static_cast<int>(m2l_tiles_h_.size());
     phase_begin();
-    int max_r_pad = 0;
-    for (const HostM2lClass &hc : m2l_host_)
-        if (!hc.cells.empty()) max_r_pad = std::max(max_r_pad, hc.r_pad16);
-    launch_m2l_stage1(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, max_r_pad, k, C, d_M_.p, d_cbuf_.p, cbuf_len_,
+    launch_m2l_stage1(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_,
                       stream_);
     phase_end(kPhM2L1);
     phase_begin();
@@ -792,30 +809,32 @@ int FmmTree::downward(int k) {
 
 // leaf_pass (bbfmm.rs:1089-1159) into ts.out / ts.grad (sorted order)
 int FmmTree::leaf_pass(const TargetSet &ts, int k, bool with_grads) {
-    CHK(leaf_pass_near(ts, k, with_grads, stream_));
+    CHK(leaf_pass_near(ts, k, with_grads, stream_, 3));
     return leaf_pass_far(ts, k, with_grads);
 }
 
 // P2P + M2P: need the weights and the multipoles only (can run beside the downward pass)
-int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st) {
+// parts: 1 = zero the outputs + P2P (needs the sorted weights), 2 = M2P (needs the multipoles)
+int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
-    HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), st));
-    double *grad = nullptr;
-    if (with_grads) {
-        grad = ts.grad.p;
-        HIPCHK(hipMemsetAsync(grad, 0, static_cast<size_t>(k) * d_ * ts.m * sizeof(double), st));
-    }
-    DirectJobs jobs{ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_u_run_ptr_.p, d_u_runs_.p};
+    double *grad = with_grads ? ts.grad.p : nullptr;
     const bool timed = st == stream_;
-    if (timed) phase_begin();
-    launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
-    if (timed) phase_end(kPhP2P);
-    if (timed) phase_begin();
-    if (t.adaptive)
-        launch_m2p(kernel_, cheb_, ts.n_w_jobs, ts.w_tgt_begin.p, ts.w_tgt_end.p, ts.w_begin.p, ts.w_end.p,
-                   d_w_idx_.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr, ts.m, k, C, d_M_.p, ts.out.p, grad, st);
-    if (timed) phase_end(kPhM2P);
+    if (parts & 1) {
+        HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), st));
+        if (with_grads) HIPCHK(hipMemsetAsync(grad, 0, static_cast<size_t>(k) * d_ * ts.m * sizeof(double), st));
+        DirectJobs jobs{ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_u_run_ptr_.p, d_u_runs_.p};
+        if (timed) phase_begin();
+        launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
+        if (timed) phase_end(kPhP2P);
+    }
+    if (parts & 2) {
+        if (timed) phase_begin();
+        if (t.adaptive)
+            launch_m2p(kernel_, cheb_, ts.n_w_jobs, ts.w_tgt_begin.p, ts.w_tgt_end.p, ts.w_begin.p, ts.w_end.p,
+                       d_w_idx_.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr, ts.m, k, C, d_M_.p, ts.out.p, grad, st);
+        if (timed) phase_end(kPhM2P);
+    }
     HIPCHK(hipGetLastError());
     return BBFMM_OK;
 }
@@ -912,26 +931,40 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
     phase_begin();
     launch_gather_weights(d_w, ldw, k, d_order_.p, N, d_w_sorted_.p, stream_);
     phase_end(kPhGather);
-    CHK(upward(k));
     if (have_part_ && part_targets_.out.n < static_cast<size_t>(k) * part_targets_.m) {
         dfree(&part_targets_.out);
         CHK(dalloc(&part_targets_.out, static_cast<size_t>(k) * part_targets_.m));
     }
     const TargetSet &ts = have_part_ ? part_targets_ : src_targets_;
-    static const bool overlap = [] {
+    static const int overlap = [] {
         const char *e = std::getenv("BBFMM_OVERLAP");
-        return e ? std::atoi(e) != 0 : false;
+        return e ? std::atoi(e) : 0;
     }();
-    if (overlap) {
+    if (overlap == 2) {
+        // P2P starts beside the (latency-bound) upward pass on a second stream
+        HIPCHK(hipEventRecord(ev_fork_, stream_));
+        HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+        CHK(leaf_pass_near(ts, k, false, stream2_, 1));
+        CHK(upward(k));
+        HIPCHK(hipEventRecord(ev_fork_, stream_));
+        HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
+        CHK(leaf_pass_near(ts, k, false, stream2_, 2));
+        HIPCHK(hipEventRecord(ev_join_, stream2_));
+        CHK(downward(k));
+        HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
+        CHK(leaf_pass_far(ts, k, false));
+    } else if (overlap == 1) {
+        CHK(upward(k));
         // near field (FP64 VALU) on a second stream beside the far field (FP64 MFMA)
         HIPCHK(hipEventRecord(ev_fork_, stream_));
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-        CHK(leaf_pass_near(ts, k, false, stream2_));
+        CHK(leaf_pass_near(ts, k, false, stream2_, 3));
         HIPCHK(hipEventRecord(ev_join_, stream2_));
         CHK(downward(k));
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
         CHK(leaf_pass_far(ts, k, false));
     } else {
+        CHK(upward(k));
         CHK(downward(k));
         CHK(leaf_pass(ts, k, false));
     }

@@ -34,7 +34,7 @@ struct HostM2lClass {
     int n_rows = 0, r_pad16 = 16, n_t = 0, k_pad = 16;
     std::vector<double> vt_all, u_all; // kept only on BBFMM_FLAG_HOST_ONLY handles
     std::vector<int> src_tv, tgt_tv, tgt_off; // transfer vectors (source / target side), slot offsets
-    std::vector<int32_t> row_tpos, row_off, cells, cslot;
+    std::vector<int32_t> row_tpos, row_off, row_dst, blk_t0, cells, cslot;
     std::vector<int64_t> cbase;
 };
 
@@ -109,7 +109,7 @@ class FmmTree {
     int upward(int k);                                  // P2M + M2M from w_sorted_
     int downward(int k);                                // M2L + P2L + L2L into L_
     int leaf_pass(const TargetSet &ts, int k, bool with_grads);
-    int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st);
+    int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts);
     int leaf_pass_far(const TargetSet &ts, int k, bool with_grads);
     int build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index);
     int build_source_target_set();
@@ -145,6 +145,7 @@ class FmmTree {
     std::vector<uint16_t> m2l_qlist_h_;
     int64_t cbuf_len_ = 0;
     double m2l_flops_k1_ = 0;
+    int m2l_slot_t_ = 1; // most transfer vectors any stage-1 column block touches
     // partition
     int part_rank_ = 0, part_world_ = 1;
     std::vector<int64_t> part_rows_;
