@@ -452,9 +452,10 @@ __global__ __launch_bounds__(64 * L2P_WAVES) void l2p_kernel(const DevCheb *__re
 }
 
 // ------------------------------------------------------------------ direct interactions
-// Shared inner loop of P2P / M2P / P2L: every thread owns one target and one "slice" of
-// the staged source tile (stride S); sources are read from LDS as two 16-byte values
-// {x, y} {z, w}.  acc[kk] += K(t, s) * w_kk(s); gradient accumulators optional.
+// Shared inner loop of P2P / M2P / P2L: every thread owns two targets and one "slice" of the
+// staged source tile (stride S); sources are read from LDS as {x, y}, z, w and serve both targets
+// (half the LDS traffic per kernel evaluation of a one-target loop, which ran at ~70 % of the LDS
+// bandwidth).  acc[t][kk] += K(t, s) * w_kk(s); gradient accumulators optional.
 constexpr int DIRECT_TILE = 512;
 constexpr int DIRECT_KB = 4;
 
@@ -466,28 +467,54 @@ struct SrcTile {
 
 template <int KID, bool GRAD, int KB>
 __device__ inline void direct_tile(const KernelSpec &ks, const SrcTile &tile, int count, int first, int stride,
-                                   double tx, double ty, double tz, double (&acc)[KB], double (&gacc)[KB][3]) {
+                                   const double (&t)[2][3], double (&acc)[2][KB], double (&gacc)[2][KB][3]) {
     for (int j = first; j < count; j += stride) {
         const double2 xy = tile.xy[j];
-        const double dx = tx - xy.x, dy = ty - xy.y, dz = tz - tile.zs[j];
-        const double r2 = dx * dx + dy * dy + dz * dz; // distance_sq, utils.rs:230-237
-        if (GRAD) {
-            double f;
-            const double v = kernel_value_grad_r2<KID>(ks, r2, &f);
+        const double z = tile.zs[j];
+        double wk[KB];
 #pragma unroll
-            for (int kk = 0; kk < KB; ++kk) {
-                const double wk = tile.w[kk][j];
-                acc[kk] += v * wk;
-                gacc[kk][0] += (f * dx) * wk;
-                gacc[kk][1] += (f * dy) * wk;
-                gacc[kk][2] += (f * dz) * wk;
+        for (int kk = 0; kk < KB; ++kk) wk[kk] = tile.w[kk][j];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const double dx = t[h][0] - xy.x, dy = t[h][1] - xy.y, dz = t[h][2] - z;
+            const double r2 = dx * dx + dy * dy + dz * dz; // distance_sq, utils.rs:230-237
+            if (GRAD) {
+                double f;
+                const double v = kernel_value_grad_r2<KID>(ks, r2, &f);
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) {
+                    acc[h][kk] += v * wk[kk];
+                    gacc[h][kk][0] += (f * dx) * wk[kk];
+                    gacc[h][kk][1] += (f * dy) * wk[kk];
+                    gacc[h][kk][2] += (f * dz) * wk[kk];
+                }
+            } else {
+                const double v = kernel_value_r2<KID>(ks, r2);
+#pragma unroll
+                for (int kk = 0; kk < KB; ++kk) acc[h][kk] += v * wk[kk];
             }
-        } else {
-            const double v = kernel_value_r2<KID>(ks, r2);
-#pragma unroll
-            for (int kk = 0; kk < KB; ++kk) acc[kk] += v * tile.w[kk][j];
         }
     }
+}
+
+// Split nt targets into m passes of n_c targets; a pass runs ceil(n_c / 2) target pairs in
+// S = 256 / pairs source slices, so the source tiles are walked m / S times in total.
+struct TargetPlan {
+    int n_c, pairs, S;
+};
+__device__ inline TargetPlan plan_targets(int nt) {
+    const int m0 = (nt + 511) / 512;
+    TargetPlan best{nt, 256, 1};
+    float best_cost = 1e30f;
+    for (int m = m0; m < m0 + 4; ++m) {
+        const int nc = (nt + m - 1) / m, pairs = (nc + 1) / 2, S = 256 / pairs;
+        const float cost = (float)m / (float)S + 0.02f * (float)m; // + restaging the tiles per pass
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = TargetPlan{nc, pairs, S};
+        }
+    }
+    return best;
 }
 
 // Cross-slice reduction through LDS; returns the total in the slice-0 thread.
@@ -513,20 +540,23 @@ __global__ __launch_bounds__(256) void p2p_kernel(KernelSpec ks, int d, DirectJo
     const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
     const int jcell = jobs.job_cell[job];
     const int64_t r0 = jobs.run_ptr[jcell], r1 = jobs.run_ptr[jcell + 1];
-    for (int tc = t0; tc < t1; tc += 256) {
-        const int nt = min(256, t1 - tc);
-        const int S = 256 / nt;
-        const int ti = tid % nt, sl = tid / nt;
-        const bool part = sl < S;
-        double tx = 0, ty = 0, tz = 0;
+    const TargetPlan tp = plan_targets(t1 - t0);
+    for (int tc = t0; tc < t1; tc += tp.n_c) {
+        const int nt = min(tp.n_c, t1 - tc);
+        const int ti = tid % tp.pairs, sl = tid / tp.pairs;
+        const bool part = sl < tp.S && ti < nt;
+        const bool two = ti + tp.pairs < nt;
+        double t[2][3] = {{0, 0, 0}, {0, 0, 0}};
         if (part) {
-            tx = tgt.x[tc + ti];
-            ty = tgt.y[tc + ti];
-            tz = tgt.z[tc + ti];
+            const int ia = tc + ti, ib = two ? ia + tp.pairs : ia;
+            t[0][0] = tgt.x[ia], t[0][1] = tgt.y[ia], t[0][2] = tgt.z[ia];
+            t[1][0] = tgt.x[ib], t[1][1] = tgt.y[ib], t[1][2] = tgt.z[ib];
         }
-        double acc[KB], gacc[KB][3];
+        double acc[2][KB], gacc[2][KB][3];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) acc[kk] = gacc[kk][0] = gacc[kk][1] = gacc[kk][2] = 0.0;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) acc[h][kk] = gacc[h][kk][0] = gacc[h][kk][1] = gacc[h][kk][2] = 0.0;
         for (int64_t r = r0; r < r1; ++r) {
             const int sb = jobs.runs[2 * r], se = jobs.runs[2 * r + 1];
             for (int base = sb; base < se; base += DIRECT_TILE) {
@@ -540,18 +570,23 @@ __global__ __launch_bounds__(256) void p2p_kernel(KernelSpec ks, int d, DirectJo
                         tile.w[kk][j] = kk < kb ? ws[(int64_t)(k0 + kk) * N + base + j] : 0.0;
                 }
                 __syncthreads();
-                if (part) direct_tile<KID, GRAD, KB>(ks, tile, cnt, sl, S, tx, ty, tz, acc, gacc);
+                if (part) direct_tile<KID, GRAD, KB>(ks, tile, cnt, sl, tp.S, t, acc, gacc);
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            if (kk >= kb) break;
-            const double v = slice_reduce(acc[kk], red, ti, sl, S, nt, part);
-            if (part && sl == 0) out[(int64_t)(k0 + kk) * n_tgt + tc + ti] += v;
-            if (GRAD) {
-                for (int a = 0; a < d; ++a) {
-                    const double g = slice_reduce(gacc[kk][a], red, ti, sl, S, nt, part);
-                    if (part && sl == 0) grad[((int64_t)(k0 + kk) * d + a) * n_tgt + tc + ti] += g;
+        for (int h = 0; h < 2; ++h) {
+            const bool wr = part && sl == 0 && (h == 0 || two);
+            const int64_t it = tc + ti + h * tp.pairs;
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                if (kk >= kb) break;
+                const double v = slice_reduce(acc[h][kk], red, ti, sl, tp.S, tp.pairs, part);
+                if (wr) out[(int64_t)(k0 + kk) * n_tgt + it] += v;
+                if (GRAD) {
+                    for (int a = 0; a < d; ++a) {
+                        const double g = slice_reduce(gacc[h][kk][a], red, ti, sl, tp.S, tp.pairs, part);
+                        if (wr) grad[((int64_t)(k0 + kk) * d + a) * n_tgt + it] += g;
+                    }
                 }
             }
         }
@@ -598,20 +633,23 @@ __global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *
     const int job = blockIdx.x;
     const int t0 = tgt_begin[job], t1 = tgt_end[job];
     const int64_t r0 = w_begin[job], r1 = w_end[job]; // a chunk of the leaf's W list
-    for (int tc = t0; tc < t1; tc += 256) {
-        const int nt = min(256, t1 - tc);
-        const int S = 256 / nt;
-        const int ti = tid % nt, sl = tid / nt;
-        const bool part = sl < S;
-        double tx = 0, ty = 0, tz = 0;
+    const TargetPlan tp = plan_targets(t1 - t0);
+    for (int tc = t0; tc < t1; tc += tp.n_c) {
+        const int nt = min(tp.n_c, t1 - tc);
+        const int ti = tid % tp.pairs, sl = tid / tp.pairs;
+        const bool part = sl < tp.S && ti < nt;
+        const bool two = ti + tp.pairs < nt;
+        double t[2][3] = {{0, 0, 0}, {0, 0, 0}};
         if (part) {
-            tx = tgt.x[tc + ti];
-            ty = tgt.y[tc + ti];
-            tz = tgt.z[tc + ti];
+            const int ia = tc + ti, ib = two ? ia + tp.pairs : ia;
+            t[0][0] = tgt.x[ia], t[0][1] = tgt.y[ia], t[0][2] = tgt.z[ia];
+            t[1][0] = tgt.x[ib], t[1][1] = tgt.y[ib], t[1][2] = tgt.z[ib];
         }
-        double acc[KB], gacc[KB][3];
+        double acc[2][KB], gacc[2][KB][3];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) acc[kk] = gacc[kk][0] = gacc[kk][1] = gacc[kk][2] = 0.0;
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) acc[h][kk] = gacc[h][kk][0] = gacc[h][kk][1] = gacc[h][kk][2] = 0.0;
         for (int64_t r = r0; r < r1; ++r) {
             const int wc = w_cells[r];
             const double half = lengths[wc] * 0.5;
@@ -622,18 +660,23 @@ __global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *
                 __syncthreads();
                 stage_nodes(tile, chp, P1, P2, j0, cnt, cx, cy, cz, half, d, coef, C * n_pad, kb, tid, 256);
                 __syncthreads();
-                if (part) direct_tile<KID, GRAD, KB>(ks, tile, cnt, sl, S, tx, ty, tz, acc, gacc);
+                if (part) direct_tile<KID, GRAD, KB>(ks, tile, cnt, sl, tp.S, t, acc, gacc);
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            if (kk >= kb) break;
-            const double v = slice_reduce(acc[kk], red, ti, sl, S, nt, part);
-            if (part && sl == 0) unsafeAtomicAdd(&out[(int64_t)(k0 + kk) * n_tgt + tc + ti], v);
-            if (GRAD) {
-                for (int a = 0; a < d; ++a) {
-                    const double g = slice_reduce(gacc[kk][a], red, ti, sl, S, nt, part);
-                    if (part && sl == 0) unsafeAtomicAdd(&grad[((int64_t)(k0 + kk) * d + a) * n_tgt + tc + ti], g);
+        for (int h = 0; h < 2; ++h) {
+            const bool wr = part && sl == 0 && (h == 0 || two);
+            const int64_t it = tc + ti + h * tp.pairs;
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                if (kk >= kb) break;
+                const double v = slice_reduce(acc[h][kk], red, ti, sl, tp.S, tp.pairs, part);
+                if (wr) unsafeAtomicAdd(&out[(int64_t)(k0 + kk) * n_tgt + it], v);
+                if (GRAD) {
+                    for (int a = 0; a < d; ++a) {
+                        const double g = slice_reduce(gacc[h][kk][a], red, ti, sl, tp.S, tp.pairs, part);
+                        if (wr) unsafeAtomicAdd(&grad[((int64_t)(k0 + kk) * d + a) * n_tgt + it], g);
+                    }
                 }
             }
         }
@@ -662,22 +705,28 @@ __global__ __launch_bounds__(256) void p2l_kernel(KernelSpec ks, const DevCheb *
     const double half = lengths[cell] * 0.5;
     const double cx = centers[cell * 3], cy = centers[cell * 3 + 1], cz = centers[cell * 3 + 2];
     const int64_t r0 = run_ptr[job], r1 = run_ptr[job + 1];
-    for (int tc = 0; tc < n; tc += 256) {
-        const int nt = min(256, n - tc);
-        const int S = 256 / nt;
-        const int ti = tid % nt, sl = tid / nt;
-        const bool part = sl < S;
-        double tx = 0, ty = 0, tz = 0;
+    const TargetPlan tp = plan_targets(n);
+    for (int tc = 0; tc < n; tc += tp.n_c) {
+        const int nt = min(tp.n_c, n - tc);
+        const int ti = tid % tp.pairs, sl = tid / tp.pairs;
+        const bool part = sl < tp.S && ti < nt;
+        const bool two = ti + tp.pairs < nt;
+        double t[2][3] = {{0, 0, 0}, {0, 0, 0}};
         if (part) {
-            const int I = tc + ti;
-            const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1);
-            tx = cx + half * chp->nodes[i0];
-            ty = d > 1 ? cy + half * chp->nodes[i1] : 0.0;
-            tz = d > 2 ? cz + half * chp->nodes[i2] : 0.0;
-        }
-        double acc[KB], gacc[KB][3];
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) acc[kk] = 0.0;
+            for (int h = 0; h < 2; ++h) {
+                const int I = tc + ti + ((h && two) ? tp.pairs : 0);
+                const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1);
+                t[h][0] = cx + half * chp->nodes[i0];
+                t[h][1] = d > 1 ? cy + half * chp->nodes[i1] : 0.0;
+                t[h][2] = d > 2 ? cz + half * chp->nodes[i2] : 0.0;
+            }
+        }
+        double acc[2][KB], gacc[2][KB][3];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) acc[h][kk] = 0.0;
         for (int64_t r = r0; r < r1; ++r) {
             const int sb = runs[2 * r], se = runs[2 * r + 1];
             for (int base = sb; base < se; base += DIRECT_TILE) {
@@ -691,14 +740,18 @@ __global__ __launch_bounds__(256) void p2l_kernel(KernelSpec ks, const DevCheb *
                         tile.w[kk][j] = kk < kb ? ws[(int64_t)(k0 + kk) * N + base + j] : 0.0;
                 }
                 __syncthreads();
-                if (part) direct_tile<KID, false, KB>(ks, tile, cnt, sl, S, tx, ty, tz, acc, gacc);
+                if (part) direct_tile<KID, false, KB>(ks, tile, cnt, sl, tp.S, t, acc, gacc);
             }
         }
 #pragma unroll
-        for (int kk = 0; kk < KB; ++kk) {
-            if (kk >= kb) break;
-            const double v = slice_reduce(acc[kk], red, ti, sl, S, nt, part);
-            if (part && sl == 0) L[((int64_t)(k0 + kk) * C + cell) * n_pad + tc + ti] += v;
+        for (int h = 0; h < 2; ++h) {
+            const bool wr = part && sl == 0 && (h == 0 || two);
+#pragma unroll
+            for (int kk = 0; kk < KB; ++kk) {
+                if (kk >= kb) break;
+                const double v = slice_reduce(acc[h][kk], red, ti, sl, tp.S, tp.pairs, part);
+                if (wr) L[((int64_t)(k0 + kk) * C + cell) * n_pad + tc + ti + h * tp.pairs] += v;
+            }
         }
     }
 }
