@@ -67,9 +67,28 @@ inline KernelSpec make_kernel_spec(int id, double base_range, double total_sill)
     return k;
 }
 
-// sqrt for the pair loops.  Host: libm.  Device: v_rsq_f64 seed + one Goldschmidt step + one
-// residual correction (about 1 ulp; 9 instructions instead of the ~24 of the correctly rounded
-// library sqrt, measured 96 -> ~56 cycles per wave on MI355X).  x >= 0 always (sum of squares).
+// sqrt / 1/sqrt / 1/x for the pair loops.  Host: libm and IEEE division.  Device: v_rsq_f64 /
+// v_rcp_f64 seeds refined by Goldschmidt / Newton steps built from FMAs (1-2 ulp; the correctly
+// rounded library sqrt and division are 24-30 instructions each; measured 96 -> ~56 cycles per
+// wave for sqrt on MI355X).  x >= 0 always (sums of squares).
+BBFMM_HD inline void bb_sqrt_rsqrt(double x, double *s, double *rs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    const double d = fma(-g, g, x);
+    g = fma(d, h, g);          // sqrt(x)
+    r = fma(-h, g, 0.5);
+    h = fma(h, r, h);          // 1 / (2 sqrt(x))
+    *s = x > 0.0 ? g : 0.0;    // rsq(0) = inf would give NaN
+    *rs = h + h;
+#else
+    *s = sqrt(x);
+    *rs = 1.0 / *s;
+#endif
+}
 BBFMM_HD inline double bb_sqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(x);
@@ -84,35 +103,113 @@ BBFMM_HD inline double bb_sqrt(double x) {
     return sqrt(x);
 #endif
 }
+BBFMM_HD inline double bb_rcp(double x) { // x > 0, finite
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+#else
+    return 1.0 / x;
+#endif
+}
+
+// Natural logarithm for the pair loops (x > 0, normal).  Host: libm.  Device: exponent / mantissa
+// split, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh((m - 1) / (m + 1)) as an odd series in
+// s = (m - 1) / (m + 1), |s| <= 0.1716, through s^23 (truncation < 1e-18): about 35 FMA-class
+// instructions against ~420 cycles per wave measured for the library log on MI355X.
+BBFMM_HD inline double bb_log(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double m = __builtin_amdgcn_frexp_mant(x); // [0.5, 1)
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double s = (m - 1.0) * bb_rcp(m + 1.0);
+    const double s2 = s * s;
+    double p = 1.0 / 23.0;
+    p = fma(p, s2, 1.0 / 21.0);
+    p = fma(p, s2, 1.0 / 19.0);
+    p = fma(p, s2, 1.0 / 17.0);
+    p = fma(p, s2, 1.0 / 15.0);
+    p = fma(p, s2, 1.0 / 13.0);
+    p = fma(p, s2, 1.0 / 11.0);
+    p = fma(p, s2, 1.0 / 9.0);
+    p = fma(p, s2, 1.0 / 7.0);
+    p = fma(p, s2, 1.0 / 5.0);
+    p = fma(p, s2, 1.0 / 3.0);
+    const double ed = (double)e;
+    const double t = s + s;
+    // e ln2 in two parts; ln2_hi has 11 trailing zero bits so e * ln2_hi is exact
+    const double hi = ed * 6.93147180369123816490e-01;
+    const double lo2 = fma(ed, 1.90821492927058770002e-10, t * (s2 * p));
+    return hi + (t + lo2);
+#else
+    return log(x);
+#endif
+}
 
 // Value from r^2 = distance_sq (utils.rs:230-237).
 template <int ID> BBFMM_HD inline double kernel_value_r2(const KernelSpec &k, double r2) {
     if constexpr (ID == kLinear) { // rbf_kernels.rs:25-36
         return -bb_sqrt(r2);
     } else if constexpr (ID == kThinPlateSpline) { // rbf_kernels.rs:69-84
-        const double r = bb_sqrt(r2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // r^2 ln r = r2 ln(r2) / 2: no square root; |r| < eps  <=>  r2 < eps^2
+        return (r2 < DBL_EPSILON * DBL_EPSILON) ? 0.0 : 0.5 * r2 * bb_log(r2);
+#else
+        const double r = sqrt(r2);
         return (fabs(r) < DBL_EPSILON) ? 0.0 : (r * r) * log(r);
+#endif
     } else if constexpr (ID == kCubic) { // rbf_kernels.rs:118-130
         const double r = bb_sqrt(r2);
         return r * r * r;
     } else if constexpr (ID >= kSpheroidal3 && ID <= kSpheroidal9) { // rbf_kernels.rs:245-256
+        constexpr int POW = ID - kSpheroidal3 + 1;
         const double sr2 = k.s2 * r2;
-        if (sr2 <= k.ip2) return k.total_sill - k.near_slope * bb_sqrt(r2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // near: sill - slope * sqrt(r2); far: far_coef / ((1 + s2 r2)^POW * sqrt(1 + s2 r2)).  Both
+        // come from one square root of the selected argument (lanes of a wave diverge here).
+        const bool near = sr2 <= k.ip2;
+        double sq, rs;
+        bb_sqrt_rsqrt(near ? r2 : 1.0 + sr2, &sq, &rs);
+        const double rs2 = rs * rs;
+        double rp = rs; // rs^(2 POW + 1) = 1 / (t^POW sqrt(t))
+#pragma unroll
+        for (int i = 0; i < POW; ++i) rp *= rs2;
+        return near ? k.total_sill - k.near_slope * sq : k.far_coef * rp;
+#else
+        if (sr2 <= k.ip2) return k.total_sill - k.near_slope * sqrt(r2);
         const double t = 1.0 + sr2;
         double tp = t;
-        constexpr int POW = ID - kSpheroidal3 + 1;
-#pragma unroll
         for (int i = 1; i < POW; ++i) tp *= t;
-        return k.far_coef / (tp * bb_sqrt(t));
-    } else if constexpr (ID == kLaplacian) { // non_rbf_kernels.rs:20-37
-        const double r = bb_sqrt(r2);
+        return k.far_coef / (tp * sqrt(t));
+#endif
+    } else if constexpr (ID == kLaplacian) { // non_rbf_kernels.rs:20-37: 0 if |r| < eps, else 1 / r
+#if defined(__HIP_DEVICE_COMPILE__)
+        double sq, rs;
+        bb_sqrt_rsqrt(r2, &sq, &rs);
+        return (sq < DBL_EPSILON) ? 0.0 : rs;
+#else
+        const double r = sqrt(r2);
         return (fabs(r) < DBL_EPSILON) ? 0.0 : 1.0 / r;
+#endif
     } else if constexpr (ID == kOneOverR2) { // non_rbf_kernels.rs:70-86
-        const double r = bb_sqrt(r2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (r2 < DBL_EPSILON * DBL_EPSILON) ? 0.0 : bb_rcp(r2);
+#else
+        const double r = sqrt(r2);
         return (fabs(r) < DBL_EPSILON) ? 0.0 : 1.0 / (r * r);
+#endif
     } else if constexpr (ID == kOneOverR4) { // non_rbf_kernels.rs:121-137
-        const double r = bb_sqrt(r2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double q = (r2 < DBL_EPSILON * DBL_EPSILON) ? 0.0 : bb_rcp(r2);
+        return q * q;
+#else
+        const double r = sqrt(r2);
         return (fabs(r) < DBL_EPSILON) ? 0.0 : 1.0 / ((r * r) * (r * r));
+#endif
     } else if constexpr (ID == kGaussianExt) {
         return exp(-r2 * k.inv_br2);
     } else { // kMultiquadricExt
@@ -132,7 +229,7 @@ BBFMM_HD inline double kernel_value_grad_r2(const KernelSpec &k, double r2, doub
         return -r;
     } else if constexpr (ID == kThinPlateSpline) {
         if (zero) { *factor = 0.0; return 0.0; }
-        const double lr = log(bb_sqrt(r2));
+        const double lr = 0.5 * bb_log(r2);
         *factor = 2.0 * lr + 1.0;
         return r2 * lr;
     } else if constexpr (ID == kCubic) {
