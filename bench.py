@@ -121,19 +121,9 @@ def main():
     out = torch.zeros((K, N), dtype=torch.float64, device=dev)
 
     if world > 1:
-        m_all = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(m_all, torch.tensor([len(rows)], dtype=torch.int64, device=dev))
-        m_all = [int(m.item()) for m in m_all]
-        m_max = max(m_all)
-        rows_t = torch.from_numpy(rows).to(dev)
-        rows_pad = torch.full((m_max,), -1, dtype=torch.int64, device=dev)
-        rows_pad[:len(rows)] = rows_t
-        all_rows = torch.empty((world, m_max), dtype=torch.int64, device=dev)
-        dist.all_gather_into_tensor(all_rows, rows_pad)
-        valid = all_rows.reshape(-1) >= 0
-        flat_rows = all_rows.reshape(-1)[valid]
-        send = torch.zeros((K, m_max), dtype=torch.float64, device=dev)
-        recv = torch.empty((world, K, m_max), dtype=torch.float64, device=dev)
+        from ferreus_rbf_rs_amd.distributed import OwnedRowsExchange
+        xchg = OwnedRowsExchange(rows, N, K, dev)     # owned rows are a disjoint cover: all-gather
+        assert xchg.check_partition(), "partition does not cover the targets exactly once"
 
     stream = torch.cuda.ExternalStream(tree.stream(), device=dev)
 
@@ -143,9 +133,7 @@ def main():
         if world > 1:
             # exchange step: owned potentials only (disjoint by construction) -> all-gather
             with torch.cuda.stream(stream):
-                send[:, :len(rows)] = out[:, rows_t]
-                dist.all_gather_into_tensor(recv, send)
-                out[:, flat_rows] = recv.permute(1, 0, 2).reshape(K, -1)[:, valid]
+                xchg.exchange(out)
 
     def sync():
         torch.cuda.synchronize()
@@ -193,10 +181,23 @@ def main():
         kd = kern[dominant]
         dur = per_launch[dominant] * 1e-3
         achieved = kd["work"] / dur * kd["scale"] if dur > 0 and world == 1 else None
+        # HBM-side bytes of the dominant kernel: bench.py cannot run rocprofv3 on itself, so the figure
+        # comes from the committed PMC passes of this same command (scripts/gpu_traffic.sh ->
+        # profiles/r01_traffic.json: FETCH_SIZE x2 (gfx950 correction for 16-B/lane reads) + WRITE_SIZE,
+        # KiB -> bytes, per launch); null when no profile matches the workload.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+                tj = json.load(f)
+            if (tj.get("points"), tj.get("kernel"), tj.get("order"), tj.get("nrhs")) == (N, args.kernel, args.order, K) \
+                    and world == 1:
+                traffic = tj["per_launch_bytes"].get(dominant)
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {
             "kernel": dominant, "bound": kd["bound"], "achieved": achieved, "peak": kd["peak"],
             "unit": kd["unit"], "frac": (achieved / kd["peak"]) if achieved else None,
-            "traffic": None,
+            "traffic": traffic,
             "avg_launch_ms": per_launch[dominant],
             "algorithmic_work_per_launch": kd["work"],
         }

@@ -8,4 +8,5 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --cpu-baseline off > $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_stdout.txt 2>&1
 grep '^{' $GRAFT_REPO_ROOT/gpurun_out/prof_${TAG}_stdout.txt | cut -c1-300
-head -12 $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/*/*_kernel_stats.csv | cut -c1-160
+head -14 $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/*/*_kernel_stats.csv | cut -c1-160
+cp $GRAFT_REPO_ROOT/gpurun_out/prof_$TAG/*/*_kernel_stats.csv $GRAFT_REPO_ROOT/gpurun_out/kernel_stats_$TAG.csv
