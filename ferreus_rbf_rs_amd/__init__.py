@@ -7,6 +7,8 @@ from .fmm_tree import (FmmError, FmmKernelType, FmmParams, FmmTree, KernelDoesNo
                        KernelParams, KernelType, M2LCompressionType, PointOutsideTree,
                        SpheroidalOrder, mfma_f64_selftest)
 
-__all__ = ["FmmTree", "FmmParams", "KernelParams", "KernelType", "FmmKernelType",
+from . import solvers  # noqa: E402  (FGMRES / Schwarz drivers, iterative_solvers.rs)
+
+__all__ = ["solvers", "FmmTree", "FmmParams", "KernelParams", "KernelType", "FmmKernelType",
            "SpheroidalOrder", "M2LCompressionType", "FmmError", "PointOutsideTree",
            "KernelDoesNotSupportGradients", "mfma_f64_selftest"]

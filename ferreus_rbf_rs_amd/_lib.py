@@ -78,7 +78,24 @@ SIGNATURES = {
     "bbfmm_debug_dense_m2m": (ctypes.c_int, [c_p, c_i32, c_p]),
     "bbfmm_debug_apply_m2l_tables_host": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_debug_get_coefficients": (ctypes.c_int, [c_p, ctypes.c_char, c_i32, c_p]),
+    "bbfmm_givens_rotation": (None, [c_f64, c_f64, c_p, c_p, c_p]),
+    "bbfmm_fgmres": (ctypes.c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f64,
+                                    c_p, c_p, c_p, c_p, c_p]),
+    "bbfmm_schwarz_ddm_solver": (ctypes.c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_f64,
+                                                c_p, c_p, c_p, c_p, c_p]),
+    "bbfmm_rbf_system_apply": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
 }
+
+# bbfmm_apply_fn, bbfmm_iteration_fn
+APPLY_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_p, ctypes.POINTER(c_f64), ctypes.POINTER(c_f64), c_i64)
+ITERATION_FN = ctypes.CFUNCTYPE(None, c_p, c_i64, c_f64, c_f64)
+ACCURACY_ABSOLUTE, ACCURACY_RELATIVE = 0, 1
+
+
+class RbfSystem(ctypes.Structure):
+    """bbfmm_rbf_system"""
+    _fields_ = [("tree", c_p), ("basis_size", c_i64), ("monomial_matrix", c_p), ("ld_monomial", c_i64),
+                ("nugget", c_f64)]
 
 _lib = None
 

@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libferreus_bbfmm_hip.so")
 
-HOST_SOURCES = ["tree.cpp", "operators.cpp", "fmm_tree.cpp", "capi.cpp"]
+HOST_SOURCES = ["tree.cpp", "operators.cpp", "fmm_tree.cpp", "capi.cpp", "solver.cpp"]
 HIP_SOURCES = ["device.hip"]
 HEADERS = ["morton.hpp", "tree.hpp", "parallel.hpp", "kernels.hpp", "operators.hpp", "device.hpp",
            "fmm_tree.hpp", os.path.join(ROOT, "include", "ferreus_bbfmm_hip.h")]

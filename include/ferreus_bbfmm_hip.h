@@ -245,6 +245,57 @@ int bbfmm_debug_apply_m2l_tables_host(const bbfmm_handle *h, const double *M, do
  * reference's n x (C*K) matrices (bbfmm.rs:234-242).  Per-phase parity checks. */
 int bbfmm_debug_get_coefficients(bbfmm_handle *h, char which, int32_t k, double *out);
 
+/* ------------------------------------------------------------------ iterative solvers
+ * ferreus_rbf/src/iterative_solvers.rs: host FGMRES / stationary Schwarz
+ * drivers around operator callbacks, so the reference's closures (`matvec`, `precon`,
+ * rbf.rs:523-524) plug in unchanged.  Vectors are host arrays of n doubles. */
+
+/* y = Op(x); return BBFMM_OK or an error code (which the solver returns as is). */
+typedef int (*bbfmm_apply_fn)(void *user, const double *x, double *y, int64_t n);
+/* ProgressMsg::SolverIteration {iter, residual, progress} (iterative_solvers.rs:142-148) */
+typedef void (*bbfmm_iteration_fn)(void *user, int64_t iter, double residual, double progress);
+
+/* FittingAccuracyType (interpolant_config.rs:54-63) */
+enum { BBFMM_ACCURACY_ABSOLUTE = 0, BBFMM_ACCURACY_RELATIVE = 1 };
+
+/* givens_rotation (iterative_solvers.rs:185-227), a port of LAPACK dlartg:
+ * [c s; -s c] [f; g] = [r; 0]. */
+void bbfmm_givens_rotation(double f, double g, double *c, double *s, double *r);
+
+/*
+ * fgmres (iterative_solvers.rs:38-172): restarted flexible GMRES, right preconditioner m
+ * (NULL: none), initial guess x0 (NULL: zero), max_outer_iterations restarts of
+ * max_inner_iterations Krylov vectors (the solver uses 20 x 5, rbf.rs:545-554), modified
+ * Gram-Schmidt, Givens rotations.  Stopping: Absolute -> |g[j+1]| (max-norm of the true residual
+ * at restarts) < tolerance; Relative -> the same over the initial 2-norm.  callback (may be NULL)
+ * receives every inner iteration.  Outputs: x (n), the number of inner iterations done and the
+ * last residual measure (both optional).
+ * Deviation: an exactly zero residual returns x instead of dividing by zero.
+ */
+int bbfmm_fgmres(int64_t n, bbfmm_apply_fn a, void *a_user, const double *b, bbfmm_apply_fn m, void *m_user,
+                 const double *x0, int32_t max_outer_iterations, int32_t max_inner_iterations,
+                 int32_t tolerance_type, double tolerance, bbfmm_iteration_fn callback, void *cb_user,
+                 double *x, int64_t *iterations, double *final_residual);
+
+/* schwarz_ddm_solver (iterative_solvers.rs:229-281): s += M(r); r = rhs - A s, at most
+ * max_iterations times (the solver uses 100, rbf.rs:555-562).  m NULL -> zero vector, as the
+ * reference. */
+int bbfmm_schwarz_ddm_solver(int64_t n, bbfmm_apply_fn matvec, void *a_user, const double *rhs,
+                             bbfmm_apply_fn m, void *m_user, int32_t max_iterations, int32_t tolerance_type,
+                             double tolerance, bbfmm_iteration_fn callback, void *cb_user, double *x,
+                             int64_t *iterations, double *final_residual);
+
+/* IterativeSolver::matvec (rbf.rs:105-117) as an operator callback: pass a bbfmm_rbf_system as
+ * `user`; n must be N + basis_size.  Runs bbfmm_fast_matrix_vector_product on all sources. */
+typedef struct bbfmm_rbf_system {
+    bbfmm_handle *tree;
+    int64_t basis_size;            /* InterpolantSettings::basis_size */
+    const double *monomial_matrix; /* N x basis_size column-major, or NULL */
+    int64_t ld_monomial;
+    double nugget;
+} bbfmm_rbf_system;
+int bbfmm_rbf_system_apply(void *user, const double *x, double *y, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif
