@@ -85,6 +85,7 @@ FmmTree::~FmmTree() {
         (void)hipEventDestroy(pp.e1);
     }
     for (hipEvent_t e : event_pool_) (void)hipEventDestroy(e);
+    if (h_pin_) (void)hipHostFree(h_pin_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (stream2_) (void)hipStreamDestroy(stream2_);
@@ -758,6 +759,16 @@ int FmmTree::upload_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     return BBFMM_OK;
 }
 
+int FmmTree::ensure_pinned(size_t n) {
+    if (n <= h_pin_n_) return BBFMM_OK;
+    if (h_pin_) (void)hipHostFree(h_pin_);
+    h_pin_ = nullptr;
+    h_pin_n_ = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_pin_), n * sizeof(double), hipHostMallocDefault));
+    h_pin_n_ = n;
+    return BBFMM_OK;
+}
+
 // upward_pass (bbfmm.rs:666-688)
 int FmmTree::upward(int k) {
     const HostTree &t = tree_;
@@ -984,20 +995,46 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
     if (!w || !result || basis_size < 0 || rows != N + basis_size)
         return fail(BBFMM_BAD_ARGUMENT, "weights must have N + basis_size rows");
     if (poly && ldp < N) return fail(BBFMM_BAD_ARGUMENT, "polynomial matrix needs N rows");
+    if (!target_indices) {
+        // All sources (the FGMRES matvec, rbf.rs:105-117): the targets already live on the device.
+        // Host traffic goes through one pinned staging buffer (pageable copies run at a fraction of
+        // the PCIe rate), and the host loops are threaded.
+        CHK(ensure_pinned(static_cast<size_t>(2 * N)));
+        double *pin_in = h_pin_, *pin_out = h_pin_ + N;
+        parallel_for_chunks(N, int64_t(1) << 18, [&](int64_t b, int64_t e) {
+            std::memcpy(pin_in + b, w + b, static_cast<size_t>(e - b) * sizeof(double));
+        });
+        CHK(ensure_rhs_capacity(1));
+        if (static_cast<size_t>(N) > d_w_in_.n) {
+            dfree(&d_w_in_);
+            CHK(dalloc(&d_w_in_, static_cast<size_t>(N)));
+        }
+        HIPCHK(hipMemcpyAsync(d_w_in_.p, pin_in, N * sizeof(double), hipMemcpyHostToDevice, stream_));
+        nrhs_ = 1;
+        if (have_part_) // a partitioned handle fills its owned rows only; the others read as 0
+            HIPCHK(hipMemsetAsync(d_out_.p, 0, static_cast<size_t>(N) * sizeof(double), stream_));
+        CHK(matvec_device(d_w_in_.p, N, 1, d_out_.p, N, false)); // set_weights + evaluate, rbf.rs:1357-1364
+        HIPCHK(hipMemcpyAsync(pin_out, d_out_.p, N * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipStreamSynchronize(stream_));
+        parallel_for_chunks(N, int64_t(1) << 16, [&](int64_t b, int64_t e) { // rbf.rs:1366-1376
+            for (int64_t i = b; i < e; ++i) {
+                double r = pin_out[i] + w[i] * nugget;
+                if (poly) {
+                    double s = 0.0;
+                    for (int64_t q = 0; q < basis_size; ++q) s += poly[q * ldp + i] * w[N + q];
+                    r += s;
+                }
+                result[i] = r;
+            }
+        });
+        std::fill(result + N, result + rows, 0.0); // the last basis_size rows stay 0 (rbf.rs:1346)
+        return BBFMM_OK;
+    }
     std::fill(result, result + rows, 0.0); // rbf.rs:1346
     CHK(set_weights(w, rows, 1, rows));    // rbf.rs:1357
     std::vector<double> vals;
     std::vector<int64_t> idx;
-    if (!target_indices) { // all sources: the targets already live on the device
-        CHK(downward(1));
-        CHK(leaf_pass(src_targets_, 1, false));
-        launch_scatter_output(src_targets_.out.p, N, 1, d_order_.p, d_out_.p, N, 0, stream_);
-        vals.resize(static_cast<size_t>(N));
-        HIPCHK(hipMemcpyAsync(vals.data(), d_out_.p, N * sizeof(double), hipMemcpyDeviceToHost, stream_));
-        HIPCHK(hipStreamSynchronize(stream_));
-        idx.resize(static_cast<size_t>(N));
-        std::iota(idx.begin(), idx.end(), int64_t(0));
-    } else {
+    {
         idx.assign(target_indices, target_indices + n_target_indices);
         for (int64_t i : idx)
             if (i < 0 || i >= N) return fail(BBFMM_BAD_ARGUMENT, "target index out of range");

@@ -193,6 +193,9 @@ class FmmTree {
     // per-rhs-capacity buffers
     int k_cap_ = 0;
     DevBuf<double> d_w_in_, d_w_sorted_, d_M_, d_L_, d_cbuf_, d_out_;
+    double *h_pin_ = nullptr; // pinned staging for the host-buffer matvec (N doubles up, N down)
+    size_t h_pin_n_ = 0;
+    int ensure_pinned(size_t n);
     int64_t w_in_rows_ = 0;
     TargetSet src_targets_;  // targets = sources (the matvec)
     TargetSet part_targets_; // sources owned by this rank (multi-GPU)
