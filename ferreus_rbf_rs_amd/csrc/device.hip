@@ -849,7 +849,8 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                                                   const M2lTileDesc *__restrict__ tiles, int n_pad, int g16_0,
                                                   int64_t C, const double *__restrict__ in, int64_t in_len,
                                                   double *__restrict__ out, int64_t out_len,
-                                                  const uint16_t *__restrict__ qlist, int slot_t) {
+                                                  const uint16_t *__restrict__ qlist, int slot_t,
+                                                  const int32_t *__restrict__ tile_idx) {
     // 2 x { operator [e][ng][k*16 + col], IN tile [wave][tg][eh][k][j] x 2 }; stage 1 adds the slot
     // lookups of the current column block, [wave][cell 0..15][slot_t] int32
     extern __shared__ double lds[];
@@ -883,13 +884,19 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
         const int e = f / NG16, ng = f - e * NG16;
         voff[i] = (unsigned)(((4 * k + e) * ld + 16 * ng + 2 * pair) * 8);
     }
+    // position of the tile's cell `pos` in its class list (a partition's source tiles are compact
+    // lists of class positions, tile.pad != 0)
+    auto cell_p = [&](int pos) {
+        const int q = pos < tile.count ? pos : 0;
+        return (STAGE == 1 && tile.pad) ? tile_idx[tile.first + q] : tile.first + q;
+    };
     // IN tile: chunk h of this wave covers tg = 2h + (lane>>5), eh = (lane>>4)&1, k = (lane>>2)&3, j = lane&3
     const double *cptr[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int tg = 2 * h + (lane >> 5), eh = (lane >> 4) & 1, k = (lane >> 2) & 3, j = lane & 3;
         const int pos = wave * 16 + 4 * tg + j;
-        const int p = tile.first + (pos < tile.count ? pos : 0);
+        const int p = cell_p(pos);
         const int64_t base = STAGE == 1 ? ((int64_t)kr * C + cls.cells[p]) * n_pad : (int64_t)kr * in_len + cls.cbase[p];
         cptr[h] = in + base + 4 * k + 2 * eh;
     }
@@ -930,7 +937,9 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     // and the stores of a block leave together and drain under the next block.
     constexpr int AUX = 192;
     const int32_t *aux = reinterpret_cast<const int32_t *>(lds + 2 * BUF);
-    const int32_t *slds = aux + 2 * AUX + wave * 16 * slot_t;
+    int32_t *ptab = reinterpret_cast<int32_t *>(lds + 2 * BUF) + 2 * AUX; // class positions of the 128 cells
+    const int32_t *slds = aux + 2 * AUX + 128 + wave * 16 * slot_t;
+    if (STAGE == 1 && lane < 16) ptab[wave * 16 + lane] = cell_p(wave * 16 + lane); // read by this wave only
     const unsigned aux0 = lds0 + (unsigned)(2 * BUF) * 8u;
     auto stage_cols = [&](int zb_, int par) {
         if (STAGE == 1 && 64 * wave <= 16 * NG16) {
@@ -942,12 +951,10 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     const int slot_sh = 31 - __builtin_clz(slot_t | 1); // slot_t is a power of two >= 16 in stage 1
     auto stage_slots = [&](int par) {
         const int t0 = __builtin_amdgcn_readfirstlane(aux[par * AUX + 16 * NG16]);
-        const unsigned dst0 = aux0 + (unsigned)(2 * AUX + wave * 16 * slot_t) * 4u;
+        const unsigned dst0 = aux0 + (unsigned)(2 * AUX + 128 + wave * 16 * slot_t) * 4u;
         for (int i = 0; i < slot_t / 4; ++i) {
             const int e = i * 64 + lane, cl = e >> slot_sh, tl = e & (slot_t - 1);
-            const int sp = wave * 16 + cl;
-            const int32_t *src = cls.cslot + (int64_t)(tile.first + (sp < tile.count ? sp : 0)) * cls.n_t +
-                                 min(t0 + tl, cls.n_t - 1);
+            const int32_t *src = cls.cslot + (int64_t)ptab[wave * 16 + cl] * cls.n_t + min(t0 + tl, cls.n_t - 1);
             dma4(src, dst0 + (unsigned)i * 256u);
         }
     };
@@ -1224,8 +1231,8 @@ void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
 template <int NG16, int STAGE, int MINW>
 static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g16_0,
                             int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
-                            int64_t out_len, const uint16_t *qlist, int slot_t, hipStream_t s) {
-    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 8 * 16 * slot_t) * 4 : 0); // + aux and slot tables
+                            int64_t out_len, const uint16_t *qlist, int slot_t, const int32_t *tile_idx, hipStream_t s) {
+    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 128 + 8 * 16 * slot_t) * 4 : 0); // + aux, cell and slot tables
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_gemm_k4<NG16, STAGE, MINW>),
@@ -1233,7 +1240,7 @@ static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, i
         attr_set = true;
     }
     hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, n_colblocks), dim3(512), lds, s, classes,
-                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t);
+                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t, tile_idx);
 }
 
 // Column-chunk plan: 16-column groups per workgroup.  Stage 1 walks column blocks of kM2lS1Block =
@@ -1253,7 +1260,8 @@ template <int STAGE> static int m2l_chunk_pref() {
 template <int STAGE>
 static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
                                 int n_pad, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
-                                double *out, int64_t out_len, const uint16_t *qlist, int slot_t, hipStream_t s) {
+                                double *out, int64_t out_len, const uint16_t *qlist, int slot_t,
+                                const int32_t *tile_idx, hipStream_t s) {
     int done = 0;
     const int pref = m2l_chunk_pref<STAGE>();
     while (done < total_groups) {
@@ -1263,7 +1271,7 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
     {                                                                                                               \
         take = NG;                                                                                                  \
         m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done, n_colblocks, K, C, in, in_len, out,    \
-                                       out_len, qlist, slot_t, s);                                                  \
+                                       out_len, qlist, slot_t, tile_idx, s);                                        \
     }
         if (pref == 22 && left >= 22) M2L_GO(22, 1)
         else if (pref == 22 && left >= 16) M2L_GO(16, 1)
@@ -1279,8 +1287,9 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
 
 // Stage 1: every class's stacked operator is padded to a whole number of kM2lS1Block columns;
 // blockIdx.z walks the column blocks, the chunk plan splits a block.
-void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int max_slot_t,
-                       int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len, hipStream_t s) {
+void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
+                       int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
+                       hipStream_t s) {
     if (n_tiles == 0) return;
     int slot_t = 16; // LDS slot-table width: power of two covering the transfer vectors of any block
     while (slot_t < max_slot_t) slot_t *= 2;
@@ -1292,14 +1301,14 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, int n_
         return v >= 1 && v <= 16 ? v : 2;
     }();
     const int n_colblocks = zsplit;
-    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, slot_t, s);
+    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, slot_t, tile_idx, s);
 }
 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
                        const double *cbuf, int64_t cbuf_len, const uint16_t *qlist, double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, s);
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, nullptr, s);
 }
 
 // ------------------------------------------------------------------ MFMA self test

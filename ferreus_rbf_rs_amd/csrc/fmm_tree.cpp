@@ -793,20 +793,33 @@ int FmmTree::downward(int k) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
     HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_)); // 627-632
-    const M2lTileDesc *tiles = have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles_.p;
-    const int n_tiles = have_part_ ? n_m2l_tiles_part_ : static_cast<int>(m2l_tiles_h_.size());
+    // a partition runs stage 1 on compact tiles of the sources its targets need, stage 2 on the
+    // tiles that hold an owned target, P2L on owned cells
+    const int n_all = static_cast<int>(m2l_tiles_h_.size());
     phase_begin();
-    launch_m2l_stage1(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_,
-                      stream_);
+    if (have_part_)
+        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles_part1_.p, d_m2l_tile_idx_part_.p,
+                          static_cast<int>(m2l_tiles_part1_h_.size()), cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p,
+                          d_cbuf_.p, cbuf_len_, stream_);
+    else
+        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles_.p, nullptr, n_all, cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p,
+                          d_cbuf_.p, cbuf_len_, stream_);
     phase_end(kPhM2L1);
     phase_begin();
-    launch_m2l_stage2(d_m2l_classes_.p, tiles, n_tiles, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, d_L_.p,
-                      stream_);
+    launch_m2l_stage2(d_m2l_classes_.p, have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles_.p,
+                      have_part_ ? n_m2l_tiles_part_ : n_all, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_,
+                      d_m2l_qlist_.p, d_L_.p, stream_);
     phase_end(kPhM2L2);
     phase_begin();
-    if (t.adaptive)
-        launch_p2l(kernel_, cheb_, static_cast<int>(x_cells_.size()), d_x_cells_.p, d_x_job_run_ptr_.p, d_x_runs_.p,
-                   d_centers_.p, d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p, stream_);
+    if (t.adaptive) {
+        if (have_part_)
+            launch_p2l(kernel_, cheb_, n_x_jobs_part_, d_x_cells_part_.p, d_x_job_run_ptr_part_.p, d_x_runs_part_.p,
+                       d_centers_.p, d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p, stream_);
+        else
+            launch_p2l(kernel_, cheb_, static_cast<int>(x_cells_.size()), d_x_cells_.p, d_x_job_run_ptr_.p,
+                       d_x_runs_.p, d_centers_.p, d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p,
+                       stream_);
+    }
     phase_end(kPhP2L);
     phase_begin();
     for (int level = 2; level <= t.depth; ++level) // children of level-1.. cells (bbfmm.rs:834-856)
@@ -1072,6 +1085,11 @@ int FmmTree::set_partition(int rank, int world) {
     if (have_part_) {
         free_target_set(&part_targets_);
         dfree(&d_m2l_tiles_part_);
+        dfree(&d_m2l_tiles_part1_);
+        dfree(&d_m2l_tile_idx_part_);
+        dfree(&d_x_cells_part_);
+        dfree(&d_x_job_run_ptr_part_);
+        dfree(&d_x_runs_part_);
         have_part_ = false;
     }
     part_rows_.clear();
@@ -1109,21 +1127,51 @@ int FmmTree::set_partition(int rank, int world) {
             c = t.parent[c];
         }
     }
-    // M2L tiles that contain an active target (stage 2) or a source of one (stage 1)
+    // M2L: stage 2 on the tiles that hold an active target; stage 1 on compact tiles (lists of class
+    // positions, 128 per tile) of the cells that are a V-list source of an active target
     std::vector<uint8_t> needed(static_cast<size_t>(C), 0);
     for (int64_t B = 0; B < C; ++B) {
         if (!active[B] || t.level[B] < 2) continue;
-        needed[B] = 1;
         for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) needed[t.v.idx[q]] = 1;
     }
     m2l_tiles_part_h_.clear();
     for (const M2lTileDesc &td : m2l_tiles_h_) {
         const HostM2lClass &hc = m2l_host_[td.level_class];
         bool any = false;
-        for (int32_t i = 0; i < td.count && !any; ++i) any = needed[hc.cells[td.first + i]] != 0;
+        for (int32_t i = 0; i < td.count && !any; ++i) any = active[hc.cells[td.first + i]] != 0;
         if (any) m2l_tiles_part_h_.push_back(td);
     }
     n_m2l_tiles_part_ = static_cast<int>(m2l_tiles_part_h_.size());
+    m2l_tiles_part1_h_.clear();
+    m2l_tile_idx_part_h_.clear();
+    for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+        const HostM2lClass &hc = m2l_host_[lc];
+        const size_t start = m2l_tile_idx_part_h_.size();
+        for (size_t i = 0; i < hc.cells.size(); ++i)
+            if (needed[hc.cells[i]]) m2l_tile_idx_part_h_.push_back(static_cast<int32_t>(i));
+        for (size_t f = start; f < m2l_tile_idx_part_h_.size(); f += kM2lTile) {
+            M2lTileDesc td;
+            std::memset(&td, 0, sizeof td);
+            td.level_class = static_cast<int32_t>(lc);
+            td.first = static_cast<int32_t>(f);
+            td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, m2l_tile_idx_part_h_.size() - f));
+            td.pad = 1; // indirect
+            m2l_tiles_part1_h_.push_back(td);
+        }
+    }
+    // P2L jobs of owned cells
+    std::vector<int32_t> xc, xruns;
+    std::vector<int64_t> xptr(1, 0);
+    for (int32_t c : x_cells_) {
+        if (!active[c]) continue;
+        xc.push_back(c);
+        for (int64_t r = x_runs_.ptr[c]; r < x_runs_.ptr[c + 1]; ++r) {
+            xruns.push_back(x_runs_.idx[2 * r]);
+            xruns.push_back(x_runs_.idx[2 * r + 1]);
+        }
+        xptr.push_back(static_cast<int64_t>(xruns.size() / 2));
+    }
+    n_x_jobs_part_ = static_cast<int>(xc.size());
     // owned targets: one contiguous range of the sorted sources
     const int64_t pb = lb < le ? t.pt_begin[src_leaves_[lb]] : 0;
     const int64_t pe = lb < le ? t.pt_end[src_leaves_[le - 1]] : 0;
@@ -1134,6 +1182,11 @@ int FmmTree::set_partition(int rank, int world) {
 
     HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
     CHK(dupload(&d_m2l_tiles_part_, m2l_tiles_part_h_));
+    CHK(dupload(&d_m2l_tiles_part1_, m2l_tiles_part1_h_));
+    CHK(dupload(&d_m2l_tile_idx_part_, m2l_tile_idx_part_h_));
+    CHK(dupload(&d_x_cells_part_, xc));
+    CHK(dupload(&d_x_job_run_ptr_part_, xptr));
+    CHK(dupload(&d_x_runs_part_, xruns));
     TargetSet &ts = part_targets_;
     ts.m = pe - pb;
     for (int a = 0; a < 3; ++a) ts.xyz_ptr[a] = src_ptr_[a] + pb;

@@ -150,7 +150,9 @@ class FmmTree {
     int part_rank_ = 0, part_world_ = 1;
     std::vector<int64_t> part_rows_;
     bool part_empty_ = false;
-    std::vector<M2lTileDesc> m2l_tiles_part_h_;
+    std::vector<M2lTileDesc> m2l_tiles_part_h_;   // partition: stage-2 tiles (contain an owned target)
+    std::vector<M2lTileDesc> m2l_tiles_part1_h_;  // partition: compact stage-1 tiles over the needed sources
+    std::vector<int32_t> m2l_tile_idx_part_h_;    // their class positions
 
     // ---- device state
     hipStream_t stream_ = nullptr, stream2_ = nullptr;
@@ -186,7 +188,10 @@ class FmmTree {
     DevBuf<int32_t> d_u_runs_, d_x_runs_, d_w_idx_, d_x_cells_;
     DevBuf<int64_t> d_x_job_run_ptr_;
     DevBuf<M2lClass> d_m2l_classes_;
-    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles_part_;
+    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles_part_, d_m2l_tiles_part1_;
+    DevBuf<int32_t> d_m2l_tile_idx_part_, d_x_cells_part_, d_x_runs_part_;
+    DevBuf<int64_t> d_x_job_run_ptr_part_;
+    int n_x_jobs_part_ = 0;
     DevBuf<uint16_t> d_m2l_qlist_;
     int n_m2l_tiles_part_ = 0;
     DevBuf<uint8_t> d_active_;
