@@ -923,6 +923,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
         for (int g = 0; g < NG16; ++g) acc[tg][g] = 0.0;
 
     const int bk = lane >> 4, bj = lane & 3; // B layout (k, j); the block index is broadcast
+    const bool wave_live = wave * 16 < tile.count;
     const int n_steps = (zb1 - zb0) * nq;
     // epilogue coordinates: D[b][i][j] at lane 16 i + 4 b + j = OUT[cell 4 tg + j][col0 + 16 g + 4 b + i]
     const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
@@ -972,29 +973,32 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
             if (qcnt == 0 && zb + 1 < zb1) stage_cols(zb + 1, (zb + 1 - zb0) & 1);
             if (qcnt == nq - 2) stage_slots((zb - zb0) & 1);
         }
-        double bq[4][4];
+        if (wave_live) { // a wave without cells (short tile) only helps with the DMA and the barriers
+            double bq[4][4];
 #pragma unroll
-        for (int tg = 0; tg < 4; ++tg)
+            for (int tg = 0; tg < 4; ++tg)
 #pragma unroll
-            for (int eh = 0; eh < 2; ++eh) {
-                const double2 v = *reinterpret_cast<const double2 *>(ct + ((tg * 2 + eh) * 16) * 2);
-                bq[tg][2 * eh] = v.x;
-                bq[tg][2 * eh + 1] = v.y;
-            }
+                for (int eh = 0; eh < 2; ++eh) {
+                    const double2 v = *reinterpret_cast<const double2 *>(ct + ((tg * 2 + eh) * 16) * 2);
+                    bq[tg][2 * eh] = v.x;
+                    bq[tg][2 * eh + 1] = v.y;
+                }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
-            for (int g = 0; g < NG16; ++g) {
-                const double a = op[(e * NG16 + g) * 64];
+                for (int g = 0; g < NG16; ++g) {
+                    const double a = op[(e * NG16 + g) * 64];
 #pragma unroll
-                for (int tg = 0; tg < 4; ++tg) acc[tg][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bq[tg][e], acc[tg][g], 0, 0, 0);
+                    for (int tg = 0; tg < 4; ++tg)
+                        acc[tg][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bq[tg][e], acc[tg][g], 0, 0, 0);
+                }
             }
         }
         if (++qcnt == nq) { // a column block is complete: write it out, start the next one
             qcnt = 0;
             const int col0 = zb * kM2lS1Block + 16 * g16_0;
             ++zb;
-            if (STAGE == 1) {
+            if (STAGE == 1 && wave_live) {
                 // Scatter into the target slots, branch-free: entries without a destination (padding
                 // rows, absent targets, cells beyond the tile) go to a dump area behind the slot buffer.
                 // Measured: the epilogue is store-issue bound (about 75 cycles per dwordx2 store
@@ -1017,7 +1021,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                         *dst = acc[tg][g];
                     }
                 }
-            } else {
+            } else if (STAGE == 2) {
 #pragma unroll
                 for (int tg = 0; tg < 4; ++tg) {
                     const int tp = wave * 16 + 4 * tg + dj;
@@ -1034,8 +1038,11 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
 #pragma unroll
                 for (int g = 0; g < NG16; ++g) acc[tg][g] = 0.0;
             // the 4 * NG16 scatter stores issued after this step's DMA drain under the next block
+            // (a wave without cells stored nothing: it waits for its DMA as usual)
             if (STAGE == 1) {
-                wait_dma_keep_stores_and_barrier<4 * NG16>();
+                if (wave_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NG16 < 63 ? 4 * NG16 : 63) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
                 continue;
             }
         }

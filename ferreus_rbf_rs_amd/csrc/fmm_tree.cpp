@@ -235,6 +235,13 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
             return fail(BBFMM_DEVICE_ERROR, "no HIP device available (the BBFMM passes have no CPU fallback)");
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                prop.multiProcessorCount > 0)
+                n_cu_ = prop.multiProcessorCount;
+        }
         HIPCHK(hipStreamCreate(&stream_));
         HIPCHK(hipStreamCreate(&stream2_));
         HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
@@ -301,6 +308,31 @@ void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<doubl
 // ------------------------------------------------------------------ M2L tables
 // Folds the reference's symmetry permutations (bbfmm.rs:910-931,964-982) into stacked
 // per-octant-class operators; see device.hip "M2L".
+// One workgroup per CU runs at a time, so a launch of T equal tiles takes ceil(T / CUs) rounds.
+// When the last round is at most half full its tiles are halved (a workgroup whose upper four
+// waves hold no cells runs one wave per SIMD and takes about half the time): the tail costs half a
+// round instead of a whole one.  Direct (contiguous) tiles only.
+static void split_tile_tail(std::vector<M2lTileDesc> *tiles, int n_cu) {
+    const size_t T = tiles->size();
+    const size_t r = T % static_cast<size_t>(n_cu);
+    if (r == 0 || r > static_cast<size_t>(n_cu) / 2) return;
+    std::vector<M2lTileDesc> out(tiles->begin(), tiles->end() - static_cast<std::ptrdiff_t>(r));
+    for (size_t i = T - r; i < T; ++i) {
+        const M2lTileDesc td = (*tiles)[i];
+        if (td.pad != 0 || td.count <= kM2lTile / 2) {
+            out.push_back(td);
+            continue;
+        }
+        M2lTileDesc a = td, b = td;
+        a.count = kM2lTile / 2;
+        b.first = td.first + kM2lTile / 2;
+        b.count = td.count - kM2lTile / 2;
+        out.push_back(a);
+        out.push_back(b);
+    }
+    tiles->swap(out);
+}
+
 int FmmTree::build_m2l_tables() {
     const HostTree &t = tree_;
     const int d = d_, n = ops_.n, n_pad = round_up(n, 32);
@@ -599,6 +631,9 @@ int FmmTree::upload() {
     }
     CHK(dupload(&d_m2l_classes_, m2l_classes_h_));
     CHK(dupload(&d_m2l_tiles_, m2l_tiles_h_));
+    m2l_tiles2_h_ = m2l_tiles_h_;
+    split_tile_tail(&m2l_tiles2_h_, n_cu_);
+    CHK(dupload(&d_m2l_tiles2_, m2l_tiles2_h_));
     CHK(dupload(&d_m2l_qlist_, m2l_qlist_h_));
     std::vector<uint8_t> act(static_cast<size_t>(C), 1);
     CHK(dupload(&d_active_, act));
@@ -806,8 +841,8 @@ int FmmTree::downward(int k) {
                           d_cbuf_.p, cbuf_len_, stream_);
     phase_end(kPhM2L1);
     phase_begin();
-    launch_m2l_stage2(d_m2l_classes_.p, have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles_.p,
-                      have_part_ ? n_m2l_tiles_part_ : n_all, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_,
+    launch_m2l_stage2(d_m2l_classes_.p, have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles2_.p,
+                      have_part_ ? n_m2l_tiles_part_ : static_cast<int>(m2l_tiles2_h_.size()), cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_,
                       d_m2l_qlist_.p, d_L_.p, stream_);
     phase_end(kPhM2L2);
     phase_begin();
@@ -1141,6 +1176,7 @@ int FmmTree::set_partition(int rank, int world) {
         for (int32_t i = 0; i < td.count && !any; ++i) any = active[hc.cells[td.first + i]] != 0;
         if (any) m2l_tiles_part_h_.push_back(td);
     }
+    split_tile_tail(&m2l_tiles_part_h_, n_cu_);
     n_m2l_tiles_part_ = static_cast<int>(m2l_tiles_part_h_.size());
     m2l_tiles_part1_h_.clear();
     m2l_tile_idx_part_h_.clear();

@@ -145,6 +145,8 @@ class FmmTree {
     std::vector<uint16_t> m2l_qlist_h_;
     int64_t cbuf_len_ = 0;
     double m2l_flops_k1_ = 0;
+    int n_cu_ = 256;      // compute units of the device (tail splitting of the tile lists)
+    std::vector<M2lTileDesc> m2l_tiles2_h_; // stage-2 launch list: m2l_tiles_h_ with a split tail
     int m2l_slot_t_ = 1; // most transfer vectors any stage-1 column block touches
     // partition
     int part_rank_ = 0, part_world_ = 1;
@@ -188,7 +190,7 @@ class FmmTree {
     DevBuf<int32_t> d_u_runs_, d_x_runs_, d_w_idx_, d_x_cells_;
     DevBuf<int64_t> d_x_job_run_ptr_;
     DevBuf<M2lClass> d_m2l_classes_;
-    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles_part_, d_m2l_tiles_part1_;
+    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles2_, d_m2l_tiles_part_, d_m2l_tiles_part1_;
     DevBuf<int32_t> d_m2l_tile_idx_part_, d_x_cells_part_, d_x_runs_part_;
     DevBuf<int64_t> d_x_job_run_ptr_part_;
     int n_x_jobs_part_ = 0;
