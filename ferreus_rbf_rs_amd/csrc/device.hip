@@ -151,10 +151,10 @@ __device__ inline void cheb_S_reg(double x, const double *__restrict__ polyn, do
 // LDS slice; then lane q owns the node pairs (i1, i2) = q and keeps the P sums over i0 in
 // registers, so a point costs two private LDS reads plus P broadcast reads per lane.
 constexpr int P2M_WAVES = 4;
-constexpr int P2M_PTS = 32;
-constexpr int P2M_KB = 2;
+constexpr int P2M_PTS = 64; // measured at 10M points, K = 1: 1.12 ms against 1.38 ms with 32
+                            // (one batch covers a 38-point leaf) and 1.55 ms with two rhs slots
 
-template <int P, int D>
+template <int P, int D, int P2M_KB>
 __global__ __launch_bounds__(64 * P2M_WAVES) void p2m_kernel(const DevCheb *__restrict__ chp, int n_leaves, Xyz src,
                                                              const double *__restrict__ ws, int64_t N, int K,
                                                              int64_t C, const int32_t *__restrict__ leaf_cells,
@@ -346,6 +346,139 @@ __global__ __launch_bounds__(256) void l2l_kernel(const DevCheb *__restrict__ ch
         }
         double *Lc = L + ((int64_t)k * C + c) * n_pad;
         for (int I = tid; I < n; I += 256) Lc[I] += in[I];
+    }
+}
+
+// ------------------------------------------------------------------ M2M / L2L, 3-D fast path
+// One wave per cell, order P a template parameter.  A lane owns "pencils" of P entries along one
+// axis in registers, so a 1-D transfer is P*P register FMAs against a wave-uniform P x P block
+// (scalar loads); between the axes the vector is transposed through a wave-private LDS slice (no
+// workgroup barrier).  Layout of a vector: index (i0*P + i1)*P + i2.
+template <int P, bool FORWARD>
+__device__ inline void pencil_apply(double (&v)[P], const double *__restrict__ xf) {
+    double o[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) s += (FORWARD ? xf[k * P + j] : xf[j * P + k]) * v[k];
+        o[j] = s;
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) v[j] = o[j];
+}
+
+// in: global vector of the source cell; buf: wave-private LDS (P^3 doubles); on return buf holds
+// the transferred vector.  oct: octant of the child (bit a <-> axis a, chebyshev.rs:183-192).
+template <int P, bool FORWARD>
+__device__ inline void transfer3_wave(const double *__restrict__ in, double *buf, const double *__restrict__ xfer,
+                                      int oct, int lane) {
+    constexpr int PP = P * P, NPEN = (PP + 63) / 64;
+    const double *x0 = xfer + ((oct >> 0) & 1) * PP, *x1 = xfer + ((oct >> 1) & 1) * PP,
+                 *x2 = xfer + ((oct >> 2) & 1) * PP;
+    // axis 0: pencil q = (i1, i2), entries at i0 * PP + q (coalesced global reads)
+#pragma unroll
+    for (int ps = 0; ps < NPEN; ++ps) {
+        const int q = lane + 64 * ps;
+        if (q < PP) {
+            double v[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] = in[i * PP + q];
+            pencil_apply<P, FORWARD>(v, x0);
+#pragma unroll
+            for (int i = 0; i < P; ++i) buf[i * PP + q] = v[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // axis 1: pencil r = (i0, i2), entries at i0 * PP + i1 * P + i2
+#pragma unroll
+    for (int ps = 0; ps < NPEN; ++ps) {
+        const int r = lane + 64 * ps;
+        if (r < PP) {
+            const int i0 = r / P, i2 = r - i0 * P;
+            double v[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] = buf[i0 * PP + i * P + i2];
+            pencil_apply<P, FORWARD>(v, x1);
+#pragma unroll
+            for (int i = 0; i < P; ++i) buf[i0 * PP + i * P + i2] = v[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // axis 2: pencil s = (i0, i1), entries at s * P + i2
+#pragma unroll
+    for (int ps = 0; ps < NPEN; ++ps) {
+        const int sidx = lane + 64 * ps;
+        if (sidx < PP) {
+            double v[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) v[i] = buf[sidx * P + i];
+            pencil_apply<P, FORWARD>(v, x2);
+#pragma unroll
+            for (int i = 0; i < P; ++i) buf[sidx * P + i] = v[i];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr int XFER_WAVES = 4;
+
+// local_to_local, one wave per child cell: L_child += T_child^T L_parent (bbfmm.rs:1051-1086)
+template <int P>
+__global__ __launch_bounds__(64 * XFER_WAVES) void l2l3_kernel(const DevCheb *__restrict__ chp, int K, int64_t C,
+                                                               const int32_t *__restrict__ cells, int n_cells,
+                                                               const int32_t *__restrict__ parent,
+                                                               const int32_t *__restrict__ octant,
+                                                               const uint8_t *__restrict__ active,
+                                                               double *__restrict__ L) {
+    constexpr int N = P * P * P;
+    __shared__ double s_buf[XFER_WAVES][N];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int job = blockIdx.x * XFER_WAVES + wave;
+    if (job >= n_cells) return;
+    const int c = __builtin_amdgcn_readfirstlane(cells[job]);
+    if (active && !active[c]) return;
+    const int Pc = __builtin_amdgcn_readfirstlane(parent[c]);
+    if (Pc < 0) return;
+    const int oct = __builtin_amdgcn_readfirstlane(octant[c]);
+    const int n_pad = chp->n_pad;
+    for (int k = 0; k < K; ++k) {
+        transfer3_wave<P, false>(L + ((int64_t)k * C + Pc) * n_pad, s_buf[wave], chp->xfer, oct, lane);
+        double *Lc = L + ((int64_t)k * C + c) * n_pad;
+        for (int I = lane; I < N; I += 64) Lc[I] += s_buf[wave][I];
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// multipole_to_multipole, one workgroup per parent, one wave per child:
+// M_parent += sum_children T_child M_child (bbfmm.rs:742-772)
+template <int P>
+__global__ __launch_bounds__(512) void m2m3_kernel(const DevCheb *__restrict__ chp, int K, int64_t C,
+                                                   const int32_t *__restrict__ parents,
+                                                   const int64_t *__restrict__ child_ptr,
+                                                   const int32_t *__restrict__ child_idx,
+                                                   const int32_t *__restrict__ octant, double *__restrict__ M) {
+    constexpr int N = P * P * P;
+    __shared__ double s_buf[8][N];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int Pc = parents[blockIdx.x];
+    const int64_t c0 = child_ptr[Pc];
+    const int n_ch = (int)(child_ptr[Pc + 1] - c0); // <= 8 in 3-D
+    const int n_pad = chp->n_pad;
+    for (int k = 0; k < K; ++k) {
+        if (wave < n_ch) {
+            const int ch = __builtin_amdgcn_readfirstlane(child_idx[c0 + wave]);
+            const int oct = __builtin_amdgcn_readfirstlane(octant[ch]);
+            transfer3_wave<P, true>(M + ((int64_t)k * C + ch) * n_pad, s_buf[wave], chp->xfer, oct, lane);
+        }
+        __syncthreads();
+        double *Mp = M + ((int64_t)k * C + Pc) * n_pad;
+        for (int I = threadIdx.x; I < N; I += 512) {
+            double s = 0.0;
+            for (int w = 0; w < n_ch; ++w) s += s_buf[w][I];
+            Mp[I] += s;
+        }
+        __syncthreads();
     }
 }
 
@@ -1058,8 +1191,12 @@ static void p2m_launch_pd(const ChebRef &ch, Xyz src, const double *w_sorted, in
                           const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin, const int32_t *pt_end,
                           const double *centers, const double *lengths, double *M, hipStream_t s) {
     const int blocks = (n_leaves + P2M_WAVES - 1) / P2M_WAVES;
-    hipLaunchKernelGGL((p2m_kernel<P, D>), dim3(blocks), dim3(64 * P2M_WAVES), 0, s, ch.dev, n_leaves, src, w_sorted, N,
-                       K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
+    if (K == 1)
+        hipLaunchKernelGGL((p2m_kernel<P, D, 1>), dim3(blocks), dim3(64 * P2M_WAVES), 0, s, ch.dev, n_leaves, src,
+                           w_sorted, N, K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
+    else
+        hipLaunchKernelGGL((p2m_kernel<P, D, 2>), dim3(blocks), dim3(64 * P2M_WAVES), 0, s, ch.dev, n_leaves, src,
+                           w_sorted, N, K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
 }
 
 void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w_sorted, int64_t N, int K, int64_t C,
@@ -1092,6 +1229,17 @@ void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w
 void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents, const int64_t *child_ptr,
                 const int32_t *child_idx, const int32_t *octant, double *M, hipStream_t s) {
     if (n_parents == 0) return;
+#define M2M3_CASE(PP)                                                                                              \
+    case PP:                                                                                                       \
+        hipLaunchKernelGGL((m2m3_kernel<PP>), dim3(n_parents), dim3(512), 0, s, ch.dev, K, C, parents, child_ptr,  \
+                           child_idx, octant, M);                                                                  \
+        return;
+    if (ch.d == 3) switch (ch.p) { // wave-per-child register kernels (8 x P^3 doubles of LDS)
+            M2M3_CASE(2) M2M3_CASE(3) M2M3_CASE(4) M2M3_CASE(5) M2M3_CASE(6) M2M3_CASE(7) M2M3_CASE(8) M2M3_CASE(9)
+            M2M3_CASE(10)
+        default: break;
+        }
+#undef M2M3_CASE
     const size_t lds = sizeof(double) * (3 * (size_t)ch.n + 2 * ch.p * ch.p);
     hipLaunchKernelGGL(m2m_kernel, dim3(n_parents), dim3(256), lds, s, ch.dev, K, C, parents, child_ptr, child_idx,
                        octant, M);
@@ -1100,6 +1248,17 @@ void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int
 void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_cells, const int32_t *parent,
                 const int32_t *octant, const uint8_t *active, double *L, hipStream_t s) {
     if (n_cells == 0) return;
+#define L2L3_CASE(PP)                                                                                              \
+    case PP:                                                                                                       \
+        hipLaunchKernelGGL((l2l3_kernel<PP>), dim3((n_cells + XFER_WAVES - 1) / XFER_WAVES), dim3(64 * XFER_WAVES),  \
+                           0, s, ch.dev, K, C, cells, n_cells, parent, octant, active, L);                         \
+        return;
+    if (ch.d == 3) switch (ch.p) {
+            L2L3_CASE(2) L2L3_CASE(3) L2L3_CASE(4) L2L3_CASE(5) L2L3_CASE(6) L2L3_CASE(7) L2L3_CASE(8) L2L3_CASE(9)
+            L2L3_CASE(10) L2L3_CASE(11) L2L3_CASE(12)
+        default: break;
+        }
+#undef L2L3_CASE
     const size_t lds = sizeof(double) * (2 * (size_t)ch.n + 2 * ch.p * ch.p);
     hipLaunchKernelGGL(l2l_kernel, dim3(n_cells), dim3(256), lds, s, ch.dev, K, C, cells, parent, octant, active, L);
 }
