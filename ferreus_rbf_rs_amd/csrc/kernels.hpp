@@ -71,9 +71,12 @@ inline KernelSpec make_kernel_spec(int id, double base_range, double total_sill)
 // v_rcp_f64 seeds refined by Goldschmidt / Newton steps built from FMAs (1-2 ulp; the correctly
 // rounded library sqrt and division are 24-30 instructions each; measured 96 -> ~56 cycles per
 // wave for sqrt on MI355X).  x >= 0 always (sums of squares).
+// x = 0 (a point against itself): only the argument of rsq is clamped (to 1e-300), so the seed
+// stays finite and g = x * y = 0 carries an exact zero through the refinement; the select that
+// would otherwise guard 0 * inf costs three instructions per pair.
 BBFMM_HD inline void bb_sqrt_rsqrt(double x, double *s, double *rs) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double y = __builtin_amdgcn_rsq(x);
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
     double g = x * y, h = 0.5 * y;
     double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
@@ -82,7 +85,7 @@ BBFMM_HD inline void bb_sqrt_rsqrt(double x, double *s, double *rs) {
     g = fma(d, h, g);          // sqrt(x)
     r = fma(-h, g, 0.5);
     h = fma(h, r, h);          // 1 / (2 sqrt(x))
-    *s = x > 0.0 ? g : 0.0;    // rsq(0) = inf would give NaN
+    *s = g;
     *rs = h + h;
 #else
     *s = sqrt(x);
@@ -91,14 +94,13 @@ BBFMM_HD inline void bb_sqrt_rsqrt(double x, double *s, double *rs) {
 }
 BBFMM_HD inline double bb_sqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double y = __builtin_amdgcn_rsq(x);
+    const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
     double g = x * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);
     h = fma(h, r, h);
     const double d = fma(-g, g, x);
-    g = fma(d, h, g);
-    return x > 0.0 ? g : 0.0; // rsq(0) = inf would give NaN
+    return fma(d, h, g);
 #else
     return sqrt(x);
 #endif
