@@ -401,10 +401,34 @@ int FmmTree::build_m2l_tables() {
         }
         const size_t first_class = m2l_host_.size();
         m2l_host_.resize(first_class + ncls);
-        for (int64_t c = t.level_ptr[level]; c < t.level_ptr[level + 1]; ++c) {
-            auto &hc = m2l_host_[first_class + t.octant[c]];
-            pos_in_class[c] = static_cast<int32_t>(hc.cells.size());
-            hc.cells.push_back(static_cast<int32_t>(c));
+        for (int64_t c = t.level_ptr[level]; c < t.level_ptr[level + 1]; ++c)
+            m2l_host_[first_class + t.octant[c]].cells.push_back(static_cast<int32_t>(c));
+        // Order the cells of a class by their V-list pattern (complete lists first, equal patterns
+        // together, Morton order inside a pattern): the 128-cell tiles then hold cells that miss
+        // the same transfer vectors (domain boundary, coarse neighbours), which lets stage 2 skip
+        // the contraction steps no cell of a tile needs.
+        {
+            std::vector<uint64_t> key(static_cast<size_t>(t.level_ptr[level + 1] - t.level_ptr[level]));
+            const int64_t c_lo = t.level_ptr[level];
+            for (int64_t c = c_lo; c < t.level_ptr[level + 1]; ++c) {
+                uint64_t hsh = 1469598103934665603ull;
+                const int64_t nv = t.v.ptr[c + 1] - t.v.ptr[c];
+                uint64_t bits[6] = {0, 0, 0, 0, 0, 0}; // presence over the 7^d transfer vectors
+                for (int64_t q = t.v.ptr[c]; q < t.v.ptr[c + 1]; ++q) {
+                    const int tv = t.v_tidx[q];
+                    if (tv >= 0 && tv < 384) bits[tv >> 6] |= 1ull << (tv & 63);
+                }
+                for (uint64_t b : bits) hsh = (hsh ^ b) * 1099511628211ull;
+                // complete lists first; the hash only has to keep equal patterns together
+                key[static_cast<size_t>(c - c_lo)] = (static_cast<uint64_t>(1023 - std::min<int64_t>(nv, 1023)) << 54) | (hsh >> 10);
+            }
+            for (int o = 0; o < ncls; ++o) {
+                auto &cells = m2l_host_[first_class + o].cells;
+                std::stable_sort(cells.begin(), cells.end(), [&](int32_t a, int32_t b) {
+                    return key[static_cast<size_t>(a - c_lo)] < key[static_cast<size_t>(b - c_lo)];
+                });
+                for (size_t i = 0; i < cells.size(); ++i) pos_in_class[cells[i]] = static_cast<int32_t>(i);
+            }
         }
         for (int o = 0; o < ncls; ++o) {
             HostM2lClass &hc = m2l_host_[first_class + o];
