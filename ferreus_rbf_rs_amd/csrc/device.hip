@@ -1009,13 +1009,24 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     constexpr int OP_DOUBLES = OP_CHUNKS * 128;
     constexpr int BUF = OP_DOUBLES + 2048;
 
+    // Operator image in LDS.  The NG16 column groups are taken as NP pairs (+ one single group when
+    // NG16 is odd).  A pair chunk (e, pr) is [k][p = 4b + i][2]: lane 16k + p holds columns
+    // 32 pr + 2p and + 1 of row 4k + e, fetched as one 16-byte DMA granule and read back with one
+    // ds_read_b128 feeding the MFMAs of groups 2 pr and 2 pr + 1.  An accumulator pair of a lane is
+    // thus two ADJACENT output columns, which the epilogues store as 16 bytes (the stage-1 scatter
+    // is bound by the number of store instructions).  The single group keeps [e][k][16 columns].
+    constexpr int NP = NG16 / 2, NS = NG16 & 1;
     unsigned voff[NCH];
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
         const int c = wave + 8 * i;
-        const int f = 2 * c + (lane >> 5), r = lane & 31, k = r >> 3, pair = r & 7;
-        const int e = f / NG16, ng = f - e * NG16;
-        voff[i] = (unsigned)(((4 * k + e) * ld + 16 * ng + 2 * pair) * 8);
+        if (c < 4 * NP) {
+            const int e = c / NP, pr = c - e * NP, k = lane >> 4, p = lane & 15;
+            voff[i] = (unsigned)(((4 * k + e) * ld + 32 * pr + 2 * p) * 8);
+        } else {
+            const int e = 2 * (c - 4 * NP) + (lane >> 5), r = lane & 31, k = r >> 3, pair = r & 7;
+            voff[i] = (unsigned)(((4 * k + e) * ld + 32 * NP + 2 * pair) * 8);
+        }
     }
     // position of the tile's cell `pos` in its class list (a partition's source tiles are compact
     // lists of class positions, tile.pad != 0)
@@ -1100,6 +1111,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     int qcnt = 0, zb = zb0;
     for (int sidx = 0; sidx < n_steps; ++sidx) {
         const double *op = lds + (sidx & 1) * BUF + lane;
+        const double2 *op2 = reinterpret_cast<const double2 *>(lds + (sidx & 1) * BUF) + lane;
         const double *ct = lds + (sidx & 1) * BUF + OP_DOUBLES + wave * 256 + (bk * 4 + bj) * 2;
         if (sidx + 1 < n_steps) stage(sidx + 1, (sidx + 1) & 1); // streams in under the MFMAs below
         if (STAGE == 1) {
@@ -1119,11 +1131,20 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
 #pragma unroll
-                for (int g = 0; g < NG16; ++g) {
-                    const double a = op[(e * NG16 + g) * 64];
+                for (int pr = 0; pr < NP; ++pr) {
+                    const double2 a = op2[(e * NP + pr) * 64];
+#pragma unroll
+                    for (int tg = 0; tg < 4; ++tg) {
+                        acc[tg][2 * pr] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.x, bq[tg][e], acc[tg][2 * pr], 0, 0, 0);
+                        acc[tg][2 * pr + 1] =
+                            __builtin_amdgcn_mfma_f64_4x4x4f64(a.y, bq[tg][e], acc[tg][2 * pr + 1], 0, 0, 0);
+                    }
+                }
+                if (NS) {
+                    const double a = op[4 * NP * 128 + e * 64];
 #pragma unroll
                     for (int tg = 0; tg < 4; ++tg)
-                        acc[tg][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bq[tg][e], acc[tg][g], 0, 0, 0);
+                        acc[tg][NG16 - 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(a, bq[tg][e], acc[tg][NG16 - 1], 0, 0, 0);
                 }
             }
         }
@@ -1134,24 +1155,32 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
             if (STAGE == 1 && wave_live) {
                 // Scatter into the target slots, branch-free: entries without a destination (padding
                 // rows, absent targets, cells beyond the tile) go to a dump area behind the slot buffer.
-                // Measured: the epilogue is store-issue bound (about 75 cycles per dwordx2 store
-                // instruction and CU, 2.7 of the 18 ms of stage 1 at 10M points), whatever the address
-                // pattern and however the wait after it is relaxed.
+                // Measured: the epilogue is store-issue bound (about 75 cycles per store instruction
+                // and CU whatever its width, the address pattern or the wait after it): adjacent
+                // column pairs leave as 16-byte stores, half the instructions of 8-byte ones.
                 double *cb = out + (int64_t)kr * out_len;
-                double *dump = cb + (out_len - 64) + lane;
-                int pk[NG16];
+                double *dump = cb + (out_len - 128) + 2 * lane; // 16-byte aligned (out_len is even)
+                const int32_t *auxb = aux + ((zb - 1 - zb0) & 1) * AUX;
+                int pk[NP + NS];
 #pragma unroll
-                for (int g = 0; g < NG16; ++g) pk[g] = aux[((zb - 1 - zb0) & 1) * AUX + 16 * g + 4 * db + di];
+                for (int pr = 0; pr < NP; ++pr) pk[pr] = auxb[32 * pr + 2 * (4 * db + di)]; // the even column
+                if (NS) pk[NP] = auxb[32 * NP + 4 * db + di];
 #pragma unroll
                 for (int tg = 0; tg < 4; ++tg) {
                     const bool spv = wave * 16 + 4 * tg + dj < tile.count;
                     const int32_t *srow = slds + (4 * tg + dj) * slot_t;
 #pragma unroll
-                    for (int g = 0; g < NG16; ++g) {
-                        const int sl = srow[max(pk[g] >> 24, 0)];
-                        const int okm = (spv ? -1 : 0) & ~(pk[g] | sl); // sign bit set: valid cell, row, slot
-                        double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[g] & 0xffffff) : dump;
-                        *dst = acc[tg][g];
+                    for (int pr = 0; pr < NP; ++pr) {
+                        const int sl = srow[max(pk[pr] >> 24, 0)];
+                        const int okm = (spv ? -1 : 0) & ~(pk[pr] | sl); // sign bit set: valid cell, row, slot
+                        double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[pr] & 0xffffff) : dump;
+                        *reinterpret_cast<double2 *>(dst) = make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
+                    }
+                    if (NS) {
+                        const int sl = srow[max(pk[NP] >> 24, 0)];
+                        const int okm = (spv ? -1 : 0) & ~(pk[NP] | sl);
+                        double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[NP] & 0xffffff) : dump;
+                        *dst = acc[tg][NG16 - 1];
                     }
                 }
             } else if (STAGE == 2) {
@@ -1160,9 +1189,12 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                     const int tp = wave * 16 + 4 * tg + dj;
                     if (tp < tile.count) {
                         const int cell = cls.cells[tile.first + tp];
-                        double *Lc = out + ((int64_t)kr * C + cell) * n_pad + col0 + 4 * db + di;
+                        double *Lc = out + ((int64_t)kr * C + cell) * n_pad + col0;
 #pragma unroll
-                        for (int g = 0; g < NG16; ++g) Lc[16 * g] = acc[tg][g];
+                        for (int pr = 0; pr < NP; ++pr)
+                            *reinterpret_cast<double2 *>(Lc + 32 * pr + 2 * (4 * db + di)) =
+                                make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
+                        if (NS) Lc[32 * NP + 4 * db + di] = acc[tg][NG16 - 1];
                     }
                 }
             }
@@ -1170,10 +1202,10 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
             for (int tg = 0; tg < 4; ++tg)
 #pragma unroll
                 for (int g = 0; g < NG16; ++g) acc[tg][g] = 0.0;
-            // the 4 * NG16 scatter stores issued after this step's DMA drain under the next block
+            // the 4 * (NP + NS) scatter stores issued after this step's DMA drain under the next block
             // (a wave without cells stored nothing: it waits for its DMA as usual)
             if (STAGE == 1) {
-                if (wave_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NG16 < 63 ? 4 * NG16 : 63) : "memory");
+                if (wave_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NP + NS) < 63 ? 4 * (NP + NS) : 63) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 continue;

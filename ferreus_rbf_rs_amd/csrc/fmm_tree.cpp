@@ -276,7 +276,7 @@ void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<doubl
     for (int tv : hc.src_tv) {
         const M2lOperator &op = lops[ops_.ref_lookup[tv]];
         row_src.push_back(RowSrc{&op, &ops_.invperm[static_cast<size_t>(ops_.perm_lookup[tv]) * n], row});
-        row += op.rank;
+        row += round_up(op.rank, 2);
     }
     // c[kk] = sum_m Vt[kk][invperm[m]] * M_V[m]   (bbfmm.rs:924-930 folded)
     parallel_for(n, 8, [&](int64_t m) {
@@ -438,7 +438,9 @@ int FmmTree::build_m2l_tables() {
             hc.k_pad = k_pad[o];
             // stage 1 tall operator rows
             hc.n_rows = 0;
-            for (int tv : src_list[o]) hc.n_rows += rank_of(tv);
+            // every transfer vector's rows start at an even stacked row (the stage-1 scatter stores
+            // pairs of adjacent rows as 16 bytes)
+            for (int tv : src_list[o]) hc.n_rows += round_up(rank_of(tv), 2);
             hc.r_pad16 = round_up(std::max(hc.n_rows, 1), kM2lS1Block);
             hc.row_tpos.assign(hc.r_pad16, -1);
             hc.row_off.assign(hc.r_pad16, 0);
@@ -455,6 +457,7 @@ int FmmTree::build_m2l_tables() {
                     hc.row_tpos[row] = static_cast<int32_t>(pos);
                     hc.row_off[row] = base_off + kk;
                 }
+                row = round_up(row, 2); // the padding row keeps tpos -1 (never stored on its own)
             }
             // per column block: first transfer-vector position, and the packed row table
             const int n_blk = hc.r_pad16 / kM2lS1Block;
@@ -1328,6 +1331,7 @@ int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
         for (size_t pos = 0; pos < hc.cells.size(); ++pos) {
             const double *Mv = M + static_cast<size_t>(hc.cells[pos]) * n;
             for (int row = 0; row < hc.n_rows; ++row) {
+                if (hc.row_tpos[row] < 0) continue; // padding row
                 const int32_t slot = hc.cslot[pos * hc.n_t + hc.row_tpos[row]];
                 if (slot < 0) continue;
                 double s = 0.0;

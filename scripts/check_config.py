@@ -46,6 +46,8 @@ idx = np.random.default_rng(7).choice(N, a.samples, replace=False)
 ref = O.dense_sum(kid, a.base_range, a.total_sill, pts[idx], pts, w_h.T).T   # C/OpenMP dense rows
 err = np.abs(yh[:, idx] - ref).max() / np.abs(ref).max()
 s = tree.stats()
-print(json.dumps({"config": vars(a), "ms_per_matvec": ms, "matvecs_per_s": 1e3 / ms, "build_s": build,
+m2l_ms = (ph.get("M2L_stage1", 0) + ph.get("M2L_stage2", 0)) / (a.steps + 1)
+print(json.dumps({"config": vars(a), "ms_per_matvec": ms, "m2l_flops_k1": s.m2l_flops_k1, "v_pairs": s.n_v,
+                  "m2l_tflops_algorithmic": (s.m2l_flops_k1 * K / (m2l_ms * 1e-3) * 1e-12) if m2l_ms > 0 else None, "matvecs_per_s": 1e3 / ms, "build_s": build,
                   "rel_err_vs_dense_sampled": err, "depth": s.depth, "cells": s.n_cells, "leaves": s.n_leaves,
                   "phase_ms": {k: round(v / (a.steps + 1), 3) for k, v in ph.items() if v > 0}}))
