@@ -33,7 +33,8 @@ class OwnedRowsExchange:
         dist.all_gather(gathered, pad, group=group)
         all_rows = torch.stack(gathered)                       # world x m_max
         self.valid = all_rows.reshape(-1) >= 0
-        self.flat_rows = all_rows.reshape(-1)[self.valid]
+        self.valid_idx = torch.nonzero(self.valid).reshape(-1)     # once: no mask (= no sync) per step
+        self.flat_rows = all_rows.reshape(-1)[self.valid_idx]
         self.send = torch.zeros((k, self.m_max), dtype=torch.float64, device=device)
         self.recv = [torch.empty((k, self.m_max), dtype=torch.float64, device=device)
                      for _ in range(self.world)]
@@ -46,8 +47,8 @@ class OwnedRowsExchange:
 
     def exchange(self, out: torch.Tensor) -> torch.Tensor:
         """out: K x N with this rank's owned columns filled in; on return every column is."""
-        self.send[:, : self.rows.numel()] = out[:, self.rows]
+        self.send[:, : self.rows.numel()] = out.index_select(1, self.rows)
         dist.all_gather(self.recv, self.send, group=self.group)
         stacked = torch.stack(self.recv, dim=1).reshape(self.k, -1)   # K x (world*m_max)
-        out[:, self.flat_rows] = stacked[:, self.valid]
+        out.index_copy_(1, self.flat_rows, stacked.index_select(1, self.valid_idx))
         return out
