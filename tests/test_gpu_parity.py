@@ -218,3 +218,21 @@ def test_full_size_10m_properties():
     idx = np.random.default_rng(2).choice(n, 64, replace=False)
     yd = O.dense_sum(0, 1.0, 1.0, pts[idx], pts, w[0].cpu().numpy()[:, None])
     assert relerr(y[0].cpu().numpy()[idx][:, None], yd) < 1e-6
+
+
+@pytest.mark.parametrize("order", [2, 3, 4, 5, 6, 8, 9, 10, 11, 12])
+def test_every_order_3d(order):
+    """Every template instance of the order-specialised kernels (P2M, L2P, the 3-D M2M / L2L register
+    kernels up to 10 / 12 and the general ones beyond) and every M2L chunk plan (n_pad = 32 ... 1728)."""
+    n = 6000 if order <= 9 else 2500
+    pts = np.random.default_rng(100 + order).random((n, 3))
+    check(pts, nrhs=2 if order % 2 else 1, order=order, params=(60, O.COMPRESSION_ACA, 10.0 ** -min(order, 9), 1024),
+          dense_tol=5.0 * 10.0 ** -min(order - 1, 6), seed=order)
+
+
+@pytest.mark.parametrize("d,order", [(1, 4), (1, 16), (2, 3), (2, 7), (2, 12), (2, 16)])
+def test_orders_1d_2d(d, order):
+    n = 3000
+    pts = np.random.default_rng(200 + 10 * d + order).random((n, d))
+    check(pts, nrhs=1, order=order, params=(40, O.COMPRESSION_ACA, 1e-8, 1024),
+          dense_tol=5.0 * 10.0 ** -min(order - 1, 6), seed=order + d)
