@@ -242,7 +242,7 @@ __global__ __launch_bounds__(64 * P2M_WAVES) void p2m_kernel(const DevCheb *__re
                     if (k0 + kk < K) {
                         double *Mc = M + ((int64_t)(k0 + kk) * C + cell) * n_pad + q;
 #pragma unroll
-                        for (int i0 = 0; i0 < P; ++i0) Mc[i0 * NPAIR] += acc[ps][kk][i0];
+                        for (int i0 = 0; i0 < P; ++i0) Mc[i0 * NPAIR] = acc[ps][kk][i0]; // a leaf is written once
                     }
                 }
             }
@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void m2m_kernel(const DevCheb *__restrict__ ch
         }
         __syncthreads();
         double *Mp = M + ((int64_t)k * C + P) * n_pad;
-        for (int I = tid; I < n; I += 256) Mp[I] += acc[I];
+        for (int I = tid; I < n; I += 256) Mp[I] = acc[I]; // a parent is written once
         __syncthreads();
     }
 }
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512) void m2m3_kernel(const DevCheb *__restrict__ c
         for (int I = threadIdx.x; I < N; I += 512) {
             double s = 0.0;
             for (int w = 0; w < n_ch; ++w) s += s_buf[w][I];
-            Mp[I] += s;
+            Mp[I] = s; // a parent is written once
         }
         __syncthreads();
     }

@@ -835,7 +835,8 @@ int FmmTree::ensure_pinned(size_t n) {
 int FmmTree::upward(int k) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
-    HIPCHK(hipMemsetAsync(d_M_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_)); // 619-624
+    // reset_multipole_coefficients (bbfmm.rs:619-624): M is zero-initialised once; P2M and M2M assign
+    // every leaf with sources and every parent, the other entries are never written.
     phase_begin();
     launch_p2m(cheb_, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_src_leaves_.p, static_cast<int>(src_leaves_.size()),
                d_pt_begin_.p, d_pt_end_.p, d_centers_.p, d_lengths_.p, d_M_.p, stream_);
@@ -854,7 +855,9 @@ int FmmTree::upward(int k) {
 int FmmTree::downward(int k) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
-    HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_)); // 627-632
+    // reset_local_coefficients (bbfmm.rs:627-632): tiles without any V-list entry are not written by
+    // stage 2, and P2L / L2L add onto L
+    HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_));
     // a partition runs stage 1 on compact tiles of the sources its targets need, stage 2 on the
     // tiles that hold an owned target, P2L on owned cells
     const int n_all = static_cast<int>(m2l_tiles_h_.size());
