@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     // lists of class positions, tile.pad != 0)
     auto cell_p = [&](int pos) {
         const int q = pos < tile.count ? pos : 0;
-        return (STAGE == 1 && tile.pad) ? tile_idx[tile.first + q] : tile.first + q;
+        return tile.pad ? tile_idx[tile.first + q] : tile.first + q;
     };
     // IN tile: chunk h of this wave covers tg = 2h + (lane>>5), eh = (lane>>4)&1, k = (lane>>2)&3, j = lane&3
     const double *cptr[2];
@@ -1188,7 +1188,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                 for (int tg = 0; tg < 4; ++tg) {
                     const int tp = wave * 16 + 4 * tg + dj;
                     if (tp < tile.count) {
-                        const int cell = cls.cells[tile.first + tp];
+                        const int cell = cls.cells[cell_p(tp)];
                         double *Lc = out + ((int64_t)kr * C + cell) * n_pad + col0;
 #pragma unroll
                         for (int pr = 0; pr < NP; ++pr)
@@ -1503,10 +1503,11 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
 }
 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
-void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int K, int64_t C,
-                       const double *cbuf, int64_t cbuf_len, const uint16_t *qlist, double *L, hipStream_t s) {
+void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
+                       int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
+                       double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, nullptr, s);
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
 }
 
 // ------------------------------------------------------------------ MFMA self test

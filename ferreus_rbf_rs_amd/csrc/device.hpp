@@ -90,9 +90,9 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf,
                        int64_t cbuf_len, hipStream_t s);
-void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad,
-                       int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
-                       double *L, hipStream_t s);
+void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
+                       int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
+                       const uint16_t *qlist, double *L, hipStream_t s);
 
 // Direct (kernel-evaluating) interactions.  Targets are sorted by leaf; job i handles
 // the targets [tgt_begin[i], tgt_end[i]) of leaf job_cell[i] against the source runs

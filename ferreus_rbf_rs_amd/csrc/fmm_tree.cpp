@@ -311,7 +311,7 @@ void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<doubl
 // One workgroup per CU runs at a time, so a launch of T equal tiles takes ceil(T / CUs) rounds.
 // When the last round is at most half full its tiles are halved (a workgroup whose upper four
 // waves hold no cells runs one wave per SIMD and takes about half the time): the tail costs half a
-// round instead of a whole one.  Direct (contiguous) tiles only.
+// round instead of a whole one.
 static void split_tile_tail(std::vector<M2lTileDesc> *tiles, int n_cu) {
     const size_t T = tiles->size();
     const size_t r = T % static_cast<size_t>(n_cu);
@@ -319,7 +319,7 @@ static void split_tile_tail(std::vector<M2lTileDesc> *tiles, int n_cu) {
     std::vector<M2lTileDesc> out(tiles->begin(), tiles->end() - static_cast<std::ptrdiff_t>(r));
     for (size_t i = T - r; i < T; ++i) {
         const M2lTileDesc td = (*tiles)[i];
-        if (td.pad != 0 || td.count <= kM2lTile / 2) {
+        if (td.count <= kM2lTile / 2) {
             out.push_back(td);
             continue;
         }
@@ -727,7 +727,8 @@ int FmmTree::build_source_target_set() {
     return BBFMM_OK;
 }
 
-int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index) {
+int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
+                              std::vector<int32_t> *leaves_out) {
     const HostTree &t = tree_;
     std::vector<int32_t> cell(static_cast<size_t>(m));
     const int64_t bad = points_to_leaves(t, x, m, ldx, cell.data());
@@ -787,6 +788,7 @@ int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet
     CHK(dupload(&ts->w_tgt_end, wte));
     CHK(dupload(&ts->w_begin, wb));
     CHK(dupload(&ts->w_end, we));
+    if (leaves_out) leaves_out->swap(leaves);
     return BBFMM_OK;
 }
 
@@ -852,34 +854,36 @@ int FmmTree::upward(int k) {
 
 // downward_pass (bbfmm.rs:778-857).  All cells are treated as "with targets": locals of
 // cells without targets are never read by the leaf pass, so results are unchanged.
-int FmmTree::downward(int k) {
+int FmmTree::downward(int k, const DownwardPlan *dp) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
     // reset_local_coefficients (bbfmm.rs:627-632): tiles without any V-list entry are not written by
     // stage 2, and P2L / L2L add onto L
     HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_));
-    // a partition runs stage 1 on compact tiles of the sources its targets need, stage 2 on the
-    // tiles that hold an owned target, P2L on owned cells
+    // a plan runs stage 1 on compact tiles of the sources its targets need, stage 2 on the tiles that
+    // hold a cell with targets, P2L / L2L on the cells with targets (cells_with_targets, bbfmm.rs:468-480)
     const int n_all = static_cast<int>(m2l_tiles_h_.size());
     phase_begin();
-    if (have_part_)
-        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles_part1_.p, d_m2l_tile_idx_part_.p,
-                          static_cast<int>(m2l_tiles_part1_h_.size()), cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p,
-                          d_cbuf_.p, cbuf_len_, stream_);
+    if (dp)
+        launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles1_h.size()),
+                          cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
     else
         launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles_.p, nullptr, n_all, cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p,
                           d_cbuf_.p, cbuf_len_, stream_);
     phase_end(kPhM2L1);
     phase_begin();
-    launch_m2l_stage2(d_m2l_classes_.p, have_part_ ? d_m2l_tiles_part_.p : d_m2l_tiles2_.p,
-                      have_part_ ? n_m2l_tiles_part_ : static_cast<int>(m2l_tiles2_h_.size()), cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_,
-                      d_m2l_qlist_.p, d_L_.p, stream_);
+    if (dp)
+        launch_m2l_stage2(d_m2l_classes_.p, dp->d_tiles2.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles2_h.size()),
+                          cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, d_L_.p, stream_);
+    else
+        launch_m2l_stage2(d_m2l_classes_.p, d_m2l_tiles2_.p, nullptr, static_cast<int>(m2l_tiles2_h_.size()),
+                          cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, d_L_.p, stream_);
     phase_end(kPhM2L2);
     phase_begin();
     if (t.adaptive) {
-        if (have_part_)
-            launch_p2l(kernel_, cheb_, n_x_jobs_part_, d_x_cells_part_.p, d_x_job_run_ptr_part_.p, d_x_runs_part_.p,
-                       d_centers_.p, d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p, stream_);
+        if (dp)
+            launch_p2l(kernel_, cheb_, dp->n_x_jobs, dp->d_x_cells.p, dp->d_x_ptr.p, dp->d_x_runs.p, d_centers_.p,
+                       d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p, stream_);
         else
             launch_p2l(kernel_, cheb_, static_cast<int>(x_cells_.size()), d_x_cells_.p, d_x_job_run_ptr_.p,
                        d_x_runs_.p, d_centers_.p, d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p,
@@ -889,10 +893,10 @@ int FmmTree::downward(int k) {
     phase_begin();
     for (int level = 2; level <= t.depth; ++level) // children of level-1.. cells (bbfmm.rs:834-856)
         launch_l2l(cheb_, k, C, d_level_cells_[level].p, static_cast<int>(level_cells_[level].size()), d_parent_.p,
-                   d_octant_.p, d_active_.p, d_L_.p, stream_);
+                   d_octant_.p, dp ? dp->d_active.p : d_active_.p, d_L_.p, stream_);
     phase_end(kPhL2L);
     HIPCHK(hipGetLastError());
-    have_locals_ = true;
+    have_locals_ = dp == nullptr; // the whole-tree expansions are in L
     return BBFMM_OK;
 }
 
@@ -944,6 +948,7 @@ int FmmTree::set_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     CHK(upload_weights(w, rows, k, ldw));
     nrhs_ = k; // bbfmm.rs:384
+    have_locals_ = locals_requested_ = false; // the stored local expansions belong to the old weights
     CHK(upward(k));
     HIPCHK(hipStreamSynchronize(stream_));
     return BBFMM_OK;
@@ -956,6 +961,7 @@ int FmmTree::set_local_coefficients(const double *w, int64_t rows, int k, int64_
     CHK(upload_weights(w, rows, k, ldw));
     CHK(downward(k));
     HIPCHK(hipStreamSynchronize(stream_));
+    locals_requested_ = true;
     return BBFMM_OK;
 }
 
@@ -970,9 +976,19 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     if (leaves_only && !have_locals_) return fail(BBFMM_BAD_ARGUMENT, "set_local_coefficients must be called first");
     if (m >= (int64_t(1) << 31)) return fail(BBFMM_BAD_ARGUMENT, "more than 2^31-1 target points");
     TargetSet ts;
-    int rc = build_target_set(x, m, ldx, &ts, bad_point_index); // points_to_keys, bbfmm.rs:455-465
+    std::vector<int32_t> target_leaves;
+    int rc = build_target_set(x, m, ldx, &ts, bad_point_index, &target_leaves); // points_to_keys, bbfmm.rs:455-465
     if (rc == BBFMM_OK) rc = upload_weights(w, rows, k, ldw);
-    if (rc == BBFMM_OK && !leaves_only) rc = downward(k);
+    DownwardPlan dplan;
+    if (rc == BBFMM_OK && !leaves_only) {
+        // downward pass over cells_with_targets (bbfmm.rs:468-480) when the targets are few; many
+        // targets touch every cell anyway and the whole-tree pass needs no plan.  Once
+        // set_local_coefficients has stored the whole-tree expansions (Leaves mode, rbf.rs:836-838)
+        // the whole-tree pass is kept, so that evaluate_leaves stays valid afterwards.
+        const bool restricted = m * 4 < tree_.n_points && !locals_requested_;
+        if (restricted) rc = build_downward_plan(target_leaves, &dplan);
+        if (rc == BBFMM_OK) rc = downward(k, restricted ? &dplan : nullptr);
+    }
     if (rc == BBFMM_OK && with_grads && !kernel_supports_gradients(kernel_.id)) // bbfmm.rs:634-658
         rc = fail(BBFMM_KERNEL_NO_GRADIENTS,
                   "FMM evaluation failed: gradient evaluation requested but kernel does not support gradients");
@@ -1008,6 +1024,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     dfree(&o_dev);
     dfree(&g_dev);
     free_target_set(&ts);
+    free_downward_plan(&dplan);
     return rc;
 }
 
@@ -1025,6 +1042,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         CHK(dalloc(&part_targets_.out, static_cast<size_t>(k) * part_targets_.m));
     }
     const TargetSet &ts = have_part_ ? part_targets_ : src_targets_;
+    const DownwardPlan *plan = have_part_ ? &part_plan_ : nullptr;
     static const int overlap = [] {
         const char *e = std::getenv("BBFMM_OVERLAP");
         return e ? std::atoi(e) : 0;
@@ -1039,7 +1057,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
         CHK(leaf_pass_near(ts, k, false, stream2_, 2));
         HIPCHK(hipEventRecord(ev_join_, stream2_));
-        CHK(downward(k));
+        CHK(downward(k, plan));
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
         CHK(leaf_pass_far(ts, k, false));
     } else if (overlap == 1) {
@@ -1049,12 +1067,12 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
         CHK(leaf_pass_near(ts, k, false, stream2_, 3));
         HIPCHK(hipEventRecord(ev_join_, stream2_));
-        CHK(downward(k));
+        CHK(downward(k, plan));
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
         CHK(leaf_pass_far(ts, k, false));
     } else {
         CHK(upward(k));
-        CHK(downward(k));
+        CHK(downward(k, plan));
         CHK(leaf_pass(ts, k, false));
     }
     phase_begin();
@@ -1108,33 +1126,204 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
         std::fill(result + N, result + rows, 0.0); // the last basis_size rows stay 0 (rbf.rs:1346)
         return BBFMM_OK;
     }
+    // A subset of the sources (matvec_partial, rbf.rs:119-133): cached sorted targets, downward pass
+    // restricted to the cells that carry them; everything else as above.
+    SubsetPlan *sp = nullptr;
+    CHK(subset_plan(target_indices, n_target_indices, &sp));
+    const int64_t m = n_target_indices;
     std::fill(result, result + rows, 0.0); // rbf.rs:1346
-    CHK(set_weights(w, rows, 1, rows));    // rbf.rs:1357
-    std::vector<double> vals;
-    std::vector<int64_t> idx;
-    {
-        idx.assign(target_indices, target_indices + n_target_indices);
-        for (int64_t i : idx)
-            if (i < 0 || i >= N) return fail(BBFMM_BAD_ARGUMENT, "target index out of range");
-        const int64_t m = n_target_indices;
-        std::vector<double> x(static_cast<size_t>(m) * d_);
-        for (int a = 0; a < d_; ++a)
-            for (int64_t j = 0; j < m; ++j) x[static_cast<size_t>(a) * m + j] = pts_[static_cast<size_t>(a) * N + idx[j]];
-        vals.resize(static_cast<size_t>(m));
-        int64_t bad = -1;
-        CHK(evaluate(w, rows, 1, rows, x.data(), m, m, vals.data(), m, nullptr, 0, false, false, &bad)); // rbf.rs:1359-1364
+    if (m == 0) return BBFMM_OK;
+    CHK(ensure_pinned(static_cast<size_t>(2 * N)));
+    double *pin_in = h_pin_, *pin_out = h_pin_ + N;
+    parallel_for_chunks(N, int64_t(1) << 18, [&](int64_t b, int64_t e) {
+        std::memcpy(pin_in + b, w + b, static_cast<size_t>(e - b) * sizeof(double));
+    });
+    CHK(ensure_rhs_capacity(1));
+    if (static_cast<size_t>(N) > d_w_in_.n) {
+        dfree(&d_w_in_);
+        CHK(dalloc(&d_w_in_, static_cast<size_t>(N)));
     }
-    for (size_t j = 0; j < idx.size(); ++j) { // rbf.rs:1366-1376
-        const int64_t i = idx[j];
-        double r = vals[j];
-        r += w[i] * nugget;
-        if (poly) {
-            double s = 0.0;
-            for (int64_t b = 0; b < basis_size; ++b) s += poly[b * ldp + i] * w[N + b];
-            r += s;
+    HIPCHK(hipMemcpyAsync(d_w_in_.p, pin_in, N * sizeof(double), hipMemcpyHostToDevice, stream_));
+    nrhs_ = 1;
+    phase_begin();
+    launch_gather_weights(d_w_in_.p, N, 1, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_end(kPhGather);
+    CHK(upward(1));            // set_weights: all sources contribute (rbf.rs:1357)
+    CHK(downward(1, &sp->dp)); // evaluate at the subset (rbf.rs:1359-1364)
+    CHK(leaf_pass(sp->ts, 1, false));
+    launch_scatter_output(sp->ts.out.p, m, 1, sp->ts.perm.p, d_out_.p, m, 0, stream_);
+    HIPCHK(hipMemcpyAsync(pin_out, d_out_.p, m * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    parallel_for_chunks(m, int64_t(1) << 16, [&](int64_t b, int64_t e) { // rbf.rs:1366-1376
+        for (int64_t j = b; j < e; ++j) {
+            const int64_t i = target_indices[j];
+            double r = pin_out[j] + w[i] * nugget;
+            if (poly) {
+                double sacc = 0.0;
+                for (int64_t q = 0; q < basis_size; ++q) sacc += poly[q * ldp + i] * w[N + q];
+                r += sacc;
+            }
+            result[i] = r;
         }
-        result[i] = r;
+    });
+    return BBFMM_OK;
+}
+
+// Restriction of the downward pass to the cells that carry targets (cells_with_targets,
+// bbfmm.rs:468-480): M2L stage 2 on the tiles that hold such a cell, stage 1 on compact tiles (lists
+// of class positions, 128 per tile) of the cells that are a V-list source of one, P2L on such cells.
+// The host part also runs on BBFMM_FLAG_HOST_ONLY handles.
+int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp) {
+    const HostTree &t = tree_;
+    const int64_t C = t.n_cells();
+    dp->active.assign(static_cast<size_t>(C), 0);
+    for (int32_t leaf : target_leaves) {
+        int32_t c = leaf;
+        while (c >= 0 && !dp->active[c]) {
+            dp->active[c] = 1;
+            c = t.parent[c];
+        }
     }
+    const std::vector<uint8_t> &active = dp->active;
+    std::vector<uint8_t> needed(static_cast<size_t>(C), 0);
+    for (int64_t B = 0; B < C; ++B) {
+        if (!active[B] || t.level[B] < 2) continue;
+        for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) needed[t.v.idx[q]] = 1;
+    }
+    dp->tiles2_h.clear();
+    dp->tiles1_h.clear();
+    dp->tile_idx_h.clear();
+    dp->qlist_h.clear();
+    std::vector<int> tpos_of(static_cast<size_t>(ops_.n_vec));
+    std::vector<uint8_t> act;
+    for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+        const HostM2lClass &hc = m2l_host_[lc];
+        if (hc.cells.empty()) continue;
+        auto add_tiles = [&](const std::vector<uint8_t> &flag, std::vector<M2lTileDesc> *tiles) {
+            const size_t start = dp->tile_idx_h.size();
+            for (size_t i = 0; i < hc.cells.size(); ++i)
+                if (flag[hc.cells[i]]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
+            for (size_t f = start; f < dp->tile_idx_h.size(); f += kM2lTile) {
+                M2lTileDesc td;
+                std::memset(&td, 0, sizeof td);
+                td.level_class = static_cast<int32_t>(lc);
+                td.first = static_cast<int32_t>(f);
+                td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - f));
+                td.pad = 1; // first indexes tile_idx (class positions)
+                tiles->push_back(td);
+            }
+        };
+        add_tiles(needed, &dp->tiles1_h);
+        const size_t t2 = dp->tiles2_h.size();
+        add_tiles(active, &dp->tiles2_h);
+        // contraction steps (16 slot entries each) that hold a V-list entry of some cell of the tile
+        std::fill(tpos_of.begin(), tpos_of.end(), -1);
+        for (size_t pos = 0; pos < hc.tgt_tv.size(); ++pos) tpos_of[hc.tgt_tv[pos]] = static_cast<int>(pos);
+        const auto &lops = ops_.m2l[hc.level];
+        const int nq = hc.k_pad / 16;
+        for (size_t ti = t2; ti < dp->tiles2_h.size(); ++ti) {
+            M2lTileDesc &td = dp->tiles2_h[ti];
+            act.assign(static_cast<size_t>(nq), 0);
+            for (int32_t i = 0; i < td.count; ++i) {
+                const int64_t B = hc.cells[dp->tile_idx_h[td.first + i]];
+                for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
+                    const int tv = t.v_tidx[q];
+                    const int pos = tv >= 0 && tv < ops_.n_vec ? tpos_of[tv] : -1;
+                    if (pos < 0) continue;
+                    const int a = hc.tgt_off[pos], b = a + lops[ops_.ref_lookup[tv]].rank;
+                    for (int sq = a / 16; sq <= (b - 1) / 16; ++sq) act[sq] = 1;
+                }
+            }
+            td.q_first = static_cast<int32_t>(dp->qlist_h.size());
+            for (int sq = 0; sq < nq; ++sq)
+                if (act[sq]) dp->qlist_h.push_back(static_cast<uint16_t>(sq));
+            td.q_count = static_cast<int32_t>(dp->qlist_h.size()) - td.q_first;
+        }
+    }
+    split_tile_tail(&dp->tiles2_h, n_cu_);
+    std::vector<int32_t> xc, xruns;
+    std::vector<int64_t> xptr(1, 0);
+    for (int32_t c : x_cells_) {
+        if (!active[c]) continue;
+        xc.push_back(c);
+        for (int64_t r = x_runs_.ptr[c]; r < x_runs_.ptr[c + 1]; ++r) {
+            xruns.push_back(x_runs_.idx[2 * r]);
+            xruns.push_back(x_runs_.idx[2 * r + 1]);
+        }
+        xptr.push_back(static_cast<int64_t>(xruns.size() / 2));
+    }
+    dp->n_x_jobs = static_cast<int>(xc.size());
+    if (host_only_) return BBFMM_OK;
+    CHK(dupload(&dp->d_active, dp->active));
+    CHK(dupload(&dp->d_tiles2, dp->tiles2_h));
+    CHK(dupload(&dp->d_tiles1, dp->tiles1_h));
+    CHK(dupload(&dp->d_tile_idx, dp->tile_idx_h));
+    CHK(dupload(&dp->d_qlist, dp->qlist_h));
+    CHK(dupload(&dp->d_x_cells, xc));
+    CHK(dupload(&dp->d_x_ptr, xptr));
+    CHK(dupload(&dp->d_x_runs, xruns));
+    return BBFMM_OK;
+}
+
+void FmmTree::free_downward_plan(DownwardPlan *dp) {
+    dfree(&dp->d_active);
+    dfree(&dp->d_tiles2);
+    dfree(&dp->d_tiles1);
+    dfree(&dp->d_tile_idx);
+    dfree(&dp->d_qlist);
+    dfree(&dp->d_x_cells);
+    dfree(&dp->d_x_ptr);
+    dfree(&dp->d_x_runs);
+    *dp = DownwardPlan();
+}
+
+// Target subset of a partial matvec (IterativeSolver::matvec_partial, rbf.rs:119-133): the Schwarz
+// preconditioner asks for the same index sets (its levels' points) in every iteration, so the
+// sorted targets and the restricted downward pass are built once per distinct index set and kept
+// (8 sets, least recently used evicted).
+int FmmTree::subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out) {
+    const int64_t N = tree_.n_points;
+    uint64_t h = 1469598103934665603ull ^ static_cast<uint64_t>(n_idx);
+    for (int64_t j = 0; j < n_idx; ++j) h = (h ^ static_cast<uint64_t>(idx[j])) * 1099511628211ull;
+    ++subset_clock_;
+    for (auto &sp : subset_plans_)
+        if (sp->key == h && sp->n_idx == n_idx) {
+            sp->last_use = subset_clock_;
+            *out = sp.get();
+            return BBFMM_OK;
+        }
+    for (int64_t j = 0; j < n_idx; ++j)
+        if (idx[j] < 0 || idx[j] >= N) return fail(BBFMM_BAD_ARGUMENT, "target index out of range");
+    if (subset_plans_.size() >= 8) {
+        size_t victim = 0;
+        for (size_t i = 1; i < subset_plans_.size(); ++i)
+            if (subset_plans_[i]->last_use < subset_plans_[victim]->last_use) victim = i;
+        free_target_set(&subset_plans_[victim]->ts);
+        free_downward_plan(&subset_plans_[victim]->dp);
+        subset_plans_.erase(subset_plans_.begin() + static_cast<std::ptrdiff_t>(victim));
+    }
+    std::unique_ptr<SubsetPlan> sp(new SubsetPlan());
+    sp->key = h;
+    sp->n_idx = n_idx;
+    sp->last_use = subset_clock_;
+    const int64_t m = n_idx;
+    std::vector<double> x(static_cast<size_t>(std::max<int64_t>(m, 1)) * d_); // select_mat_rows, rbf.rs:1359-1360
+    for (int a = 0; a < d_; ++a)
+        parallel_for_chunks(m, int64_t(1) << 16, [&](int64_t b, int64_t e) {
+            for (int64_t j = b; j < e; ++j) x[static_cast<size_t>(a) * m + j] = pts_[static_cast<size_t>(a) * N + idx[j]];
+        });
+    std::vector<int32_t> leaves;
+    int64_t bad = -1;
+    int rc = build_target_set(x.data(), m, std::max<int64_t>(m, 1), &sp->ts, &bad, &leaves);
+    if (rc == BBFMM_OK) rc = build_downward_plan(leaves, &sp->dp);
+    if (rc == BBFMM_OK) rc = dalloc(&sp->ts.out, static_cast<size_t>(std::max<int64_t>(m, 1)));
+    if (rc != BBFMM_OK) {
+        free_target_set(&sp->ts);
+        free_downward_plan(&sp->dp);
+        return rc;
+    }
+    *out = sp.get();
+    subset_plans_.push_back(std::move(sp));
     return BBFMM_OK;
 }
 
@@ -1149,20 +1338,11 @@ int FmmTree::set_partition(int rank, int world) {
     part_world_ = world;
     if (have_part_) {
         free_target_set(&part_targets_);
-        dfree(&d_m2l_tiles_part_);
-        dfree(&d_m2l_tiles_part1_);
-        dfree(&d_m2l_tile_idx_part_);
-        dfree(&d_x_cells_part_);
-        dfree(&d_x_job_run_ptr_part_);
-        dfree(&d_x_runs_part_);
+        free_downward_plan(&part_plan_);
         have_part_ = false;
     }
     part_rows_.clear();
-    std::vector<uint8_t> active(static_cast<size_t>(C), 1);
-    if (world == 1) {
-        if (!host_only_) HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
-        return BBFMM_OK;
-    }
+    if (world == 1) return BBFMM_OK;
     // balance the leaf-pass + M2L work proxy: P2P pair count + a per-point share of the far field
     const size_t nl = src_leaves_.size();
     std::vector<double> work(nl);
@@ -1184,60 +1364,9 @@ int FmmTree::set_partition(int rank, int world) {
         return i;
     };
     const size_t lb = rank == 0 ? 0 : cut(rank), le = rank == world - 1 ? nl : cut(rank + 1);
-    std::fill(active.begin(), active.end(), 0);
-    for (size_t i = lb; i < le; ++i) {
-        int32_t c = src_leaves_[i];
-        while (c >= 0 && !active[c]) {
-            active[c] = 1;
-            c = t.parent[c];
-        }
-    }
-    // M2L: stage 2 on the tiles that hold an active target; stage 1 on compact tiles (lists of class
-    // positions, 128 per tile) of the cells that are a V-list source of an active target
-    std::vector<uint8_t> needed(static_cast<size_t>(C), 0);
-    for (int64_t B = 0; B < C; ++B) {
-        if (!active[B] || t.level[B] < 2) continue;
-        for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) needed[t.v.idx[q]] = 1;
-    }
-    m2l_tiles_part_h_.clear();
-    for (const M2lTileDesc &td : m2l_tiles_h_) {
-        const HostM2lClass &hc = m2l_host_[td.level_class];
-        bool any = false;
-        for (int32_t i = 0; i < td.count && !any; ++i) any = active[hc.cells[td.first + i]] != 0;
-        if (any) m2l_tiles_part_h_.push_back(td);
-    }
-    split_tile_tail(&m2l_tiles_part_h_, n_cu_);
-    n_m2l_tiles_part_ = static_cast<int>(m2l_tiles_part_h_.size());
-    m2l_tiles_part1_h_.clear();
-    m2l_tile_idx_part_h_.clear();
-    for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
-        const HostM2lClass &hc = m2l_host_[lc];
-        const size_t start = m2l_tile_idx_part_h_.size();
-        for (size_t i = 0; i < hc.cells.size(); ++i)
-            if (needed[hc.cells[i]]) m2l_tile_idx_part_h_.push_back(static_cast<int32_t>(i));
-        for (size_t f = start; f < m2l_tile_idx_part_h_.size(); f += kM2lTile) {
-            M2lTileDesc td;
-            std::memset(&td, 0, sizeof td);
-            td.level_class = static_cast<int32_t>(lc);
-            td.first = static_cast<int32_t>(f);
-            td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, m2l_tile_idx_part_h_.size() - f));
-            td.pad = 1; // indirect
-            m2l_tiles_part1_h_.push_back(td);
-        }
-    }
-    // P2L jobs of owned cells
-    std::vector<int32_t> xc, xruns;
-    std::vector<int64_t> xptr(1, 0);
-    for (int32_t c : x_cells_) {
-        if (!active[c]) continue;
-        xc.push_back(c);
-        for (int64_t r = x_runs_.ptr[c]; r < x_runs_.ptr[c + 1]; ++r) {
-            xruns.push_back(x_runs_.idx[2 * r]);
-            xruns.push_back(x_runs_.idx[2 * r + 1]);
-        }
-        xptr.push_back(static_cast<int64_t>(xruns.size() / 2));
-    }
-    n_x_jobs_part_ = static_cast<int>(xc.size());
+    std::vector<int32_t> owned_leaves(src_leaves_.begin() + static_cast<std::ptrdiff_t>(lb),
+                                      src_leaves_.begin() + static_cast<std::ptrdiff_t>(le));
+    CHK(build_downward_plan(owned_leaves, &part_plan_));
     // owned targets: one contiguous range of the sorted sources
     const int64_t pb = lb < le ? t.pt_begin[src_leaves_[lb]] : 0;
     const int64_t pe = lb < le ? t.pt_end[src_leaves_[le - 1]] : 0;
@@ -1246,13 +1375,6 @@ int FmmTree::set_partition(int rank, int world) {
     part_empty_ = pe == pb;
     if (host_only_) return BBFMM_OK;
 
-    HIPCHK(hipMemcpy(d_active_.p, active.data(), active.size(), hipMemcpyHostToDevice));
-    CHK(dupload(&d_m2l_tiles_part_, m2l_tiles_part_h_));
-    CHK(dupload(&d_m2l_tiles_part1_, m2l_tiles_part1_h_));
-    CHK(dupload(&d_m2l_tile_idx_part_, m2l_tile_idx_part_h_));
-    CHK(dupload(&d_x_cells_part_, xc));
-    CHK(dupload(&d_x_job_run_ptr_part_, xptr));
-    CHK(dupload(&d_x_runs_part_, xruns));
     TargetSet &ts = part_targets_;
     ts.m = pe - pb;
     for (int a = 0; a < 3; ++a) ts.xyz_ptr[a] = src_ptr_[a] + pb;

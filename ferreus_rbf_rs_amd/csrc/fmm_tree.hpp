@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <string>
+#include <memory>
 #include <vector>
 
 #include "device.hpp"
@@ -49,6 +50,30 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     DevBuf<int64_t> w_begin, w_end;
     int n_w_jobs = 0;
     DevBuf<double> out, grad;  // K x m, K*d x m (sorted order)
+};
+
+// The part of the downward pass a set of target leaves needs (a partition of the sources, or the
+// target subset of a partial matvec): cells that carry targets, the M2L tiles and P2L jobs for them.
+struct DownwardPlan {
+    std::vector<uint8_t> active;            // cells with targets (leaves and their ancestors)
+    std::vector<M2lTileDesc> tiles2_h;      // compact stage-2 tiles over the active cells (tail split)
+    std::vector<M2lTileDesc> tiles1_h;      // compact stage-1 tiles over the V-list sources of active cells
+    std::vector<int32_t> tile_idx_h;        // class positions of the cells of both tile lists
+    std::vector<uint16_t> qlist_h;          // active contraction steps of the stage-2 tiles
+    int n_x_jobs = 0;
+    DevBuf<uint8_t> d_active;
+    DevBuf<M2lTileDesc> d_tiles2, d_tiles1;
+    DevBuf<int32_t> d_tile_idx, d_x_cells, d_x_runs;
+    DevBuf<int64_t> d_x_ptr;
+    DevBuf<uint16_t> d_qlist;
+};
+
+struct SubsetPlan { // cached target subset of bbfmm_fast_matrix_vector_product (rbf.rs:119-133)
+    uint64_t key = 0;
+    int64_t n_idx = 0;
+    uint64_t last_use = 0;
+    TargetSet ts;
+    DownwardPlan dp;
 };
 
 class FmmTree {
@@ -107,11 +132,12 @@ class FmmTree {
                                   std::vector<double> *u_all) const;
     int ensure_rhs_capacity(int k);
     int upward(int k);                                  // P2M + M2M from w_sorted_
-    int downward(int k);                                // M2L + P2L + L2L into L_
+    int downward(int k, const DownwardPlan *dp = nullptr); // M2L + P2L + L2L into L_ (restricted by a plan)
     int leaf_pass(const TargetSet &ts, int k, bool with_grads);
     int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts);
     int leaf_pass_far(const TargetSet &ts, int k, bool with_grads);
-    int build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index);
+    int build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
+                         std::vector<int32_t> *leaves_out = nullptr);
     int build_source_target_set();
     void free_target_set(TargetSet *ts);
     int upload_weights(const double *w, int64_t rows, int k, int64_t ldw);
@@ -131,6 +157,7 @@ class FmmTree {
     Operators ops_;
     int nrhs_ = 0;           // set by set_weights (bbfmm.rs:384); 0 = no weights yet
     bool have_locals_ = false;
+    bool locals_requested_ = false; // set_local_coefficients was called for the current weights (Leaves mode)
     // leaf-pass run lists per cell (merged sorted-source ranges)
     Csr u_runs_;             // ptr per cell, idx = 2 ints per run
     Csr x_runs_;
@@ -152,9 +179,12 @@ class FmmTree {
     int part_rank_ = 0, part_world_ = 1;
     std::vector<int64_t> part_rows_;
     bool part_empty_ = false;
-    std::vector<M2lTileDesc> m2l_tiles_part_h_;   // partition: stage-2 tiles (contain an owned target)
-    std::vector<M2lTileDesc> m2l_tiles_part1_h_;  // partition: compact stage-1 tiles over the needed sources
-    std::vector<int32_t> m2l_tile_idx_part_h_;    // their class positions
+    DownwardPlan part_plan_;                     // partition: restricted downward pass
+    std::vector<std::unique_ptr<SubsetPlan>> subset_plans_; // partial matvecs, least recently used evicted
+    uint64_t subset_clock_ = 0;
+    int build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp);
+    void free_downward_plan(DownwardPlan *dp);
+    int subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out);
 
     // ---- device state
     hipStream_t stream_ = nullptr, stream2_ = nullptr;
@@ -190,12 +220,9 @@ class FmmTree {
     DevBuf<int32_t> d_u_runs_, d_x_runs_, d_w_idx_, d_x_cells_;
     DevBuf<int64_t> d_x_job_run_ptr_;
     DevBuf<M2lClass> d_m2l_classes_;
-    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles2_, d_m2l_tiles_part_, d_m2l_tiles_part1_;
-    DevBuf<int32_t> d_m2l_tile_idx_part_, d_x_cells_part_, d_x_runs_part_;
-    DevBuf<int64_t> d_x_job_run_ptr_part_;
-    int n_x_jobs_part_ = 0;
+    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles2_;
     DevBuf<uint16_t> d_m2l_qlist_;
-    int n_m2l_tiles_part_ = 0;
+
     DevBuf<uint8_t> d_active_;
     // per-rhs-capacity buffers
     int k_cap_ = 0;

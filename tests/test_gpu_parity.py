@@ -236,3 +236,37 @@ def test_orders_1d_2d(d, order):
     pts = np.random.default_rng(200 + 10 * d + order).random((n, d))
     check(pts, nrhs=1, order=order, params=(40, O.COMPRESSION_ACA, 1e-8, 1024),
           dense_tol=5.0 * 10.0 ** -min(order - 1, 6), seed=order + d)
+
+
+def test_partial_matvec_plans_and_restricted_evaluate():
+    """matvec_partial (rbf.rs:119-133) with cached target-subset plans, and evaluate() on few targets:
+    both run the downward pass over cells_with_targets only and must match the whole-tree results."""
+    n = 40000
+    pts = clustered_points(np.random.default_rng(31), n, 3)
+    t, r = make(pts, kid=0, order=6, params=(80, O.COMPRESSION_ACA, 1e-6, 1024))
+    rng = np.random.default_rng(32)
+    w = rng.random(n)
+    full = t.fast_matrix_vector_product(w, nugget=0.25)
+    subsets = [np.sort(rng.choice(n, m, replace=False)).astype(np.int64) for m in (7, 300, 5000, 20000)]
+    subsets += [rng.choice(n, 50, replace=True).astype(np.int64) for _ in range(7)]   # > 8 plans: eviction
+    for rep in range(2):                                                              # second round: cached or rebuilt
+        for idx in subsets:
+            y = t.fast_matrix_vector_product(w, target_indices=idx, nugget=0.25)
+            assert relerr(y[idx], full[idx]) < TOL
+            mask = np.ones(n, bool)
+            mask[idx] = False
+            assert not y[mask].any()                                                  # other rows stay 0 (rbf.rs:1346)
+    # evaluate() on few targets in Full mode (no set_local_coefficients): restricted pass vs oracle
+    w2 = rng.random((n, 2))
+    t.set_weights(w2)
+    r.set_weights(w2)
+    x = pts[rng.choice(n, 200, replace=False)] + 1e-3 * rng.standard_normal((200, 3))
+    x = np.clip(x, pts.min(0), pts.max(0))
+    assert relerr(t.evaluate(w2, x), r.evaluate(w2, x)) < TOL
+    # Leaves mode: set_local_coefficients, then evaluate() must leave the stored expansions intact
+    t.set_local_coefficients(w2)
+    r.set_local_coefficients(w2)
+    a = t.evaluate_leaves(w2, x)
+    t.evaluate(w2, x[:10])
+    assert relerr(t.evaluate_leaves(w2, x), a) < 1e-14       # (M2P adds with atomics: order may differ)
+    assert relerr(a, r.evaluate_leaves(w2, x)) < TOL
