@@ -2,6 +2,9 @@
 // Restates ferreus_bbfmm/src/linear_tree.rs (citations inline) with deterministic
 // containers.  See tree.hpp.
 #include "tree.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 #include <algorithm>
 #include <cmath>
@@ -200,9 +203,23 @@ void interaction_lists_regular(HostTree &t) {
 
 } // namespace
 
+namespace {
+struct TreeTimer { // BBFMM_VERBOSE=1: tree build stage times on stderr
+    bool on = std::getenv("BBFMM_VERBOSE") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm]   tree: %-22s %8.3f s\n", what, std::chrono::duration<double>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+} // namespace
+
 void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *center, double radius,
                 int64_t max_points_per_cell, bool store_empty_leaves, bool adaptive_tree,
                 HostTree *out) {
+    TreeTimer timer;
     HostTree &t = *out;
     t = HostTree();
     t.d = d;
@@ -224,6 +241,66 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
     std::vector<uint64_t> keys(static_cast<size_t>(n));
     std::vector<int64_t> tmp(static_cast<size_t>(n));
 
+    // Fast path (every point inside the root box): the level-l anchor of a point is its level-16
+    // anchor shifted right by 16 - l (the side lengths differ by exact powers of two), so one stable
+    // sort by the interleaved level-16 code orders the points for every level at once and the
+    // children of a cell are found by searching its range for the digit boundaries.  Inside a leaf
+    // the row order of the level-by-level stable grouping is restored at the end.  Points outside
+    // the box (explicit extents smaller than the data) take the level-by-level path below.
+    std::vector<uint64_t> code16;
+    bool fast = n > 0;
+    {
+        const double side16 = get_side_length(radius, kMaximumLevel);
+        std::vector<uint8_t> bad_chunk(static_cast<size_t>((n + (1 << 15) - 1) >> 15) + 1, 0);
+        code16.resize(static_cast<size_t>(n));
+        parallel_for_chunks(n, 1 << 15, [&](int64_t lo, int64_t hi) {
+            bool bad = false;
+            for (int64_t i = lo; i < hi; ++i) {
+                uint64_t code = 0;
+                for (int a = 0; a < d; ++a) {
+                    const double q = std::floor((pts[a * ld + i] - disp[a]) / side16);
+                    if (!(q >= 0.0 && q < 65536.0)) bad = true;
+                    code |= spread_bits(f64_to_u64_saturating(q), d) << a;
+                }
+                code16[i] = code;
+            }
+            if (bad) bad_chunk[static_cast<size_t>(lo >> 15)] = 1;
+        });
+        for (uint8_t b : bad_chunk) fast = fast && !b;
+    }
+    if (fast) { // stable LSD radix sort of (code, row) by 8-bit digits, threaded
+        const int nbits = 16 * d, T = std::max(1, host_threads());
+        std::vector<uint64_t> code_tmp(static_cast<size_t>(n));
+        const int64_t chunk = (n + T - 1) / T;
+        std::vector<int64_t> hist(static_cast<size_t>(T) * 256);
+        for (int shift = 0; shift < nbits; shift += 8) {
+            std::fill(hist.begin(), hist.end(), 0);
+            parallel_for(T, 1, [&](int64_t th) {
+                int64_t *h = &hist[static_cast<size_t>(th) * 256];
+                for (int64_t i = th * chunk; i < std::min(n, (th + 1) * chunk); ++i) ++h[(code16[i] >> shift) & 255];
+            });
+            int64_t run = 0;
+            for (int bin = 0; bin < 256; ++bin)
+                for (int th = 0; th < T; ++th) {
+                    const int64_t c = hist[static_cast<size_t>(th) * 256 + bin];
+                    hist[static_cast<size_t>(th) * 256 + bin] = run;
+                    run += c;
+                }
+            parallel_for(T, 1, [&](int64_t th) {
+                int64_t *h = &hist[static_cast<size_t>(th) * 256];
+                for (int64_t i = th * chunk; i < std::min(n, (th + 1) * chunk); ++i) {
+                    const int64_t dst = h[(code16[i] >> shift) & 255]++;
+                    code_tmp[dst] = code16[i];
+                    tmp[dst] = t.order[i];
+                }
+            });
+            code16.swap(code_tmp);
+            t.order.swap(tmp);
+        }
+    } else {
+        std::vector<uint64_t>().swap(code16);
+    }
+
     std::vector<TmpCell> cells;
     cells.push_back(TmpCell{0, 0, -1, 0, n, false});
     std::vector<int32_t> active{0}, next;
@@ -241,6 +318,7 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
         bool any_child_exceeds = false;
 
         // child key of every point of every active cell (linear_tree.rs:56-61)
+        if (!fast)
         for (int32_t ci : active) {
             const int64_t b = cells[ci].b, e = cells[ci].e;
             parallel_for_chunks(e - b, 1 << 15, [&](int64_t lo, int64_t hi) {
@@ -254,6 +332,22 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
             const TmpCell cell = cells[active[ai]];
             const int64_t b = cell.b, e = cell.e;
             if (e == b) return;
+            if (fast) { // the digit of the child level is non-decreasing over the sorted range
+                const int shift = d * static_cast<int>(kMaximumLevel - child_level);
+                auto &gf = groups[ai];
+                int64_t lo = b;
+                while (lo < e) {
+                    const uint64_t dig = (code16[lo] >> shift) & static_cast<uint64_t>(nchild - 1);
+                    const int64_t hi = std::partition_point(code16.begin() + lo, code16.begin() + e,
+                                                            [&](uint64_t c) {
+                                                                return ((c >> shift) & static_cast<uint64_t>(nchild - 1)) <= dig;
+                                                            }) -
+                                       code16.begin();
+                    gf.push_back(Group{get_child(cell.key, d, dig), lo, hi});
+                    lo = hi;
+                }
+                return;
+            }
             bool proper = true;
             for (int64_t i = b; i < e && proper; ++i) {
                 uint64_t par;
@@ -338,6 +432,12 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
         }
     }
     t.depth = static_cast<int>(current_level + 1); // linear_tree.rs:160
+    if (fast) // rows ascending inside a leaf, as the level-by-level stable grouping leaves them
+        parallel_for(static_cast<int64_t>(cells.size()), 64, [&](int64_t ci) {
+            const TmpCell &c = cells[ci];
+            if (c.leaf && c.e - c.b > 1) std::sort(t.order.begin() + c.b, t.order.begin() + c.e);
+        });
+    timer.lap("subdivision");
 
     // number the cells by (level, key)
     const int64_t C = static_cast<int64_t>(cells.size());
@@ -386,11 +486,13 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
             if (t.parent[i] >= 0) t.children.idx[pos[t.parent[i]]++] = static_cast<int32_t>(i);
     }
     t.table.build(t.key);
+    timer.lap("numbering, children");
 
     if (adaptive_tree)
         interaction_lists_adaptive(t);
     else
         interaction_lists_regular(t);
+    timer.lap("interaction lists");
 
     // M2L transfer index of every V pair (bbfmm.rs:872-888, 989-998)
     t.v_tidx.resize(t.v.idx.size());
