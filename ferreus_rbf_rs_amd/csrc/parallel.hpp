@@ -52,4 +52,41 @@ template <class F> void parallel_for(int64_t n, int64_t chunk, F &&fn) {
     });
 }
 
+// Stable LSD radix sort of (key, value) pairs by the low `nbits` bits of the keys, 8-bit digits,
+// threaded: per-thread histograms over fixed chunks, one prefix over (digit, thread), scatter.
+inline void parallel_radix_sort_pairs(std::vector<uint64_t> *keys, std::vector<int64_t> *vals, int nbits) {
+    const int64_t n = static_cast<int64_t>(keys->size());
+    if (n <= 1) return;
+    const int T = std::max(1, host_threads());
+    std::vector<uint64_t> ktmp(static_cast<size_t>(n));
+    std::vector<int64_t> vtmp(static_cast<size_t>(n));
+    const int64_t chunk = (n + T - 1) / T;
+    std::vector<int64_t> hist(static_cast<size_t>(T) * 256);
+    for (int shift = 0; shift < nbits; shift += 8) {
+        std::fill(hist.begin(), hist.end(), 0);
+        const std::vector<uint64_t> &k = *keys;
+        parallel_for(T, 1, [&](int64_t th) {
+            int64_t *h = &hist[static_cast<size_t>(th) * 256];
+            for (int64_t i = th * chunk; i < std::min(n, (th + 1) * chunk); ++i) ++h[(k[i] >> shift) & 255];
+        });
+        int64_t run = 0;
+        for (int bin = 0; bin < 256; ++bin)
+            for (int th = 0; th < T; ++th) {
+                const int64_t c = hist[static_cast<size_t>(th) * 256 + bin];
+                hist[static_cast<size_t>(th) * 256 + bin] = run;
+                run += c;
+            }
+        parallel_for(T, 1, [&](int64_t th) {
+            int64_t *h = &hist[static_cast<size_t>(th) * 256];
+            for (int64_t i = th * chunk; i < std::min(n, (th + 1) * chunk); ++i) {
+                const int64_t dst = h[(k[i] >> shift) & 255]++;
+                ktmp[dst] = k[i];
+                vtmp[dst] = (*vals)[i];
+            }
+        });
+        keys->swap(ktmp);
+        vals->swap(vtmp);
+    }
+}
+
 } // namespace bbfmm

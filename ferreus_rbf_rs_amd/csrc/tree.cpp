@@ -268,35 +268,8 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
         });
         for (uint8_t b : bad_chunk) fast = fast && !b;
     }
-    if (fast) { // stable LSD radix sort of (code, row) by 8-bit digits, threaded
-        const int nbits = 16 * d, T = std::max(1, host_threads());
-        std::vector<uint64_t> code_tmp(static_cast<size_t>(n));
-        const int64_t chunk = (n + T - 1) / T;
-        std::vector<int64_t> hist(static_cast<size_t>(T) * 256);
-        for (int shift = 0; shift < nbits; shift += 8) {
-            std::fill(hist.begin(), hist.end(), 0);
-            parallel_for(T, 1, [&](int64_t th) {
-                int64_t *h = &hist[static_cast<size_t>(th) * 256];
-                for (int64_t i = th * chunk; i < std::min(n, (th + 1) * chunk); ++i) ++h[(code16[i] >> shift) & 255];
-            });
-            int64_t run = 0;
-            for (int bin = 0; bin < 256; ++bin)
-                for (int th = 0; th < T; ++th) {
-                    const int64_t c = hist[static_cast<size_t>(th) * 256 + bin];
-                    hist[static_cast<size_t>(th) * 256 + bin] = run;
-                    run += c;
-                }
-            parallel_for(T, 1, [&](int64_t th) {
-                int64_t *h = &hist[static_cast<size_t>(th) * 256];
-                for (int64_t i = th * chunk; i < std::min(n, (th + 1) * chunk); ++i) {
-                    const int64_t dst = h[(code16[i] >> shift) & 255]++;
-                    code_tmp[dst] = code16[i];
-                    tmp[dst] = t.order[i];
-                }
-            });
-            code16.swap(code_tmp);
-            t.order.swap(tmp);
-        }
+    if (fast) {
+        parallel_radix_sort_pairs(&code16, &t.order, 16 * d);
     } else {
         std::vector<uint64_t>().swap(code16);
     }
