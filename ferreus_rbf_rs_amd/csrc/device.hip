@@ -1373,7 +1373,11 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
         constexpr int ID = decltype(idc)::value;
         for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
             const int kb = std::min(DIRECT_KB, K - k0);
-            if (grad_sorted) {
+            if (grad_sorted && kb == 1) { // single right-hand side: a quarter of the accumulators
+                hipLaunchKernelGGL((p2p_kernel<ID, true, 1>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d, jobs,
+                                   make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted,
+                                   grad_sorted);
+            } else if (grad_sorted) {
                 hipLaunchKernelGGL((p2p_kernel<ID, true, DIRECT_KB>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d, jobs,
                                    make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted,
                                    grad_sorted);
@@ -1400,14 +1404,15 @@ void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
         constexpr int ID = decltype(idc)::value;
         for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
             const int kb = std::min(DIRECT_KB, K - k0);
-            if (grad_sorted)
-                hipLaunchKernelGGL((m2p_kernel<ID, true, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev,
-                                   tgt_begin, tgt_end, w_begin, w_end, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
-                                   kb, C, M, out_sorted, grad_sorted);
-            else
-                hipLaunchKernelGGL((m2p_kernel<ID, false, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev,
-                                   tgt_begin, tgt_end, w_begin, w_end, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0,
-                                   kb, C, M, out_sorted, grad_sorted);
+#define M2P_GO(GR, KBV)                                                                                           \
+    hipLaunchKernelGGL((m2p_kernel<ID, GR, KBV>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev, tgt_begin, tgt_end,   \
+                       w_begin, w_end, w_cells, centers, lengths, make_xyz(tgt_xyz), n_tgt, k0, kb, C, M,          \
+                       out_sorted, grad_sorted)
+            if (grad_sorted && kb == 1) M2P_GO(true, 1);
+            else if (grad_sorted) M2P_GO(true, DIRECT_KB);
+            else if (kb == 1) M2P_GO(false, 1);
+            else M2P_GO(false, DIRECT_KB);
+#undef M2P_GO
         }
     });
 }
@@ -1420,8 +1425,12 @@ void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
         constexpr int ID = decltype(idc)::value;
         for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
             const int kb = std::min(DIRECT_KB, K - k0);
-            hipLaunchKernelGGL((p2l_kernel<ID, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev, cells, run_ptr,
-                               runs, centers, lengths, make_xyz(src_xyz), w_sorted, N, k0, kb, C, L);
+            if (kb == 1)
+                hipLaunchKernelGGL((p2l_kernel<ID, 1>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev, cells, run_ptr, runs,
+                                   centers, lengths, make_xyz(src_xyz), w_sorted, N, k0, kb, C, L);
+            else
+                hipLaunchKernelGGL((p2l_kernel<ID, DIRECT_KB>), dim3(n_jobs), dim3(256), 0, s, ks, ch.dev, cells,
+                                   run_ptr, runs, centers, lengths, make_xyz(src_xyz), w_sorted, N, k0, kb, C, L);
         }
     });
 }
