@@ -1100,12 +1100,24 @@ def dense_sum(kernel_id, base_range, total_sill, targets, sources, weights, with
     w = np.asfortranarray(w)
     m, d = t.shape
     K = w.shape[1]
+    if K > 16:
+        raise ValueError("dense_sum handles at most 16 right-hand sides (use kernel_matrix)")
     out = np.zeros((m, K), order="F")
     grad = np.zeros((m, K * d), order="F") if with_grads else None
     lib().oracle_dense_sum(I32(kernel_id), F64(base_range), F64(total_sill), I32(d), I64(m),
                            _p(t), I64(s.shape[0]), _p(s), I32(K), _p(w), I64(w.shape[0]),
                            _p(out), I64(m), _p(grad), I64(m))
     return (out, grad) if with_grads else out
+
+
+def kernel_matrix(kernel_id, base_range, total_sill, targets, sources):
+    """A[i, j] = phi(t_i, s_j)  (get_a_matrix, ferreus_rbf_utils/src/utils.rs:288-312)"""
+    t = np.ascontiguousarray(np.atleast_2d(np.asarray(targets, dtype=np.float64)))
+    s = np.ascontiguousarray(np.atleast_2d(np.asarray(sources, dtype=np.float64)))
+    out = np.zeros((t.shape[0], s.shape[0]), order="F")
+    lib().oracle_kernel_matrix(I32(kernel_id), F64(base_range), F64(total_sill), I32(t.shape[1]), I64(t.shape[0]),
+                               _p(t), I64(s.shape[0]), _p(s), _p(out), I64(t.shape[0]))
+    return out
 
 
 def kernel_phi(kernel_id, r, base_range=1.0, total_sill=1.0):

@@ -240,6 +240,17 @@ void oracle_kernel_block(int id, double base_range, double total_sill, int d,
  * gradients grad[(k*d + a)*ldg + i] (layout [rhs0_dx, rhs0_dy, rhs0_dz, rhs1_dx..],
  * bbfmm.rs:431-433).  Dense builder in the reference:
  * ferreus_rbf_utils/src/utils.rs:288-312. */
+/* Kernel matrix A[i + j*ldo] = phi(t_i, s_j) (get_a_matrix, ferreus_rbf_utils/src/utils.rs:288-312) */
+void oracle_kernel_matrix(int id, double base_range, double total_sill, int d, int64_t nt, const double *tgt,
+                          int64_t ns, const double *src, double *out, int64_t ldo)
+{
+    kspec_t k = make_kspec(id, base_range, total_sill);
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < ns; ++j)
+        for (int64_t i = 0; i < nt; ++i) out[j * ldo + i] = kval_r2(&k, dist2(tgt + i * d, src + j * d, d));
+}
+
+/* at most 16 right-hand sides */
 void oracle_dense_sum(int id, double base_range, double total_sill, int d,
                       int64_t nt, const double *tgt, int64_t ns, const double *src,
                       int K, const double *w, int64_t ldw, double *out, int64_t ldo,
