@@ -84,7 +84,22 @@ SIGNATURES = {
     "bbfmm_schwarz_ddm_solver": (ctypes.c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_f64,
                                                 c_p, c_p, c_p, c_p, c_p]),
     "bbfmm_rbf_system_apply": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
+    "bbfmm_ddm_params_defaults": (None, [c_p]),
+    "bbfmm_ddm_build": (ctypes.c_int, [c_p, c_i64, c_i32, c_i64, c_p, c_p]),
+    "bbfmm_ddm_destroy": (None, [c_p]),
+    "bbfmm_ddm_num_levels": (c_i32, [c_p]),
+    "bbfmm_ddm_level_size": (c_i64, [c_p, c_i32]),
+    "bbfmm_ddm_level_points": (ctypes.c_int, [c_p, c_i32, c_p]),
+    "bbfmm_ddm_num_domains": (c_i64, [c_p, c_i32]),
+    "bbfmm_ddm_domain_size": (c_i64, [c_p, c_i32, c_i64]),
+    "bbfmm_ddm_domain": (ctypes.c_int, [c_p, c_i32, c_i64, c_p, c_p, c_p]),
 }
+
+
+class DdmParams(ctypes.Structure):
+    """bbfmm_ddm_params <-> DDMParams (ferreus_rbf/src/config.rs:42-69)."""
+    _fields_ = [("leaf_threshold", c_i64), ("overlap_quota", c_f64), ("coarse_ratio", c_f64),
+                ("coarse_threshold", c_i64)]
 
 # bbfmm_apply_fn, bbfmm_iteration_fn
 APPLY_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_p, ctypes.POINTER(c_f64), ctypes.POINTER(c_f64), c_i64)

@@ -321,3 +321,81 @@ int bbfmm_debug_get_coefficients(bbfmm_handle *h, char which, int32_t k, double 
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------ domain decomposition (host part)
+#include "ddm.hpp"
+struct bbfmm_ddm {
+    bbfmm::DdmTree tree;
+};
+extern "C" {
+void bbfmm_ddm_params_defaults(bbfmm_ddm_params *out) {
+    if (!out) return;
+    const bbfmm::DdmParams p;
+    out->leaf_threshold = p.leaf_threshold;
+    out->overlap_quota = p.overlap_quota;
+    out->coarse_ratio = p.coarse_ratio;
+    out->coarse_threshold = p.coarse_threshold;
+}
+int bbfmm_ddm_build(const double *points, int64_t n, int32_t d, int64_t ld, const bbfmm_ddm_params *params,
+                    bbfmm_ddm **out) {
+    if (!out) return BBFMM_BAD_ARGUMENT;
+    *out = nullptr;
+    bbfmm::DdmParams p;
+    if (params) {
+        p.leaf_threshold = params->leaf_threshold;
+        p.overlap_quota = params->overlap_quota;
+        p.coarse_ratio = params->coarse_ratio;
+        p.coarse_threshold = params->coarse_threshold;
+    }
+    bbfmm_ddm *t = new (std::nothrow) bbfmm_ddm();
+    if (!t) return BBFMM_DEVICE_ERROR;
+    int rc = BBFMM_BAD_ARGUMENT;
+    try {
+        rc = bbfmm::build_ddm_tree(points, n, d, ld, p, &t->tree);
+    } catch (...) {
+        rc = BBFMM_DEVICE_ERROR;
+    }
+    if (rc != BBFMM_OK) {
+        delete t;
+        return rc;
+    }
+    *out = t;
+    return BBFMM_OK;
+}
+void bbfmm_ddm_destroy(bbfmm_ddm *t) { delete t; }
+int32_t bbfmm_ddm_num_levels(const bbfmm_ddm *t) { return t ? static_cast<int32_t>(t->tree.levels.size()) : 0; }
+static const bbfmm::DdmLevel *ddm_level(const bbfmm_ddm *t, int32_t level) {
+    if (!t || level < 0 || level >= static_cast<int32_t>(t->tree.levels.size())) return nullptr;
+    return &t->tree.levels[static_cast<size_t>(level)];
+}
+int64_t bbfmm_ddm_level_size(const bbfmm_ddm *t, int32_t level) {
+    const bbfmm::DdmLevel *l = ddm_level(t, level);
+    return l ? static_cast<int64_t>(l->point_indices.size()) : -1;
+}
+int bbfmm_ddm_level_points(const bbfmm_ddm *t, int32_t level, int64_t *out) {
+    const bbfmm::DdmLevel *l = ddm_level(t, level);
+    if (!l || !out) return BBFMM_BAD_ARGUMENT;
+    std::copy(l->point_indices.begin(), l->point_indices.end(), out);
+    return BBFMM_OK;
+}
+int64_t bbfmm_ddm_num_domains(const bbfmm_ddm *t, int32_t level) {
+    const bbfmm::DdmLevel *l = ddm_level(t, level);
+    return l ? static_cast<int64_t>(l->leaves.size()) : -1;
+}
+int64_t bbfmm_ddm_domain_size(const bbfmm_ddm *t, int32_t level, int64_t domain) {
+    const bbfmm::DdmLevel *l = ddm_level(t, level);
+    if (!l || domain < 0 || domain >= static_cast<int64_t>(l->leaves.size())) return -1;
+    return static_cast<int64_t>(l->leaves[static_cast<size_t>(domain)].idx.size());
+}
+int bbfmm_ddm_domain(const bbfmm_ddm *t, int32_t level, int64_t domain, int64_t *indices, uint8_t *internal,
+                     double *extents) {
+    const bbfmm::DdmLevel *l = ddm_level(t, level);
+    if (!l || domain < 0 || domain >= static_cast<int64_t>(l->leaves.size())) return BBFMM_BAD_ARGUMENT;
+    const bbfmm::DdmDomain &dm = l->leaves[static_cast<size_t>(domain)];
+    if (indices) std::copy(dm.idx.begin(), dm.idx.end(), indices);
+    if (internal) std::copy(dm.internal.begin(), dm.internal.end(), internal);
+    if (extents) std::copy(dm.extents.begin(), dm.extents.end(), extents);
+    return BBFMM_OK;
+}
+} // extern "C"
+

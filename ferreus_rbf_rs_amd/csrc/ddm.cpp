@@ -1,0 +1,224 @@
+// See ddm.hpp.  Follows DDMTree::new (domain_decomposition.rs:67-347) with deterministic, threaded
+// loops: the median splits of a level are processed breadth first (VecDeque order), the per-leaf
+// coarse-point and overlap selection runs in parallel over the leaves (it only reads the
+// neighbours' internal points, which no leaf changes).
+#include "ddm.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <deque>
+#include <numeric>
+
+#include "../../include/ferreus_bbfmm_hip.h"
+#include "parallel.hpp"
+
+namespace bbfmm {
+namespace {
+
+struct Pts {
+    const double *p;
+    int64_t ld;
+    int d;
+    double at(int64_t i, int a) const { return p[a * ld + i]; }
+};
+
+void extents_of(const Pts &P, const std::vector<int64_t> &idx, std::vector<double> *e) { // utils.rs:196-228
+    const int d = P.d;
+    e->assign(static_cast<size_t>(2 * d), 0.0);
+    for (int a = 0; a < d; ++a) (*e)[a] = (*e)[a + d] = P.at(idx[0], a);
+    for (int64_t i : idx)
+        for (int a = 0; a < d; ++a) {
+            const double v = P.at(i, a);
+            if (v < (*e)[a]) (*e)[a] = v;
+            if (v > (*e)[a + d]) (*e)[a + d] = v;
+        }
+}
+
+double dist(const Pts &P, int64_t i, int64_t j) { // get_distance, utils.rs:263-284
+    double s = 0.0;
+    for (int a = 0; a < P.d; ++a) {
+        const double t = P.at(i, a) - P.at(j, a);
+        s += t * t;
+    }
+    return std::sqrt(s);
+}
+
+// farthest_point_sampling (common.rs:246-288) over the points `ids`; returns positions in ids
+std::vector<int64_t> farthest_point_sampling(const Pts &P, const std::vector<int64_t> &ids, int64_t wanted,
+                                             int64_t seed) {
+    const int64_t n = static_cast<int64_t>(ids.size());
+    std::vector<int64_t> sel;
+    sel.reserve(static_cast<size_t>(wanted));
+    std::vector<uint8_t> is_sel(static_cast<size_t>(n), 0);
+    std::vector<double> min_d(static_cast<size_t>(n), INFINITY);
+    sel.push_back(seed);
+    is_sel[seed] = 1;
+    for (int64_t k = 1; k < wanted; ++k) {
+        const int64_t last = sel.back();
+        for (int64_t i = 0; i < n; ++i) {
+            if (is_sel[i]) continue;
+            const double dd = dist(P, ids[last], ids[i]);
+            if (dd < min_d[i]) min_d[i] = dd;
+        }
+        int64_t far = 0;
+        double mx = -1.0;
+        for (int64_t i = 0; i < n; ++i)
+            if (!is_sel[i] && min_d[i] > mx) {
+                mx = min_d[i];
+                far = i;
+            }
+        sel.push_back(far);
+        is_sel[far] = 1;
+    }
+    return sel;
+}
+
+} // namespace
+
+int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmParams &prm, DdmTree *out) {
+    if (!pts || n < 1 || d < 1 || d > 3 || ld < n || prm.leaf_threshold < 1 || prm.coarse_threshold < 1 ||
+        !(prm.coarse_ratio > 0.0) || prm.overlap_quota < 0.0)
+        return BBFMM_BAD_ARGUMENT;
+    const Pts P{pts, ld, d};
+    out->d = d;
+    out->levels.clear();
+    std::vector<int64_t> active(static_cast<size_t>(n));
+    std::iota(active.begin(), active.end(), int64_t(0));
+
+    while (static_cast<int64_t>(active.size()) > prm.coarse_threshold) {
+        DdmLevel level;
+        level.point_indices = active;
+        // recursive median splits along the longest axis of a domain's own points (:96-162)
+        DdmDomain root;
+        root.idx = active;
+        extents_of(P, root.idx, &root.extents);
+        std::deque<DdmDomain> queue;
+        queue.push_back(std::move(root));
+        while (!queue.empty()) {
+            DdmDomain cur = std::move(queue.front());
+            queue.pop_front();
+            const int64_t np = static_cast<int64_t>(cur.idx.size());
+            std::vector<double> ext;
+            extents_of(P, cur.idx, &ext);
+            int axis = 0; // argmax (utils.rs:147-170): first value greater than the running maximum, from 0
+            double best = 0.0;
+            for (int a = 0; a < d; ++a)
+                if (ext[a + d] - ext[a] > best) {
+                    best = ext[a + d] - ext[a];
+                    axis = a;
+                }
+            std::vector<int64_t> order(static_cast<size_t>(np));
+            std::iota(order.begin(), order.end(), int64_t(0));
+            std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { // argsort: stable
+                return P.at(cur.idx[x], axis) < P.at(cur.idx[y], axis);
+            });
+            const int64_t mid = np / 2;
+            DdmDomain left, right;
+            for (int64_t k = 0; k < mid; ++k) left.idx.push_back(cur.idx[order[k]]);
+            for (int64_t k = mid; k < np; ++k) right.idx.push_back(cur.idx[order[k]]);
+            const double mid_coord = P.at(cur.idx[order[mid]], axis);
+            std::sort(left.idx.begin(), left.idx.end());
+            std::sort(right.idx.begin(), right.idx.end());
+            left.extents = cur.extents;
+            left.extents[axis + d] = mid_coord;
+            right.extents = cur.extents;
+            right.extents[axis] = mid_coord;
+            if (static_cast<double>(np) + static_cast<double>(np) * prm.overlap_quota >=
+                2.0 * static_cast<double>(prm.leaf_threshold)) {
+                queue.push_back(std::move(left));
+                queue.push_back(std::move(right));
+            } else {
+                left.internal.assign(left.idx.size(), 1);
+                right.internal.assign(right.idx.size(), 1);
+                level.leaves.push_back(std::move(left));
+                level.leaves.push_back(std::move(right));
+            }
+        }
+        const int64_t nl = static_cast<int64_t>(level.leaves.size());
+        const int64_t num_coarse = static_cast<int64_t>(
+            std::ceil(std::ceil(static_cast<double>(active.size()) * prm.coarse_ratio) / static_cast<double>(nl))); // :165-168
+
+        // per leaf: coarse points (farthest point sampling from the point closest to the centroid)
+        // and the overlap taken from the neighbouring leaves' internal points (:183-307)
+        std::vector<std::vector<int64_t>> internal(static_cast<size_t>(nl)), coarse(static_cast<size_t>(nl)),
+            overlap(static_cast<size_t>(nl));
+        for (int64_t i = 0; i < nl; ++i) internal[i] = level.leaves[i].idx; // all internal at this point
+        std::vector<int64_t> n_overlap(static_cast<size_t>(nl), 0);
+        parallel_for(nl, 1, [&](int64_t i) {
+            const DdmDomain &dom = level.leaves[i];
+            const std::vector<int64_t> &in = internal[i];
+            const int64_t ni = static_cast<int64_t>(in.size());
+            double c[3] = {0, 0, 0}; // get_centroid (:350-359)
+            for (int a = 0; a < d; ++a) {
+                double s = 0.0;
+                for (int64_t k = 0; k < ni; ++k) s += P.at(in[k], a);
+                c[a] = s / static_cast<double>(ni);
+            }
+            int64_t center = 0; // argmin (utils.rs:116-143): first minimum
+            double dmin = 0.0;
+            for (int64_t k = 0; k < ni; ++k) {
+                double s = 0.0;
+                for (int a = 0; a < d; ++a) {
+                    const double t = c[a] - P.at(in[k], a);
+                    s += t * t;
+                }
+                const double dd = std::sqrt(s);
+                if (k == 0 || dd < dmin) {
+                    dmin = dd;
+                    center = k;
+                }
+            }
+            const int64_t sample = std::min(ni, num_coarse);
+            for (int64_t pos : farthest_point_sampling(P, in, sample, center)) coarse[i].push_back(in[pos]);
+            std::sort(coarse[i].begin(), coarse[i].end());
+            // neighbours: leaves whose (closed) box intersects this one, self excluded (rtree.rs:76-88)
+            std::vector<int64_t> cand;
+            for (int64_t j = 0; j < nl; ++j) {
+                if (j == i) continue;
+                bool hit = true;
+                for (int a = 0; a < d && hit; ++a)
+                    hit = level.leaves[j].extents[a] <= dom.extents[a + d] &&
+                          level.leaves[j].extents[a + d] >= dom.extents[a];
+                if (!hit) continue;
+                cand.insert(cand.end(), internal[j].begin(), internal[j].end());
+            }
+            n_overlap[i] = static_cast<int64_t>(std::ceil(static_cast<double>(dom.idx.size() * 2) * prm.overlap_quota));
+            std::vector<double> bd(cand.size());
+            for (size_t k = 0; k < cand.size(); ++k) { // distance to the box (:268-287)
+                double s = 0.0;
+                for (int a = 0; a < d; ++a) {
+                    const double x = P.at(cand[k], a);
+                    const double cl = std::max(std::min(x, dom.extents[a + d]), dom.extents[a]);
+                    s += (x - cl) * (x - cl);
+                }
+                bd[k] = std::sqrt(s);
+            }
+            std::vector<int64_t> ord(cand.size());
+            std::iota(ord.begin(), ord.end(), int64_t(0));
+            std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return bd[x] < bd[y]; });
+            const size_t take = std::min<size_t>(static_cast<size_t>(n_overlap[i]), cand.size());
+            for (size_t k = 0; k < take; ++k) overlap[i].push_back(cand[ord[k]]);
+        });
+        std::vector<int64_t> next;
+        for (int64_t i = 0; i < nl; ++i) {
+            DdmDomain &dom = level.leaves[i];
+            dom.idx.insert(dom.idx.end(), overlap[i].begin(), overlap[i].end());
+            dom.internal.resize(dom.idx.size(), 0); // the overlap is never internal
+            next.insert(next.end(), coarse[i].begin(), coarse[i].end());
+        }
+        std::sort(next.begin(), next.end());
+        out->levels.push_back(std::move(level));
+        active.swap(next);
+    }
+    DdmLevel coarse_level; // one domain over the remaining points (:320-343)
+    coarse_level.point_indices = active;
+    DdmDomain cd;
+    cd.idx = active;
+    cd.internal.assign(active.size(), 1);
+    extents_of(P, cd.idx, &cd.extents);
+    coarse_level.leaves.push_back(std::move(cd));
+    out->levels.push_back(std::move(coarse_level));
+    return BBFMM_OK;
+}
+
+} // namespace bbfmm

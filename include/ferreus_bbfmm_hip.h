@@ -296,6 +296,32 @@ typedef struct bbfmm_rbf_system {
 } bbfmm_rbf_system;
 int bbfmm_rbf_system_apply(void *user, const double *x, double *y, int64_t n);
 
+/* ------------------------------------------------------------------ domain decomposition (host part)
+ * DDMTree::new (ferreus_rbf/src/preconditioning/domain_decomposition.rs:67-347), SURVEY.md 8(f)-1:
+ * the multi-level overlapping decomposition of the Schwarz preconditioner -- which points form which
+ * leaf domain on which level.  The local factorisations (domain.rs) and the apply (schwarz.rs) are
+ * not behind this ABI yet; the index sets are what they will run on. */
+typedef struct bbfmm_ddm bbfmm_ddm;
+typedef struct bbfmm_ddm_params { /* DDMParams, config.rs:42-69 */
+    int64_t leaf_threshold;   /* 1024 */
+    double overlap_quota;     /* 0.5 */
+    double coarse_ratio;      /* 0.125 */
+    int64_t coarse_threshold; /* 4096 */
+} bbfmm_ddm_params;
+void bbfmm_ddm_params_defaults(bbfmm_ddm_params *out);
+/* points: n x d column-major (ld); params NULL -> defaults */
+int bbfmm_ddm_build(const double *points, int64_t n, int32_t d, int64_t ld, const bbfmm_ddm_params *params,
+                    bbfmm_ddm **out);
+void bbfmm_ddm_destroy(bbfmm_ddm *t);
+int32_t bbfmm_ddm_num_levels(const bbfmm_ddm *t);                 /* finest first, coarse domain last */
+int64_t bbfmm_ddm_level_size(const bbfmm_ddm *t, int32_t level);  /* Level::point_indices.len() */
+int bbfmm_ddm_level_points(const bbfmm_ddm *t, int32_t level, int64_t *out);
+int64_t bbfmm_ddm_num_domains(const bbfmm_ddm *t, int32_t level); /* Level::leaf_domains.len() */
+int64_t bbfmm_ddm_domain_size(const bbfmm_ddm *t, int32_t level, int64_t domain);
+/* Domain::{overlapping_point_indices, internal_points_mask, extents [mins..., maxs...]} */
+int bbfmm_ddm_domain(const bbfmm_ddm *t, int32_t level, int64_t domain, int64_t *indices, uint8_t *internal,
+                     double *extents);
+
 #ifdef __cplusplus
 }
 #endif

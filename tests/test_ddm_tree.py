@@ -1,0 +1,67 @@
+"""Host part of the Schwarz preconditioner: the C++ domain decomposition behind the
+C ABI against the numpy restatement of domain_decomposition.rs -- index sets compared for exact
+equality (no GPU)."""
+import numpy as np
+import pytest
+
+from ferreus_rbf_rs_amd.ddm import DDMParams, DDMTree
+from oracle import ddm as D
+
+
+def _oracle_levels(pts, prm):
+    class NoFactor(D.Domain):                     # the decomposition only: skip the local factorisations
+        def factorise(self, *a, **k):
+            pass
+    saved = D.Domain
+    D.Domain = NoFactor
+    try:
+        st = D.InterpolantSettings(3, pts.shape[1])
+        return D.build_ddm_tree(pts, st, D.DDMParams(prm.leaf_threshold, prm.overlap_quota, prm.coarse_ratio,
+                                                     prm.coarse_threshold))
+    finally:
+        D.Domain = saved
+
+
+def _clustered(rng, n, d):
+    c = rng.random((6, d))
+    return np.clip(c[rng.integers(0, 6, n)] + 0.05 * rng.standard_normal((n, d)), 0.0, 1.0)
+
+
+@pytest.mark.parametrize("dim,n,prm,clustered", [
+    (1, 700, DDMParams(20, 0.5, 0.25, 60), False),
+    (2, 3000, DDMParams(50, 0.5, 0.125, 200), False),
+    (3, 6000, DDMParams(64, 0.5, 0.125, 256), False),
+    (3, 5000, DDMParams(100, 0.25, 0.2, 300), True),
+    (2, 2500, DDMParams(40, 1.0, 0.3, 100), True),
+])
+def test_decomposition_equals_the_restatement(dim, n, prm, clustered):
+    rng = np.random.default_rng(100 * dim + n)
+    pts = _clustered(rng, n, dim) if clustered else rng.random((n, dim))
+    tree = DDMTree(pts, prm)
+    ref = _oracle_levels(pts, prm)
+    assert len(tree.levels) == len(ref) >= 2
+    for lv, (a, b) in enumerate(zip(tree.levels, ref)):
+        assert list(a.point_indices) == list(b.point_indices), f"level {lv}"
+        assert len(a.leaf_domains) == len(b.leaf_domains)
+        for da, db in zip(a.leaf_domains, b.leaf_domains):
+            k = len(db.overlapping_point_indices)
+            assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
+            assert list(da.internal_points_mask) == [bool(m) for m in db.internal_points_mask[:k]]
+            if db.extents is not None:            # (the reference leaves the coarse domain's extents empty)
+                np.testing.assert_array_equal(da.extents, db.extents)
+    # the reference's structural test (domain_decomposition.rs:378-596) on the product tree
+    for lvl in tree.levels:
+        union = sorted(int(g) for dm in lvl.leaf_domains
+                       for g, m in zip(dm.overlapping_point_indices, dm.internal_points_mask) if m)
+        assert union == sorted(int(g) for g in lvl.point_indices)
+
+
+def test_defaults_and_bad_arguments():
+    prm = DDMParams()
+    assert (prm.leaf_threshold, prm.overlap_quota, prm.coarse_ratio, prm.coarse_threshold) == (1024, 0.5, 0.125, 4096)
+    pts = np.random.default_rng(1).random((5000, 3))
+    t = DDMTree(pts)                              # defaults: 5000 > 4096 -> one fine level + the coarse domain
+    assert len(t.levels) == 2 and len(t.levels[1].leaf_domains) == 1
+    assert len(t.levels[1].point_indices) <= 4096
+    with pytest.raises(ValueError):
+        DDMTree(np.zeros((10, 4)))
