@@ -93,7 +93,19 @@ SIGNATURES = {
     "bbfmm_ddm_num_domains": (c_i64, [c_p, c_i32]),
     "bbfmm_ddm_domain_size": (c_i64, [c_p, c_i32, c_i64]),
     "bbfmm_ddm_domain": (ctypes.c_int, [c_p, c_i32, c_i64, c_p, c_p, c_p]),
+    "bbfmm_schwarz_create": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64, c_p, c_p, c_p]),
+    "bbfmm_schwarz_destroy": (None, [c_p]),
+    "bbfmm_schwarz_basis_size": (c_i64, [c_p]),
+    "bbfmm_schwarz_num_levels": (c_i32, [c_p]),
+    "bbfmm_schwarz_monomial_matrix": (c_p, [c_p]),
+    "bbfmm_schwarz_apply": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
 }
+
+
+class Interpolant(ctypes.Structure):
+    """bbfmm_interpolant"""
+    _fields_ = [("kernel_type", c_i32), ("polynomial_degree", c_i32), ("nugget", c_f64), ("base_range", c_f64),
+                ("total_sill", c_f64)]
 
 
 class DdmParams(ctypes.Structure):

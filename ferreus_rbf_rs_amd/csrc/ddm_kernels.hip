@@ -1,0 +1,312 @@
+// Device kernels of the Schwarz preconditioner's local solvers (see ddm_solver.hpp): one workgroup
+// per leaf domain.  A domain's points are stored special points first (k of them), then the m
+// others; its reduced matrix  lhs = Q^T A11 Q + Q^T A12 + A21 Q + A22  (domain.rs:312-346) is m x m,
+// column-major, lower triangle used.
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "ddm_solver.hpp"
+
+namespace bbfmm {
+namespace {
+
+struct View {
+    const double *x, *y, *z;
+    const int64_t *gidx, *dom_off, *q_off, *fac_off;
+    const int32_t *k;
+    const uint8_t *internal;
+    const double *q;
+    double *t, *g, *fac, *work;
+};
+
+View make_view(const DdmLevelSolver &lv) {
+    return View{lv.d_xyz[0], lv.d_xyz[1], lv.d_xyz[2], lv.d_gidx, lv.d_dom_off, lv.d_q_off, lv.d_fac_off,
+                lv.d_k,      lv.d_internal, lv.d_q, lv.d_t, lv.d_g, lv.d_fac, lv.d_work};
+}
+
+template <int KID> __device__ inline double phi(const KernelSpec &ks, const View &v, int64_t a, int64_t b) {
+    const double dx = v.x[a] - v.x[b], dy = v.y[a] - v.y[b], dz = v.z[a] - v.z[b];
+    return kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
+}
+
+// T[a][j] = phi(s_a, x_j);  G[a][j] = T[a][j] + sum_b A11[a][b] Q[b][j],  A11 = phi(s, s) + nugget I
+template <int KID> __global__ __launch_bounds__(256) void ddm_prep_kernel(KernelSpec ks, double nugget, View v) {
+    const int dom = blockIdx.x;
+    const int64_t o = v.dom_off[dom];
+    const int k = v.k[dom], m = static_cast<int>(v.dom_off[dom + 1] - o) - k;
+    if (k == 0) return;
+    __shared__ double a11[16 * 16];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < k * k; e += 256) {
+        const int a = e / k, b = e % k;
+        a11[e] = phi<KID>(ks, v, o + a, o + b) + (a == b ? nugget : 0.0);
+    }
+    __syncthreads();
+    const double *Q = v.q + v.q_off[dom];
+    double *T = v.t + v.q_off[dom], *G = v.g + v.q_off[dom];
+    for (int e = tid; e < k * m; e += 256) {
+        const int a = e / m, j = e % m;
+        const double tv = phi<KID>(ks, v, o + a, o + k + j);
+        double w = 0.0;
+        for (int b = 0; b < k; ++b) w += a11[a * k + b] * Q[b * m + j];
+        T[e] = tv;
+        G[e] = tv + w;
+    }
+}
+
+// lhs[i][j] (i >= j) = phi(x_i, x_j) + nugget [i == j] + sum_a (Q[a][i] G[a][j] + T[a][i] Q[a][j])
+template <int KID> __global__ __launch_bounds__(256) void ddm_assemble_kernel(KernelSpec ks, double nugget, View v) {
+    const int dom = blockIdx.x;
+    const int64_t o = v.dom_off[dom];
+    const int k = v.k[dom], m = static_cast<int>(v.dom_off[dom + 1] - o) - k;
+    const double *Q = v.q + v.q_off[dom], *T = v.t + v.q_off[dom], *G = v.g + v.q_off[dom];
+    double *A = v.fac + v.fac_off[dom];
+    // blockIdx.y takes every gridDim.y-th column
+    for (int j = blockIdx.y; j < m; j += gridDim.y)
+        for (int i = j + threadIdx.x; i < m; i += 256) {
+            double s = phi<KID>(ks, v, o + k + i, o + k + j) + (i == j ? nugget : 0.0);
+            for (int a = 0; a < k; ++a) s += Q[a * m + i] * G[a * m + j] + T[a * m + i] * Q[a * m + j];
+            A[i + static_cast<int64_t>(j) * m] = s;
+        }
+}
+
+// In-place lower Cholesky, right-looking with 32-column panels; one workgroup per matrix.
+constexpr int NB = 32;
+__global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
+    const int dom = blockIdx.x;
+    const int64_t o = v.dom_off[dom];
+    const int m = static_cast<int>(v.dom_off[dom + 1] - o) - v.k[dom];
+    double *A = v.fac + v.fac_off[dom];
+    __shared__ double Ld[NB][NB + 1];
+    __shared__ double Pr[64][NB + 1], Pc[64][NB + 1];
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    if (tid == 0) bad = 0;
+    for (int jb = 0; jb < m; jb += NB) {
+        const int nb = min(NB, m - jb);
+        __syncthreads();
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e % nb, c = e / nb;
+            Ld[r][c] = r >= c ? A[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        }
+        __syncthreads();
+        for (int c = 0; c < nb; ++c) { // unblocked factorisation of the diagonal block
+            if (tid == 0) {
+                const double dd = Ld[c][c];
+                if (!(dd > 0.0)) bad = 1;
+                Ld[c][c] = sqrt(dd > 0.0 ? dd : 1.0);
+            }
+            __syncthreads();
+            if (tid > c && tid < nb) Ld[tid][c] /= Ld[c][c];
+            __syncthreads();
+            for (int e = tid; e < nb * nb; e += 256) {
+                const int r = e % nb, c2 = e / nb;
+                if (c2 > c && r >= c2) Ld[r][c2] -= Ld[r][c] * Ld[c2][c];
+            }
+            __syncthreads();
+        }
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e % nb, c = e / nb;
+            if (r >= c) A[(jb + r) + static_cast<int64_t>(jb + c) * m] = Ld[r][c];
+        }
+        // panel: rows below the block, X L11^T = A21
+        for (int r = jb + nb + tid; r < m; r += 256) {
+            double xr[NB];
+            for (int c = 0; c < nb; ++c) {
+                double s = A[r + static_cast<int64_t>(jb + c) * m];
+                for (int c2 = 0; c2 < c; ++c2) s -= xr[c2] * Ld[c][c2];
+                xr[c] = s / Ld[c][c];
+            }
+            for (int c = 0; c < nb; ++c) A[r + static_cast<int64_t>(jb + c) * m] = xr[c];
+        }
+        __threadfence_block();
+        __syncthreads();
+        // trailing update, lower part: A22 -= L21 L21^T in 64 x 64 tiles, 4 x 4 per thread
+        const int t0 = jb + nb;
+        const int tx = tid & 15, ty = tid >> 4;
+        for (int tr = t0; tr < m; tr += 64)
+            for (int tc = t0; tc <= tr; tc += 64) {
+                __syncthreads();
+                for (int e = tid; e < 64 * nb; e += 256) {
+                    const int r = e % 64, c = e / 64;
+                    Pr[r][c] = (tr + r < m) ? A[(tr + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+                    Pc[r][c] = (tc + r < m) ? A[(tc + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+                }
+                __syncthreads();
+                double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                for (int c = 0; c < nb; ++c) {
+                    double pr[4], pc[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        pr[u] = Pr[4 * ty + u][c];
+                        pc[u] = Pc[4 * tx + u][c];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+#pragma unroll
+                        for (int w = 0; w < 4; ++w) acc[u][w] += pr[u] * pc[w];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const int r = tr + 4 * ty + u, c = tc + 4 * tx + w;
+                        if (r < m && c < m && r >= c) A[r + static_cast<int64_t>(c) * m] -= acc[u][w];
+                    }
+            }
+        __threadfence_block();
+    }
+    __syncthreads();
+    if (tid == 0 && bad) atomicExch(fail, 1);
+}
+
+// Domain::solve (domain.rs:393-475) for one right-hand side: gather, rhs = Q^T d_s + d_ns,
+// L L^T gamma = rhs, lambda = [Q gamma; gamma], scatter.
+__global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__restrict__ values,
+                                                        double *__restrict__ out, int all_points) {
+    const int dom = blockIdx.x;
+    const int64_t o = v.dom_off[dom];
+    const int n = static_cast<int>(v.dom_off[dom + 1] - o), k = v.k[dom], m = n - k;
+    const double *Q = v.q + v.q_off[dom];
+    const double *L = v.fac + v.fac_off[dom];
+    double *w = v.work + o; // [d_s (k) | y (m)]
+    double *y = w + k;
+    __shared__ double yb[NB];
+    __shared__ double Ld[NB][NB + 1];
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n; e += 256) w[e] = values[v.gidx[o + e]];
+    __threadfence_block();
+    __syncthreads();
+    for (int j = tid; j < m; j += 256) {
+        double s = y[j];
+        for (int a = 0; a < k; ++a) s += Q[a * m + j] * w[a];
+        y[j] = s;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // forward substitution L z = rhs, 32 columns at a time: the diagonal block goes to LDS and is solved
+    // by one wave (column sweep, lane r owns row r), the rows below are updated by all threads
+    for (int jb = 0; jb < m; jb += NB) {
+        const int nb = min(NB, m - jb);
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e % nb, c = e / nb;
+            Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        }
+        if (tid < nb) yb[tid] = y[jb + tid];
+        __syncthreads();
+        if (tid < 64) {
+            for (int c = 0; c < nb; ++c) {
+                if (tid == c) yb[c] = yb[c] / Ld[c][c];
+                __builtin_amdgcn_wave_barrier();
+                if (tid > c && tid < nb) yb[tid] -= Ld[tid][c] * yb[c];
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (tid < nb) y[jb + tid] = yb[tid];
+        }
+        __syncthreads();
+        for (int r = jb + nb + tid; r < m; r += 256) {
+            double s = y[r];
+            for (int c = 0; c < nb; ++c) s -= L[r + static_cast<int64_t>(jb + c) * m] * yb[c];
+            y[r] = s;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    // back substitution L^T gamma = z: a wave reduces the part below the block for its columns, then
+    // one wave solves the transposed diagonal block (row sweep from the bottom)
+    const int wave = tid >> 6, lane = tid & 63;
+    for (int jb = ((m - 1) / NB) * NB; jb >= 0; jb -= NB) {
+        const int nb = min(NB, m - jb);
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e % nb, c = e / nb;
+            Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        }
+        for (int c = wave; c < nb; c += 4) {
+            double s = 0.0;
+            for (int r = jb + nb + lane; r < m; r += 64) s += L[r + static_cast<int64_t>(jb + c) * m] * y[r];
+            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+            if (lane == 0) yb[c] = y[jb + c] - s;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int c = nb - 1; c >= 0; --c) {
+                if (tid == c) yb[c] = yb[c] / Ld[c][c];
+                __builtin_amdgcn_wave_barrier();
+                if (tid < c) yb[tid] -= Ld[c][tid] * yb[c];
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (tid < nb) y[jb + tid] = yb[tid];
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    // lambda of the special points = Q gamma
+    for (int a = 0; a < k; ++a) {
+        double s = 0.0;
+        for (int j = tid; j < m; j += 256) s += Q[a * m + j] * y[j];
+        red[tid] = s;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) red[tid] += red[tid + st];
+            __syncthreads();
+        }
+        if (tid == 0) w[a] = red[0];
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int e = tid; e < n; e += 256)
+        if (all_points || v.internal[o + e]) out[v.gidx[o + e]] = w[e];
+}
+
+template <class F> void dispatch_rbf_kernel(int id, F &&f) { // the kernels the solver supports (interpolant_config.rs:30-36)
+    switch (id) {
+    case kLinear: f(std::integral_constant<int, kLinear>{}); break;
+    case kThinPlateSpline: f(std::integral_constant<int, kThinPlateSpline>{}); break;
+    case kCubic: f(std::integral_constant<int, kCubic>{}); break;
+    case kSpheroidal3: f(std::integral_constant<int, kSpheroidal3>{}); break;
+    case kSpheroidal5: f(std::integral_constant<int, kSpheroidal5>{}); break;
+    case kSpheroidal7: f(std::integral_constant<int, kSpheroidal7>{}); break;
+    case kSpheroidal9: f(std::integral_constant<int, kSpheroidal9>{}); break;
+    default: break;
+    }
+}
+
+} // namespace
+
+void launch_ddm_prep(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s) {
+    (void)d;
+    if (lv.n_dom == 0 || !lv.d_q) return;
+    const View v = make_view(lv);
+    dispatch_rbf_kernel(ks.id, [&](auto idc) {
+        constexpr int ID = decltype(idc)::value;
+        hipLaunchKernelGGL((ddm_prep_kernel<ID>), dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, ks, nugget, v);
+    });
+}
+
+void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s) {
+    (void)d;
+    if (lv.n_dom == 0) return;
+    const View v = make_view(lv);
+    const unsigned gy = lv.n_dom >= 512 ? 4 : 64; // few domains (the coarse one): split the columns wider
+    dispatch_rbf_kernel(ks.id, [&](auto idc) {
+        constexpr int ID = decltype(idc)::value;
+        hipLaunchKernelGGL((ddm_assemble_kernel<ID>), dim3(static_cast<unsigned>(lv.n_dom), gy), dim3(256), 0, s, ks,
+                           nugget, v);
+    });
+}
+
+void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
+    if (lv.n_dom == 0) return;
+    hipLaunchKernelGGL(ddm_cholesky_kernel, dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, make_view(lv), d_fail);
+}
+
+void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s) {
+    if (lv.n_dom == 0) return;
+    hipLaunchKernelGGL(ddm_solve_kernel, dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, make_view(lv), d_values,
+                       d_out, all_points ? 1 : 0);
+}
+
+} // namespace bbfmm

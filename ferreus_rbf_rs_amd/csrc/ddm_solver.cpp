@@ -1,0 +1,283 @@
+// See ddm_solver.hpp.
+#include "ddm_solver.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/ferreus_bbfmm_hip.h"
+#include "parallel.hpp"
+
+namespace bbfmm {
+namespace {
+
+// Column-pivoted Householder QR of a (rows x cols, row-major) copy: LAPACK dgeqp3's rule, the
+// remaining column of largest norm next (first of equals).  Returns the pivot order and |R_jj|.
+void pivoted_qr(std::vector<double> a, int rows, int cols, std::vector<int> *piv, std::vector<double> *rdiag) {
+    piv->resize(static_cast<size_t>(cols));
+    std::iota(piv->begin(), piv->end(), 0);
+    const int steps = std::min(rows, cols);
+    rdiag->assign(static_cast<size_t>(steps), 0.0);
+    auto A = [&](int r, int c) -> double & { return a[static_cast<size_t>(r) * cols + c]; };
+    for (int j = 0; j < steps; ++j) {
+        int best = j;
+        double bn = -1.0;
+        for (int c = j; c < cols; ++c) {
+            double s = 0.0;
+            for (int r = j; r < rows; ++r) s += A(r, c) * A(r, c);
+            if (s > bn) {
+                bn = s;
+                best = c;
+            }
+        }
+        if (best != j) {
+            for (int r = 0; r < rows; ++r) std::swap(A(r, j), A(r, best));
+            std::swap((*piv)[j], (*piv)[best]);
+        }
+        double norm = 0.0;
+        for (int r = j; r < rows; ++r) norm += A(r, j) * A(r, j);
+        norm = std::sqrt(norm);
+        (*rdiag)[j] = norm;
+        if (norm == 0.0) continue;
+        const double alpha = A(j, j) > 0.0 ? -norm : norm;
+        std::vector<double> v(static_cast<size_t>(rows - j));
+        for (int r = j; r < rows; ++r) v[r - j] = A(r, j);
+        v[0] -= alpha;
+        double vn = 0.0;
+        for (double x : v) vn += x * x;
+        if (vn == 0.0) continue;
+        for (int c = j; c < cols; ++c) {
+            double dotp = 0.0;
+            for (int r = j; r < rows; ++r) dotp += v[r - j] * A(r, c);
+            const double f = 2.0 * dotp / vn;
+            for (int r = j; r < rows; ++r) A(r, c) -= f * v[r - j];
+        }
+    }
+}
+
+// inverse of a small k x k matrix (row-major) by Gaussian elimination with partial pivoting
+bool invert_small(const std::vector<double> &m, int k, std::vector<double> *inv) {
+    std::vector<double> a(m);
+    inv->assign(static_cast<size_t>(k) * k, 0.0);
+    for (int i = 0; i < k; ++i) (*inv)[static_cast<size_t>(i) * k + i] = 1.0;
+    for (int c = 0; c < k; ++c) {
+        int p = c;
+        for (int r = c + 1; r < k; ++r)
+            if (std::fabs(a[static_cast<size_t>(r) * k + c]) > std::fabs(a[static_cast<size_t>(p) * k + c])) p = r;
+        if (a[static_cast<size_t>(p) * k + c] == 0.0) return false;
+        if (p != c)
+            for (int x = 0; x < k; ++x) {
+                std::swap(a[static_cast<size_t>(p) * k + x], a[static_cast<size_t>(c) * k + x]);
+                std::swap((*inv)[static_cast<size_t>(p) * k + x], (*inv)[static_cast<size_t>(c) * k + x]);
+            }
+        const double piv = a[static_cast<size_t>(c) * k + c];
+        for (int x = 0; x < k; ++x) {
+            a[static_cast<size_t>(c) * k + x] /= piv;
+            (*inv)[static_cast<size_t>(c) * k + x] /= piv;
+        }
+        for (int r = 0; r < k; ++r) {
+            if (r == c) continue;
+            const double f = a[static_cast<size_t>(r) * k + c];
+            if (f == 0.0) continue;
+            for (int x = 0; x < k; ++x) {
+                a[static_cast<size_t>(r) * k + x] -= f * a[static_cast<size_t>(c) * k + x];
+                (*inv)[static_cast<size_t>(r) * k + x] -= f * (*inv)[static_cast<size_t>(c) * k + x];
+            }
+        }
+    }
+    return true;
+}
+
+} // namespace
+
+int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_size, DdmDomain *dom, DomainPrep *out) {
+    *out = DomainPrep();
+    if (basis_size == 0) return BBFMM_OK;
+    const int n = static_cast<int>(dom->idx.size());
+    // get_cheb_cube_scaling_factors (common.rs:299-322) of the domain's points
+    for (int a = 0; a < d; ++a) {
+        double lo = pts[a * ld + dom->idx[0]], hi = lo;
+        for (int64_t i : dom->idx) {
+            lo = std::min(lo, pts[a * ld + i]);
+            hi = std::max(hi, pts[a * ld + i]);
+        }
+        out->tr[a] = (hi + lo) / 2.0;
+        out->sc[a] = (hi - lo) / 2.0;
+        if (out->sc[a] == 0.0) out->sc[a] = 1.0;
+    }
+    // evaluate_monomials (polynomials.rs:30-74), n x basis_size row-major
+    std::vector<double> mono(static_cast<size_t>(n) * basis_size, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double sx[3] = {0, 0, 0};
+        for (int a = 0; a < d; ++a) sx[a] = (pts[a * ld + dom->idx[i]] - out->tr[a]) / out->sc[a];
+        double *row = &mono[static_cast<size_t>(i) * basis_size];
+        row[0] = 1.0;
+        if (degree >= 1)
+            for (int a = 0; a < d; ++a) row[1 + a] = sx[a];
+        if (degree == 2) {
+            int c = 1 + d;
+            for (int a = 0; a < d; ++a)
+                for (int b = a; b < d; ++b) row[c++] = sx[a] * sx[b];
+        }
+    }
+    // rank and unisolvent columns (domain.rs:186-212)
+    std::vector<int> piv;
+    std::vector<double> rd;
+    pivoted_qr(mono, n, basis_size, &piv, &rd);
+    int rank = 0;
+    for (size_t j = 0; j < rd.size(); ++j)
+        if (std::fabs(rd[j]) > 1e-10 * std::fabs(rd[0])) ++rank;
+    if (rank == 0) return BBFMM_BAD_ARGUMENT;
+    out->k = rank;
+    out->cols.assign(piv.begin(), piv.begin() + rank);
+    std::sort(out->cols.begin(), out->cols.end());
+    // special points: pivoted QR of the transposed reduced monomial matrix (domain.rs:214-224)
+    std::vector<double> mt(static_cast<size_t>(rank) * n);
+    for (int a = 0; a < rank; ++a)
+        for (int i = 0; i < n; ++i) mt[static_cast<size_t>(a) * n + i] = mono[static_cast<size_t>(i) * basis_size + out->cols[a]];
+    std::vector<int> pivr;
+    pivoted_qr(mt, rank, n, &pivr, &rd);
+    std::vector<int> special(pivr.begin(), pivr.begin() + rank);
+    std::sort(special.begin(), special.end());
+    std::vector<uint8_t> is_sp(static_cast<size_t>(n), 0);
+    for (int sidx : special) is_sp[sidx] = 1;
+    std::vector<int> order(special);
+    for (int i = 0; i < n; ++i)
+        if (!is_sp[i]) order.push_back(i);
+    std::vector<int64_t> nidx(static_cast<size_t>(n));
+    std::vector<uint8_t> nint(static_cast<size_t>(n));
+    for (int i = 0; i < n; ++i) {
+        nidx[i] = dom->idx[order[i]];
+        nint[i] = dom->internal[order[i]];
+    }
+    dom->idx.swap(nidx);
+    dom->internal.swap(nint);
+    // Lagrange coefficients on the special points and Q = -(N_ns lag)^T (domain.rs:296-307)
+    out->sp_mono.resize(static_cast<size_t>(rank) * rank);
+    for (int a = 0; a < rank; ++a)
+        for (int c = 0; c < rank; ++c)
+            out->sp_mono[static_cast<size_t>(a) * rank + c] = mono[static_cast<size_t>(order[a]) * basis_size + out->cols[c]];
+    std::vector<double> lag;
+    if (!invert_small(out->sp_mono, rank, &lag)) return BBFMM_BAD_ARGUMENT;
+    const int m = n - rank;
+    out->q.assign(static_cast<size_t>(rank) * m, 0.0);
+    for (int j = 0; j < m; ++j) {
+        const double *row = &mono[static_cast<size_t>(order[rank + j]) * basis_size];
+        for (int a = 0; a < rank; ++a) {
+            double s = 0.0;
+            for (int c = 0; c < rank; ++c) s += row[out->cols[c]] * lag[static_cast<size_t>(c) * rank + a];
+            out->q[static_cast<size_t>(a) * m + j] = -s;
+        }
+    }
+    return BBFMM_OK;
+}
+
+#define DHIP(x)                                                                                                      \
+    do {                                                                                                             \
+        if ((x) != hipSuccess) return BBFMM_DEVICE_ERROR;                                                            \
+    } while (0)
+
+template <class T> static int up(T **dst, const std::vector<T> &v, hipStream_t s) {
+    *dst = nullptr;
+    if (v.empty()) return BBFMM_OK;
+    DHIP(hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(T)));
+    DHIP(hipMemcpyAsync(*dst, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return BBFMM_OK;
+}
+
+int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const KernelSpec &ks, double nugget,
+                    int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *lv) {
+    *lv = DdmLevelSolver();
+    lv->d = d;
+    lv->solve_for_poly = solve_for_poly;
+    const int64_t nd = static_cast<int64_t>(level->leaves.size());
+    lv->n_dom = nd;
+    lv->prep.resize(static_cast<size_t>(nd));
+    std::vector<int> rcs(static_cast<size_t>(nd), BBFMM_OK);
+    parallel_for(nd, 1, [&](int64_t i) {
+        rcs[i] = prepare_domain(pts, ld, d, degree, basis_size, &level->leaves[i], &lv->prep[i]);
+    });
+    for (int rc : rcs)
+        if (rc != BBFMM_OK) return rc;
+    lv->dom_off.assign(static_cast<size_t>(nd) + 1, 0);
+    lv->q_off.assign(static_cast<size_t>(nd) + 1, 0);
+    lv->fac_off.assign(static_cast<size_t>(nd) + 1, 0);
+    lv->k.resize(static_cast<size_t>(nd));
+    for (int64_t i = 0; i < nd; ++i) {
+        const int64_t n = static_cast<int64_t>(level->leaves[i].idx.size());
+        const int64_t kk = lv->prep[i].k, m = n - kk;
+        lv->k[i] = static_cast<int32_t>(kk);
+        lv->dom_off[i + 1] = lv->dom_off[i] + n;
+        lv->q_off[i + 1] = lv->q_off[i] + kk * m;
+        lv->fac_off[i + 1] = lv->fac_off[i] + m * m;
+        lv->max_m = std::max<int>(lv->max_m, static_cast<int>(m));
+    }
+    lv->n_entries = lv->dom_off[nd];
+    std::vector<double> xyz[3];
+    std::vector<uint8_t> internal(static_cast<size_t>(lv->n_entries));
+    lv->gidx_h.resize(static_cast<size_t>(lv->n_entries));
+    for (int a = 0; a < 3; ++a) xyz[a].assign(static_cast<size_t>(lv->n_entries), 0.0);
+    std::vector<double> q(static_cast<size_t>(lv->q_off[nd]));
+    parallel_for(nd, 1, [&](int64_t i) {
+        const DdmDomain &dom = level->leaves[i];
+        const int64_t o = lv->dom_off[i];
+        for (size_t e = 0; e < dom.idx.size(); ++e) {
+            lv->gidx_h[o + e] = dom.idx[e];
+            internal[o + e] = dom.internal[e];
+            for (int a = 0; a < d; ++a) xyz[a][o + e] = pts[a * ld + dom.idx[e]];
+        }
+        std::copy(lv->prep[i].q.begin(), lv->prep[i].q.end(), q.begin() + lv->q_off[i]);
+    });
+    int rc;
+    for (int a = 0; a < 3; ++a)
+        if ((rc = up(&lv->d_xyz[a], xyz[a], s)) != BBFMM_OK) return rc;
+    if ((rc = up(&lv->d_gidx, lv->gidx_h, s)) != BBFMM_OK) return rc;
+    if ((rc = up(&lv->d_dom_off, lv->dom_off, s)) != BBFMM_OK) return rc;
+    if ((rc = up(&lv->d_q_off, lv->q_off, s)) != BBFMM_OK) return rc;
+    if ((rc = up(&lv->d_fac_off, lv->fac_off, s)) != BBFMM_OK) return rc;
+    if ((rc = up(&lv->d_k, lv->k, s)) != BBFMM_OK) return rc;
+    if ((rc = up(&lv->d_internal, internal, s)) != BBFMM_OK) return rc;
+    if ((rc = up(&lv->d_q, q, s)) != BBFMM_OK) return rc;
+    if (!q.empty()) {
+        DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_t), q.size() * sizeof(double)));
+        DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_g), q.size() * sizeof(double)));
+    }
+    DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_fac), static_cast<size_t>(std::max<int64_t>(lv->fac_off[nd], 1)) * sizeof(double)));
+    DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_work), static_cast<size_t>(std::max<int64_t>(lv->n_entries, 1)) * sizeof(double)));
+    int *d_fail = nullptr;
+    DHIP(hipMalloc(reinterpret_cast<void **>(&d_fail), sizeof(int)));
+    DHIP(hipMemsetAsync(d_fail, 0, sizeof(int), s));
+    launch_ddm_prep(ks, nugget, d, *lv, s);
+    launch_ddm_assemble(ks, nugget, d, *lv, s);
+    launch_ddm_cholesky(*lv, d_fail, s);
+    int fail = 0;
+    DHIP(hipMemcpyAsync(&fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    (void)hipFree(d_fail);
+    DHIP(hipGetLastError());
+    return fail ? BBFMM_UNSUPPORTED : BBFMM_OK; // a local system that is not positive definite
+}
+
+void ddm_level_free(DdmLevelSolver *lv) {
+    for (int a = 0; a < 3; ++a) (void)hipFree(lv->d_xyz[a]);
+    (void)hipFree(lv->d_gidx);
+    (void)hipFree(lv->d_dom_off);
+    (void)hipFree(lv->d_q_off);
+    (void)hipFree(lv->d_fac_off);
+    (void)hipFree(lv->d_k);
+    (void)hipFree(lv->d_internal);
+    (void)hipFree(lv->d_q);
+    (void)hipFree(lv->d_t);
+    (void)hipFree(lv->d_g);
+    (void)hipFree(lv->d_fac);
+    (void)hipFree(lv->d_work);
+    *lv = DdmLevelSolver();
+}
+
+int ddm_level_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s) {
+    launch_ddm_solve(lv, d_values, d_out, all_points, s);
+    return hipGetLastError() == hipSuccess ? BBFMM_OK : BBFMM_DEVICE_ERROR;
+}
+
+} // namespace bbfmm

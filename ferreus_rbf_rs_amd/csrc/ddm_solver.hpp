@@ -1,0 +1,62 @@
+// Local solvers of the Schwarz preconditioner on the device:
+// Domain::factorise / Domain::solve (ferreus_rbf/src/domain.rs:153-475) for all leaf domains of a
+// level at once.  Host: monomials, pivoted QR, special points and Beatson's Q per domain
+// (rank <= 10 columns).  Device: assembly of Q^T A Q from the points, blocked Cholesky one
+// workgroup per domain, forward / back substitution per right-hand side.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include <hip/hip_runtime.h>
+
+#include "ddm.hpp"
+#include "kernels.hpp"
+
+namespace bbfmm {
+
+struct DomainPrep { // host result of the polynomial part of Domain::factorise (domain.rs:163-310)
+    int k = 0;                   // rank of the monomial basis on the domain = number of special points
+    std::vector<int> cols;       // the unisolvent monomial columns (ascending)
+    std::vector<double> q;       // Q top block, k x m row-major (m = points - k): -(L(x_j))_a
+    std::vector<double> sp_mono; // k x k special-point monomials, row-major (point, monomial)
+    double tr[3] = {0, 0, 0}, sc[3] = {1, 1, 1};
+};
+
+// Reorders dom->idx / dom->internal so that the special points come first (domain.rs:250-279).
+int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_size, DdmDomain *dom, DomainPrep *out);
+
+// All leaf domains of one level, factorised and resident on the device.
+struct DdmLevelSolver {
+    int d = 0;
+    int64_t n_dom = 0, n_entries = 0;
+    std::vector<int64_t> dom_off;  // n_dom + 1: first entry (point) of a domain
+    std::vector<int32_t> k;        // special points per domain
+    std::vector<int64_t> q_off;    // n_dom + 1: offsets into q / scratch (k*m doubles each)
+    std::vector<int64_t> fac_off;  // n_dom + 1: offsets into fac (m*m doubles each)
+    std::vector<DomainPrep> prep;  // host copies (polynomial recovery of the coarse domain)
+    std::vector<int64_t> gidx_h;   // global index per entry
+    bool solve_for_poly = false;
+    // device
+    double *d_xyz[3] = {nullptr, nullptr, nullptr}; // entries, domain order
+    int64_t *d_gidx = nullptr, *d_dom_off = nullptr, *d_q_off = nullptr, *d_fac_off = nullptr;
+    int32_t *d_k = nullptr;
+    uint8_t *d_internal = nullptr;
+    double *d_q = nullptr, *d_t = nullptr, *d_g = nullptr, *d_fac = nullptr;
+    double *d_work = nullptr; // n_entries: rhs / solution per entry
+    int max_m = 0;
+};
+
+int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const KernelSpec &ks, double nugget,
+                    int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *out);
+void ddm_level_free(DdmLevelSolver *lv);
+// values: global vector on the device (n_total); out: global vector on the device, rows of internal
+// points (all points when `all_points`) receive the domain coefficients, other rows are left alone.
+int ddm_level_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s);
+
+// launchers (ddm_kernels.hip)
+void launch_ddm_prep(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s);
+void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s);
+void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s);
+void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s);
+
+} // namespace bbfmm

@@ -1,0 +1,274 @@
+// The overlapping Schwarz preconditioner of ferreus_rbf (preconditioning/schwarz.rs:32-155) behind the
+// C ABI: restricted additive Schwarz inside a level (local solves on the device, ddm_solver.hpp),
+// multiplicative between the levels with the coarse domain as smoother, two partial matvecs per fine
+// level through the BBFMM tree (IterativeSolver::precon, rbf.rs:140-155).  SURVEY.md 8(f)-1.
+// Vectors are host arrays (the FGMRES driver is a host driver); the residual of a level goes to the
+// device for the batched local solves and the correction comes back.
+#include "../../include/ferreus_bbfmm_hip.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <new>
+#include <vector>
+
+#include "ddm.hpp"
+#include "ddm_solver.hpp"
+#include "parallel.hpp"
+
+namespace {
+using namespace bbfmm;
+
+struct Schwarz {
+    bbfmm_handle *tree = nullptr;
+    int64_t n = 0;
+    int d = 0, degree = -1, basis = 0;
+    double nugget = 0.0;
+    KernelSpec ks{};
+    DdmTree ddm;
+    std::vector<DdmLevelSolver> levels;
+    std::vector<double> mono;  // N x basis column-major, the solver's global monomial matrix (rbf.rs:485-491)
+    std::vector<double> ortho; // N x basis column-major, thin Q of mono (rbf.rs:493-495)
+    std::vector<double> a_special; // coarse domain: k x n_coarse rows of A (domain.rs:352-355), row-major
+    std::vector<double> coarse_xyz; // coarse domain points (domain order), 3 x n_c
+    hipStream_t stream = nullptr;
+    double *d_in = nullptr, *d_out = nullptr;
+    std::vector<double> res, tmp, s1;
+    ~Schwarz() {
+        for (auto &lv : levels) ddm_level_free(&lv);
+        if (d_in) (void)hipFree(d_in);
+        if (d_out) (void)hipFree(d_out);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+int partial_matvec(Schwarz &S, const double *w, const std::vector<int64_t> &idx, double *y) {
+    return bbfmm_fast_matrix_vector_product(S.tree, w, S.n + S.basis, S.basis, idx.data(),
+                                            static_cast<int64_t>(idx.size()), S.basis ? S.mono.data() : nullptr,
+                                            S.n, S.nugget, y);
+}
+
+// res = rg - matvec(sl, rows idx); then the level's local solves into s1 (zero elsewhere)
+int level_correction(Schwarz &S, size_t li, const double *rg, const double *sl, bool coarse, bool add_poly) {
+    const int64_t nt = S.n + S.basis;
+    const DdmLevel &L = S.ddm.levels[li];
+    int rc = partial_matvec(S, sl, L.point_indices, S.tmp.data());
+    if (rc) return rc;
+    parallel_for_chunks(nt, 1 << 16, [&](int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) S.res[i] = rg[i] - S.tmp[i];
+    });
+    if (hipMemcpyAsync(S.d_in, S.res.data(), static_cast<size_t>(S.n) * sizeof(double), hipMemcpyHostToDevice, S.stream) != hipSuccess ||
+        hipMemsetAsync(S.d_out, 0, static_cast<size_t>(S.n) * sizeof(double), S.stream) != hipSuccess)
+        return BBFMM_DEVICE_ERROR;
+    rc = ddm_level_solve(S.levels[li], S.d_in, S.d_out, coarse, S.stream);
+    if (rc) return rc;
+    if (hipMemcpyAsync(S.s1.data(), S.d_out, static_cast<size_t>(S.n) * sizeof(double), hipMemcpyDeviceToHost, S.stream) != hipSuccess ||
+        hipStreamSynchronize(S.stream) != hipSuccess)
+        return BBFMM_DEVICE_ERROR;
+    for (int64_t i = S.n; i < nt; ++i) S.s1[i] = 0.0;
+    if (!coarse) {
+        if (S.basis) { // orthogonalise against the global polynomial basis (schwarz.rs:113-126)
+            std::vector<double> proj(static_cast<size_t>(S.basis), 0.0);
+            for (int b = 0; b < S.basis; ++b) {
+                double s = 0.0;
+                const double *q = &S.ortho[static_cast<size_t>(b) * S.n];
+                for (int64_t i = 0; i < S.n; ++i) s += q[i] * S.s1[i];
+                proj[b] = s;
+            }
+            parallel_for_chunks(S.n, 1 << 16, [&](int64_t bb, int64_t e) {
+                for (int64_t i = bb; i < e; ++i) {
+                    double s = 0.0;
+                    for (int b = 0; b < S.basis; ++b) s += S.ortho[static_cast<size_t>(b) * S.n + i] * proj[b];
+                    S.s1[i] -= s;
+                }
+            });
+        }
+        return BBFMM_OK;
+    }
+    // coarse domain: polynomial 'tail' (schwarz.rs:145-151, domain.rs:452-472)
+    const DdmLevelSolver &lv = S.levels[li];
+    if (lv.solve_for_poly && add_poly && S.basis) {
+        const DomainPrep &pp = lv.prep[0];
+        const int k = pp.k;
+        const int64_t nc = static_cast<int64_t>(lv.gidx_h.size());
+        std::vector<double> r(static_cast<size_t>(k));
+        for (int a = 0; a < k; ++a) {
+            double s = S.res[lv.gidx_h[a]];
+            const double *row = &S.a_special[static_cast<size_t>(a) * nc];
+            for (int64_t j = 0; j < nc; ++j) s -= row[j] * S.s1[lv.gidx_h[j]];
+            r[a] = s;
+        }
+        // solve sp_mono * poly = r (k x k, partial pivoting)
+        std::vector<double> a(pp.sp_mono), x(r);
+        for (int c = 0; c < k; ++c) {
+            int p = c;
+            for (int rr = c + 1; rr < k; ++rr)
+                if (std::fabs(a[static_cast<size_t>(rr) * k + c]) > std::fabs(a[static_cast<size_t>(p) * k + c])) p = rr;
+            if (p != c) {
+                for (int q = 0; q < k; ++q) std::swap(a[static_cast<size_t>(p) * k + q], a[static_cast<size_t>(c) * k + q]);
+                std::swap(x[p], x[c]);
+            }
+            for (int rr = c + 1; rr < k; ++rr) {
+                const double f = a[static_cast<size_t>(rr) * k + c] / a[static_cast<size_t>(c) * k + c];
+                for (int q = c; q < k; ++q) a[static_cast<size_t>(rr) * k + q] -= f * a[static_cast<size_t>(c) * k + q];
+                x[rr] -= f * x[c];
+            }
+        }
+        for (int c = k - 1; c >= 0; --c) {
+            double s = x[c];
+            for (int q = c + 1; q < k; ++q) s -= a[static_cast<size_t>(c) * k + q] * x[q];
+            x[c] = s / a[static_cast<size_t>(c) * k + c];
+        }
+        // sc.subrows_mut(idx_offset, num_poly) <- poly coefficients (schwarz.rs:146-151)
+        for (int a2 = 0; a2 < k; ++a2) S.s1[nt - k + a2] = x[a2];
+    }
+    return BBFMM_OK;
+}
+
+} // namespace
+
+struct bbfmm_schwarz {
+    Schwarz s;
+};
+
+extern "C" {
+
+int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
+                         const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, bbfmm_schwarz **out) {
+    if (!out) return BBFMM_BAD_ARGUMENT;
+    *out = nullptr;
+    if (!tree || !points || !settings || n < 1 || d < 1 || d > 3 || ld < n) return BBFMM_BAD_ARGUMENT;
+    if (settings->kernel_type < 0 || settings->kernel_type > 6 || settings->polynomial_degree < -1 ||
+        settings->polynomial_degree > 2)
+        return BBFMM_BAD_ARGUMENT;
+    std::unique_ptr<bbfmm_schwarz> h(new (std::nothrow) bbfmm_schwarz());
+    if (!h) return BBFMM_DEVICE_ERROR;
+    Schwarz &S = h->s;
+    S.tree = tree;
+    S.n = n;
+    S.d = d;
+    S.degree = settings->polynomial_degree;
+    S.nugget = settings->nugget;
+    S.ks = make_kernel_spec(settings->kernel_type, settings->base_range, settings->total_sill);
+    const int kk = S.degree + 1; // set_basis_size, interpolant_config.rs:150-178
+    S.basis = S.degree < 0 ? 0 : (d == 1 ? kk : (d == 2 ? kk * (kk + 1) / 2 : kk * (kk + 1) * (kk + 2) / 6));
+    DdmParams p;
+    if (params) {
+        p.leaf_threshold = params->leaf_threshold;
+        p.overlap_quota = params->overlap_quota;
+        p.coarse_ratio = params->coarse_ratio;
+        p.coarse_threshold = params->coarse_threshold;
+    }
+    int rc = build_ddm_tree(points, n, d, ld, p, &S.ddm);
+    if (rc) return rc;
+    if (hipStreamCreate(&S.stream) != hipSuccess) return BBFMM_DEVICE_ERROR;
+    // global monomial matrix on the cube-scaled points and its thin Q (rbf.rs:418-421, 476-495)
+    if (S.basis) {
+        double tr[3] = {0, 0, 0}, sc[3] = {1, 1, 1};
+        for (int a = 0; a < d; ++a) {
+            double lo = points[a * ld], hi = lo;
+            for (int64_t i = 0; i < n; ++i) {
+                lo = std::min(lo, points[a * ld + i]);
+                hi = std::max(hi, points[a * ld + i]);
+            }
+            tr[a] = (hi + lo) / 2.0;
+            sc[a] = (hi - lo) / 2.0;
+            if (sc[a] == 0.0) sc[a] = 1.0;
+        }
+        S.mono.assign(static_cast<size_t>(n) * S.basis, 0.0);
+        for (int64_t i = 0; i < n; ++i) {
+            double sx[3] = {0, 0, 0};
+            for (int a = 0; a < d; ++a) sx[a] = (points[a * ld + i] - tr[a]) / sc[a];
+            S.mono[i] = 1.0;
+            if (S.degree >= 1)
+                for (int a = 0; a < d; ++a) S.mono[static_cast<size_t>(1 + a) * n + i] = sx[a];
+            if (S.degree == 2) {
+                int c = 1 + d;
+                for (int a = 0; a < d; ++a)
+                    for (int b = a; b < d; ++b) S.mono[static_cast<size_t>(c++) * n + i] = sx[a] * sx[b];
+            }
+        }
+        S.ortho = S.mono; // modified Gram-Schmidt, twice
+        for (int pass = 0; pass < 2; ++pass)
+            for (int b = 0; b < S.basis; ++b) {
+                double *qb = &S.ortho[static_cast<size_t>(b) * n];
+                for (int c = 0; c < b; ++c) {
+                    const double *qc = &S.ortho[static_cast<size_t>(c) * n];
+                    double s = 0.0;
+                    for (int64_t i = 0; i < n; ++i) s += qc[i] * qb[i];
+                    for (int64_t i = 0; i < n; ++i) qb[i] -= s * qc[i];
+                }
+                double nn = 0.0;
+                for (int64_t i = 0; i < n; ++i) nn += qb[i] * qb[i];
+                nn = std::sqrt(nn);
+                if (nn == 0.0) return BBFMM_BAD_ARGUMENT;
+                for (int64_t i = 0; i < n; ++i) qb[i] /= nn;
+            }
+    }
+    S.levels.resize(S.ddm.levels.size());
+    for (size_t li = 0; li < S.ddm.levels.size(); ++li) {
+        const bool coarse = li + 1 == S.ddm.levels.size();
+        rc = ddm_level_build(points, ld, d, &S.ddm.levels[li], S.ks, S.nugget, S.degree, S.basis, coarse && S.basis != 0,
+                             S.stream, &S.levels[li]);
+        if (rc) return rc;
+    }
+    if (S.basis) { // rows of A for the coarse domain's special points (domain.rs:352-355)
+        const DdmLevelSolver &lv = S.levels.back();
+        const int k = lv.prep[0].k;
+        const int64_t nc = static_cast<int64_t>(lv.gidx_h.size());
+        S.a_special.assign(static_cast<size_t>(k) * nc, 0.0);
+        for (int a = 0; a < k; ++a)
+            for (int64_t j = 0; j < nc; ++j) {
+                double r2 = 0.0;
+                for (int ax = 0; ax < d; ++ax) {
+                    const double t = points[ax * ld + lv.gidx_h[a]] - points[ax * ld + lv.gidx_h[j]];
+                    r2 += t * t;
+                }
+                S.a_special[static_cast<size_t>(a) * nc + j] = kernel_value_r2_rt(S.ks, r2) + (a == j ? S.nugget : 0.0);
+            }
+    }
+    if (hipMalloc(reinterpret_cast<void **>(&S.d_in), static_cast<size_t>(n) * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&S.d_out), static_cast<size_t>(n) * sizeof(double)) != hipSuccess)
+        return BBFMM_DEVICE_ERROR;
+    S.res.assign(static_cast<size_t>(n + S.basis), 0.0);
+    S.tmp.assign(static_cast<size_t>(n + S.basis), 0.0);
+    S.s1.assign(static_cast<size_t>(n + S.basis), 0.0);
+    *out = h.release();
+    return BBFMM_OK;
+}
+
+void bbfmm_schwarz_destroy(bbfmm_schwarz *h) { delete h; }
+
+int64_t bbfmm_schwarz_basis_size(const bbfmm_schwarz *h) { return h ? h->s.basis : -1; }
+int32_t bbfmm_schwarz_num_levels(const bbfmm_schwarz *h) { return h ? static_cast<int32_t>(h->s.ddm.levels.size()) : 0; }
+const double *bbfmm_schwarz_monomial_matrix(const bbfmm_schwarz *h) { return (h && h->s.basis) ? h->s.mono.data() : nullptr; }
+
+// schwarz_preconditioner (schwarz.rs:32-82) as a bbfmm_apply_fn: user = bbfmm_schwarz*, n = N + basis
+int bbfmm_schwarz_apply(void *user, const double *rg, double *sl, int64_t n) {
+    bbfmm_schwarz *h = static_cast<bbfmm_schwarz *>(user);
+    if (!h || !rg || !sl || n != h->s.n + h->s.basis) return BBFMM_BAD_ARGUMENT;
+    Schwarz &S = h->s;
+    std::memset(sl, 0, static_cast<size_t>(n) * sizeof(double));
+    const size_t coarse = S.ddm.levels.size() - 1;
+    auto add = [&]() {
+        parallel_for_chunks(n, 1 << 16, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i) sl[i] += S.s1[i];
+        });
+    };
+    int rc;
+    if (coarse > 0) {
+        for (size_t i = 0; i < coarse; ++i) {
+            if ((rc = level_correction(S, i, rg, sl, false, false))) return rc;
+            add();
+            if ((rc = level_correction(S, coarse, rg, sl, true, i == coarse - 1))) return rc;
+            add();
+        }
+    } else {
+        if ((rc = level_correction(S, coarse, rg, sl, true, true))) return rc;
+        add();
+    }
+    return BBFMM_OK;
+}
+
+} // extern "C"

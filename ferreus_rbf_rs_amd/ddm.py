@@ -72,3 +72,70 @@ class DDMTree:
                 self.levels.append(Level(pi, doms))
         finally:
             lib.bbfmm_ddm_destroy(h)
+
+
+class InterpolantSettings:
+    """InterpolantSettings (interpolant_config.rs:118-190) as the solver reads it.  kernel_type: a
+    KernelType of the RBF family (Linear, ThinPlateSpline, Cubic, Spheroidal3/5/7/9); drift: None ->
+    the kernel's minimum (get_min_drift), else -1 none / 0 constant / 1 linear / 2 quadratic."""
+
+    _MIN = {0: 0, 1: 1, 2: 1}
+
+    def __init__(self, kernel_type, dimensions: int, drift: Optional[int] = None, nugget: float = 0.0,
+                 base_range: float = 1.0, total_sill: float = 1.0):
+        self.kernel_type = int(kernel_type)
+        if not 0 <= self.kernel_type <= 6:
+            raise ValueError("the solver supports the RBF kernels only (Linear, ThinPlateSpline, Cubic, Spheroidal)")
+        mn = self._MIN.get(self.kernel_type, -1)
+        self.polynomial_degree = mn if drift is None else int(drift)
+        if self.polynomial_degree < mn:
+            raise ValueError(f"Min degree for kernel: {mn}")              # interpolant_config.rs:173
+        k = self.polynomial_degree + 1
+        self.basis_size = 0 if k <= 0 else {1: k, 2: k * (k + 1) // 2, 3: k * (k + 1) * (k + 2) // 6}[dimensions]
+        self.nugget, self.base_range, self.total_sill = float(nugget), float(base_range), float(total_sill)
+
+
+class SchwarzPreconditioner:
+    """schwarz_preconditioner (preconditioning/schwarz.rs:32-155) with the local solves batched on
+    the device.  `tree`: an FmmTree over the same points / kernel (serves matvec_partial).  Use it
+    as the `m` of solvers.fgmres, or call it on a residual of N + basis_size values."""
+
+    def __init__(self, tree, points, settings: InterpolantSettings, ddm_params: Optional[DDMParams] = None):
+        pts = np.asfortranarray(np.atleast_2d(np.asarray(points, dtype=np.float64)))
+        n, d = pts.shape
+        lib = L.load()
+        st = L.Interpolant(settings.kernel_type, settings.polynomial_degree, settings.nugget, settings.base_range,
+                           settings.total_sill)
+        prm = (ddm_params or DDMParams())._c()
+        h = ctypes.c_void_p()
+        rc = lib.bbfmm_schwarz_create(tree._h, pts.ctypes.data, n, d, n, ctypes.byref(st), ctypes.byref(prm),
+                                      ctypes.byref(h))
+        if rc != L.OK:
+            raise ValueError(f"bbfmm_schwarz_create failed with status {rc}"
+                             + (" (a local system is not positive definite)" if rc == L.UNSUPPORTED else ""))
+        self._h, self._lib, self._tree = h, lib, tree
+        self.n = n
+        self.basis_size = int(lib.bbfmm_schwarz_basis_size(h))
+        self.num_levels = int(lib.bbfmm_schwarz_num_levels(h))
+        mp = lib.bbfmm_schwarz_monomial_matrix(h)
+        self.monomial_matrix = None
+        if mp:
+            buf = (ctypes.c_double * (n * self.basis_size)).from_address(mp)
+            self.monomial_matrix = np.frombuffer(buf, dtype=np.float64).reshape((n, self.basis_size), order="F").copy(order="F")
+        from .solvers import _Operator
+        self._op = _Operator(ctypes.cast(lib.bbfmm_schwarz_apply, ctypes.c_void_p), h, (self,))
+        self._op.errors = []
+
+    def __call__(self, residual):
+        r = np.ascontiguousarray(residual, dtype=np.float64).reshape(-1)
+        z = np.zeros_like(r)
+        rc = self._lib.bbfmm_schwarz_apply(self._h, r.ctypes.data, z.ctypes.data, r.size)
+        if rc != L.OK:
+            raise RuntimeError(f"bbfmm_schwarz_apply failed with status {rc}")
+        return z
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._lib.bbfmm_schwarz_destroy(h)
+            self._h = None

@@ -94,8 +94,8 @@ class RbfSystemOperator:
 def _as_operator(f) -> Optional[_Operator]:
     if f is None:
         return None
-    if isinstance(f, RbfSystemOperator):
-        return f._op
+    if isinstance(f, RbfSystemOperator) or isinstance(getattr(f, "_op", None), _Operator):
+        return f._op                      # natively bound operators (system matvec, Schwarz preconditioner)
     return _wrap_callable(f)
 
 

@@ -322,6 +322,29 @@ int64_t bbfmm_ddm_domain_size(const bbfmm_ddm *t, int32_t level, int64_t domain)
 int bbfmm_ddm_domain(const bbfmm_ddm *t, int32_t level, int64_t domain, int64_t *indices, uint8_t *internal,
                      double *extents);
 
+/* ------------------------------------------------------------------ Schwarz preconditioner
+ * schwarz_preconditioner (ferreus_rbf/src/preconditioning/schwarz.rs:32-155) with Domain::factorise /
+ * Domain::solve (domain.rs:153-475) for all leaf domains of a level batched on the device: Beatson's Q
+ * formulation, Q^T A Q assembled from the points, blocked Cholesky and substitutions one workgroup
+ * per domain.  The two partial matvecs per fine level go through `tree`
+ * (IterativeSolver::precon, rbf.rs:140-155).  Global trend transforms are not supported. */
+typedef struct bbfmm_schwarz bbfmm_schwarz;
+typedef struct bbfmm_interpolant { /* InterpolantSettings, interpolant_config.rs:118-147, as the solver reads it */
+    int32_t kernel_type;       /* bbfmm_kernel_type 0..6 (Linear, ThinPlateSpline, Cubic, Spheroidal3/5/7/9) */
+    int32_t polynomial_degree; /* -1 none, 0 constant, 1 linear, 2 quadratic (Drift) */
+    double nugget, base_range, total_sill;
+} bbfmm_interpolant;
+/* tree: a handle over the same points, kernel and ranges (it serves matvec_partial); it must outlive
+ * the preconditioner.  params NULL -> DDMParams defaults. */
+int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
+                         const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, bbfmm_schwarz **out);
+void bbfmm_schwarz_destroy(bbfmm_schwarz *h);
+int64_t bbfmm_schwarz_basis_size(const bbfmm_schwarz *h);           /* InterpolantSettings::basis_size */
+int32_t bbfmm_schwarz_num_levels(const bbfmm_schwarz *h);
+const double *bbfmm_schwarz_monomial_matrix(const bbfmm_schwarz *h); /* N x basis column-major (rbf.rs:485-491) or NULL */
+/* a bbfmm_apply_fn: user = bbfmm_schwarz*, vectors of N + basis_size doubles */
+int bbfmm_schwarz_apply(void *user, const double *residual, double *correction, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+"""The Schwarz preconditioner with device-batched local solves against the numpy
+restatement of schwarz.rs / domain.rs (oracle/ddm.py, dense system) and end to end inside FGMRES."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import ferreus_rbf_rs_amd as F
+from ferreus_rbf_rs_amd import solvers as S
+from ferreus_rbf_rs_amd.ddm import DDMParams, InterpolantSettings, SchwarzPreconditioner
+from oracle import ddm as D
+from oracle import solvers as OS
+
+
+def _dense_partial(pts, st):
+    n = pts.shape[0]
+    A = D.a_matrix(pts, st)
+    tr, sc = D.cheb_cube_scaling_factors(pts)
+    P = D.evaluate_monomials(pts, st.polynomial_degree, st.basis_size, tr, sc) if st.basis_size else None
+    m = st.basis_size
+
+    def partial(w, idx):
+        y = np.zeros(n + m)
+        idx = np.asarray(idx)
+        y[idx] = A[idx] @ w[:n] + (P[idx] @ w[n:] if m else 0.0)
+        return y
+    return A, P, partial
+
+
+CASES = [  # kernel id, dims, drift, nugget, base_range/sill
+    (0, 3, None, 0.0, 1.0),
+    (0, 3, 1, 0.0, 1.0),
+    (1, 2, None, 0.0, 1.0),
+    (2, 3, None, 0.0, 1.0),
+    (3, 3, None, 0.02, 0.3),
+]
+
+
+@pytest.mark.parametrize("kid,dim,drift,nugget,rng_", CASES)
+def test_apply_matches_the_restatement(kid, dim, drift, nugget, rng_):
+    rng = np.random.default_rng(50 + kid + dim)
+    n = 2500
+    pts = rng.random((n, dim))
+    prm = DDMParams(80, 0.5, 0.125, 250)
+    st = InterpolantSettings(kid, dim, drift=drift, nugget=nugget, base_range=rng_, total_sill=rng_)
+    tree = F.FmmTree(pts, 8, F.KernelParams(F.KernelType(kid), base_range=rng_, total_sill=rng_), True, True)
+    pre = SchwarzPreconditioner(tree, pts, st, prm)
+    ost = D.InterpolantSettings(kid, dim, drift=drift, nugget=nugget, base_range=rng_, total_sill=rng_)
+    assert pre.basis_size == ost.basis_size
+    levels = D.build_ddm_tree(pts, ost, D.DDMParams(80, 0.5, 0.125, 250))
+    assert pre.num_levels == len(levels) >= 2
+    A, P, partial = _dense_partial(pts, ost)
+    ortho = None
+    if ost.basis_size:
+        tr, sc = D.cheb_cube_scaling_factors(pts)
+        mono, ortho = D.orthonormal_poly(pts, ost, tr, sc)
+        np.testing.assert_allclose(pre.monomial_matrix, mono, rtol=0, atol=1e-14)
+    r = rng.standard_normal(n + ost.basis_size)
+    r[n:] = 0.0
+    z = pre(r)
+    zo = D.schwarz_preconditioner(r, levels, partial, ost, ortho)
+    # the FMM matvec inside (order 8, ~1e-8) is the only difference between the two; the cubic kernel's
+    # local systems (condition ~1e9) amplify it most
+    assert np.abs(z - zo).max() < (1e-3 if kid == 2 else 2e-5) * np.abs(zo).max()
+
+
+@pytest.mark.parametrize("kid,dim,drift,nugget,rng_", [CASES[0], CASES[2], CASES[4]])
+def test_fgmres_with_schwarz_preconditioner_solves_the_interpolation_problem(kid, dim, drift, nugget, rng_):
+    rng = np.random.default_rng(70 + kid)
+    n = 6000
+    pts = rng.random((n, dim))
+    st = InterpolantSettings(kid, dim, drift=drift, nugget=nugget, base_range=rng_, total_sill=rng_)
+    tree = F.FmmTree(pts, 8, F.KernelParams(F.KernelType(kid), base_range=rng_, total_sill=rng_), True, True)
+    pre = SchwarzPreconditioner(tree, pts, st, DDMParams(128, 0.5, 0.125, 512))
+    op = S.RbfSystemOperator(tree, st.basis_size, pre.monomial_matrix, nugget)
+    vals = np.sin(4 * pts[:, 0]) * np.cos(3 * pts[:, -1]) + pts[:, 0]
+    rhs = np.concatenate([vals, np.zeros(st.basis_size)])
+    x, hist = S.fgmres(op, rhs, pre, None, 20, 5, S.FittingAccuracy(1e-6))        # the solver's call, rbf.rs:545-554
+    assert hist[-1][1] < 1e-6 and len(hist) <= 40
+    x0, hist0 = S.fgmres(op, rhs, None, None, 4, 5, S.FittingAccuracy(1e-6))
+    assert hist0[-1][1] > 10 * hist[min(len(hist), len(hist0)) - 1][1]           # the preconditioner is why
+    fitted = op(x)[:n]
+    assert np.abs(fitted - vals).max() < 1e-4 * np.abs(vals).max()
