@@ -99,13 +99,19 @@ SIGNATURES = {
     "bbfmm_schwarz_num_levels": (c_i32, [c_p]),
     "bbfmm_schwarz_monomial_matrix": (c_p, [c_p]),
     "bbfmm_schwarz_apply": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
+    "bbfmm_schwarz_level_size": (c_i64, [c_p, c_i32]),
+    "bbfmm_schwarz_level_points": (ctypes.c_int, [c_p, c_i32, c_p]),
+    "bbfmm_schwarz_debug_level_solve": (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32]),
 }
 
 
 class Interpolant(ctypes.Structure):
     """bbfmm_interpolant"""
     _fields_ = [("kernel_type", c_i32), ("polynomial_degree", c_i32), ("nugget", c_f64), ("base_range", c_f64),
-                ("total_sill", c_f64)]
+                ("total_sill", c_f64), ("flags", c_u32)]
+
+
+FLAG_GLOBAL_SCALING = 1
 
 
 class DdmParams(ctypes.Structure):

@@ -91,7 +91,8 @@ bool invert_small(const std::vector<double> &m, int k, std::vector<double> *inv)
 
 } // namespace
 
-int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_size, DdmDomain *dom, DomainPrep *out) {
+int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_size, DdmDomain *dom, DomainPrep *out,
+                   const double *scaling) {
     *out = DomainPrep();
     if (basis_size == 0) return BBFMM_OK;
     const int n = static_cast<int>(dom->idx.size());
@@ -105,6 +106,10 @@ int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_s
         out->tr[a] = (hi + lo) / 2.0;
         out->sc[a] = (hi - lo) / 2.0;
         if (out->sc[a] == 0.0) out->sc[a] = 1.0;
+        if (scaling) {
+            out->tr[a] = scaling[a];
+            out->sc[a] = scaling[3 + a];
+        }
     }
     // evaluate_monomials (polynomials.rs:30-74), n x basis_size row-major
     std::vector<double> mono(static_cast<size_t>(n) * basis_size, 0.0);
@@ -187,7 +192,8 @@ template <class T> static int up(T **dst, const std::vector<T> &v, hipStream_t s
 }
 
 int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const KernelSpec &ks, double nugget,
-                    int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *lv) {
+                    int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *lv,
+                    const double *scaling) {
     *lv = DdmLevelSolver();
     lv->d = d;
     lv->solve_for_poly = solve_for_poly;
@@ -196,7 +202,7 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     lv->prep.resize(static_cast<size_t>(nd));
     std::vector<int> rcs(static_cast<size_t>(nd), BBFMM_OK);
     parallel_for(nd, 1, [&](int64_t i) {
-        rcs[i] = prepare_domain(pts, ld, d, degree, basis_size, &level->leaves[i], &lv->prep[i]);
+        rcs[i] = prepare_domain(pts, ld, d, degree, basis_size, &level->leaves[i], &lv->prep[i], scaling);
     });
     for (int rc : rcs)
         if (rc != BBFMM_OK) return rc;

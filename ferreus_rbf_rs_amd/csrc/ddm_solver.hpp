@@ -23,7 +23,10 @@ struct DomainPrep { // host result of the polynomial part of Domain::factorise (
 };
 
 // Reorders dom->idx / dom->internal so that the special points come first (domain.rs:250-279).
-int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_size, DdmDomain *dom, DomainPrep *out);
+// scaling: NULL -> the cube scaling of the domain's own points (get_cheb_cube_scaling_factors of the
+// domain, domain.rs:171-172), else {translation[3], scale[3]} to use instead.
+int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_size, DdmDomain *dom, DomainPrep *out,
+                   const double *scaling = nullptr);
 
 // All leaf domains of one level, factorised and resident on the device.
 struct DdmLevelSolver {
@@ -47,7 +50,8 @@ struct DdmLevelSolver {
 };
 
 int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const KernelSpec &ks, double nugget,
-                    int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *out);
+                    int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *out,
+                    const double *scaling = nullptr);
 void ddm_level_free(DdmLevelSolver *lv);
 // values: global vector on the device (n_total); out: global vector on the device, rows of internal
 // points (all points when `all_points`) receive the domain coefficients, other rows are left alone.

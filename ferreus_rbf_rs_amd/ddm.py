@@ -100,12 +100,16 @@ class SchwarzPreconditioner:
     the device.  `tree`: an FmmTree over the same points / kernel (serves matvec_partial).  Use it
     as the `m` of solvers.fgmres, or call it on a residual of N + basis_size values."""
 
-    def __init__(self, tree, points, settings: InterpolantSettings, ddm_params: Optional[DDMParams] = None):
+    def __init__(self, tree, points, settings: InterpolantSettings, ddm_params: Optional[DDMParams] = None,
+                 global_scaling: bool = False):
+        """global_scaling: scale the coarse domain's monomials by the extents of all points (the basis of the
+        system's monomial matrix) instead of by its own extents as the reference does (domain.rs:171-172);
+        see csrc/schwarz.cpp."""
         pts = np.asfortranarray(np.atleast_2d(np.asarray(points, dtype=np.float64)))
         n, d = pts.shape
         lib = L.load()
         st = L.Interpolant(settings.kernel_type, settings.polynomial_degree, settings.nugget, settings.base_range,
-                           settings.total_sill)
+                           settings.total_sill, L.FLAG_GLOBAL_SCALING if global_scaling else 0)
         prm = (ddm_params or DDMParams())._c()
         h = ctypes.c_void_p()
         rc = lib.bbfmm_schwarz_create(tree._h, pts.ctypes.data, n, d, n, ctypes.byref(st), ctypes.byref(prm),
@@ -132,6 +136,21 @@ class SchwarzPreconditioner:
         rc = self._lib.bbfmm_schwarz_apply(self._h, r.ctypes.data, z.ctypes.data, r.size)
         if rc != L.OK:
             raise RuntimeError(f"bbfmm_schwarz_apply failed with status {rc}")
+        return z
+
+    def level_points(self, level: int) -> np.ndarray:
+        """Level::point_indices of one level (finest first)"""
+        out = np.zeros(self._lib.bbfmm_schwarz_level_size(self._h, level), dtype=np.int64)
+        self._lib.bbfmm_schwarz_level_points(self._h, level, out.ctypes.data)
+        return out
+
+    def debug_level_solve(self, level: int, residual, add_poly: bool = True) -> np.ndarray:
+        """solve_fine_level / solve_coarse_level (schwarz.rs:84-155) of one level"""
+        r = np.ascontiguousarray(residual, dtype=np.float64).reshape(-1)
+        z = np.zeros_like(r)
+        rc = self._lib.bbfmm_schwarz_debug_level_solve(self._h, level, r.ctypes.data, z.ctypes.data, int(add_poly))
+        if rc != L.OK:
+            raise RuntimeError(f"bbfmm_schwarz_debug_level_solve failed with status {rc}")
         return z
 
     def __del__(self):

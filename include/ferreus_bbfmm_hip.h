@@ -333,7 +333,12 @@ typedef struct bbfmm_interpolant { /* InterpolantSettings, interpolant_config.rs
     int32_t kernel_type;       /* bbfmm_kernel_type 0..6 (Linear, ThinPlateSpline, Cubic, Spheroidal3/5/7/9) */
     int32_t polynomial_degree; /* -1 none, 0 constant, 1 linear, 2 quadratic (Drift) */
     double nugget, base_range, total_sill;
+    uint32_t flags;            /* 0, or BBFMM_FLAG_GLOBAL_SCALING */
 } bbfmm_interpolant;
+/* Default (0): the coarse domain scales its monomials by the extents of its own points, as the
+ * reference does (domain.rs:171-172).  With this flag it uses the extents of all points, the basis
+ * of the system's monomial matrix, which makes its polynomial tail exact (see csrc/schwarz.cpp). */
+#define BBFMM_FLAG_GLOBAL_SCALING 1u
 /* tree: a handle over the same points, kernel and ranges (it serves matvec_partial); it must outlive
  * the preconditioner.  params NULL -> DDMParams defaults. */
 int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
@@ -342,6 +347,12 @@ void bbfmm_schwarz_destroy(bbfmm_schwarz *h);
 int64_t bbfmm_schwarz_basis_size(const bbfmm_schwarz *h);           /* InterpolantSettings::basis_size */
 int32_t bbfmm_schwarz_num_levels(const bbfmm_schwarz *h);
 const double *bbfmm_schwarz_monomial_matrix(const bbfmm_schwarz *h); /* N x basis column-major (rbf.rs:485-491) or NULL */
+int64_t bbfmm_schwarz_level_size(const bbfmm_schwarz *h, int32_t level);      /* Level::point_indices */
+int bbfmm_schwarz_level_points(const bbfmm_schwarz *h, int32_t level, int64_t *out);
+/* solve_fine_level / solve_coarse_level (schwarz.rs:84-155) of one level for a given residual
+ * (N + basis_size values in, N + basis_size out); parity checks. */
+int bbfmm_schwarz_debug_level_solve(bbfmm_schwarz *h, int32_t level, const double *residual, double *out,
+                                    int32_t add_poly);
 /* a bbfmm_apply_fn: user = bbfmm_schwarz*, vectors of N + basis_size doubles */
 int bbfmm_schwarz_apply(void *user, const double *residual, double *correction, int64_t n);
 
