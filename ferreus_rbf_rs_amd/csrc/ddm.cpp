@@ -6,7 +6,8 @@
 
 #include <algorithm>
 #include <cmath>
-#include <deque>
+#include <cstdlib>
+#include <cstring>
 #include <numeric>
 
 #include "../../include/ferreus_bbfmm_hip.h"
@@ -80,6 +81,8 @@ int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmPar
         !(prm.coarse_ratio > 0.0) || prm.overlap_quota < 0.0)
         return BBFMM_BAD_ARGUMENT;
     const Pts P{pts, ld, d};
+    // domains at least this large are argsorted by the threaded radix sort (BBFMM_DDM_RADIX_MIN overrides; tests)
+    const int64_t radix_min = std::getenv("BBFMM_DDM_RADIX_MIN") ? std::atoll(std::getenv("BBFMM_DDM_RADIX_MIN")) : (int64_t(1) << 20);
     out->d = d;
     out->levels.clear();
     std::vector<int64_t> active(static_cast<size_t>(n));
@@ -92,47 +95,78 @@ int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmPar
         DdmDomain root;
         root.idx = active;
         extents_of(P, root.idx, &root.extents);
-        std::deque<DdmDomain> queue;
-        queue.push_back(std::move(root));
-        while (!queue.empty()) {
-            DdmDomain cur = std::move(queue.front());
-            queue.pop_front();
-            const int64_t np = static_cast<int64_t>(cur.idx.size());
-            std::vector<double> ext;
-            extents_of(P, cur.idx, &ext);
-            int axis = 0; // argmax (utils.rs:147-170): first value greater than the running maximum, from 0
-            double best = 0.0;
-            for (int a = 0; a < d; ++a)
-                if (ext[a + d] - ext[a] > best) {
-                    best = ext[a + d] - ext[a];
-                    axis = a;
+        // The reference pops a FIFO queue: every domain of one generation is split before any of the
+        // next, and a leaf pair is appended when its parent is processed.  The same order results
+        // from splitting a generation in parallel and collecting the children in parent order.
+        std::vector<DdmDomain> gen;
+        gen.push_back(std::move(root));
+        while (!gen.empty()) {
+            const int64_t ng = static_cast<int64_t>(gen.size());
+            std::vector<DdmDomain> left(static_cast<size_t>(ng)), right(static_cast<size_t>(ng));
+            std::vector<uint8_t> is_leaf(static_cast<size_t>(ng), 0);
+            parallel_for(ng, 1, [&](int64_t g) {
+                DdmDomain &cur = gen[g];
+                const int64_t np = static_cast<int64_t>(cur.idx.size());
+                std::vector<double> ext;
+                extents_of(P, cur.idx, &ext);
+                int axis = 0; // argmax (utils.rs:147-170): first value greater than the running maximum, from 0
+                double best = 0.0;
+                for (int a = 0; a < d; ++a)
+                    if (ext[a + d] - ext[a] > best) {
+                        best = ext[a + d] - ext[a];
+                        axis = a;
+                    }
+                std::vector<int64_t> order(static_cast<size_t>(np));
+                std::iota(order.begin(), order.end(), int64_t(0));
+                if (np >= radix_min && ng <= 8) {
+                    // the few huge domains of the first generations: threaded stable radix sort on an
+                    // order-preserving integer image of the coordinate (same order as the comparison sort)
+                    std::vector<uint64_t> keys(static_cast<size_t>(np));
+                    for (int64_t k = 0; k < np; ++k) {
+                        double v = P.at(cur.idx[k], axis);
+                        if (v == 0.0) v = 0.0; // -0.0 == +0.0 for the comparison
+                        uint64_t b;
+                        std::memcpy(&b, &v, sizeof b);
+                        keys[k] = (b >> 63) ? ~b : (b | (uint64_t(1) << 63));
+                    }
+                    parallel_radix_sort_pairs(&keys, &order, 64);
+                } else {
+                    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { // argsort: stable
+                        return P.at(cur.idx[x], axis) < P.at(cur.idx[y], axis);
+                    });
                 }
-            std::vector<int64_t> order(static_cast<size_t>(np));
-            std::iota(order.begin(), order.end(), int64_t(0));
-            std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { // argsort: stable
-                return P.at(cur.idx[x], axis) < P.at(cur.idx[y], axis);
+                const int64_t mid = np / 2;
+                DdmDomain &l = left[g], &r = right[g];
+                l.idx.reserve(static_cast<size_t>(mid));
+                r.idx.reserve(static_cast<size_t>(np - mid));
+                for (int64_t k = 0; k < mid; ++k) l.idx.push_back(cur.idx[order[k]]);
+                for (int64_t k = mid; k < np; ++k) r.idx.push_back(cur.idx[order[k]]);
+                const double mid_coord = P.at(cur.idx[order[mid]], axis);
+                std::sort(l.idx.begin(), l.idx.end());
+                std::sort(r.idx.begin(), r.idx.end());
+                l.extents = cur.extents;
+                l.extents[axis + d] = mid_coord;
+                r.extents = cur.extents;
+                r.extents[axis] = mid_coord;
+                if (!(static_cast<double>(np) + static_cast<double>(np) * prm.overlap_quota >=
+                      2.0 * static_cast<double>(prm.leaf_threshold))) { // :150-162
+                    is_leaf[g] = 1;
+                    l.internal.assign(l.idx.size(), 1);
+                    r.internal.assign(r.idx.size(), 1);
+                }
+                std::vector<int64_t>().swap(cur.idx);
             });
-            const int64_t mid = np / 2;
-            DdmDomain left, right;
-            for (int64_t k = 0; k < mid; ++k) left.idx.push_back(cur.idx[order[k]]);
-            for (int64_t k = mid; k < np; ++k) right.idx.push_back(cur.idx[order[k]]);
-            const double mid_coord = P.at(cur.idx[order[mid]], axis);
-            std::sort(left.idx.begin(), left.idx.end());
-            std::sort(right.idx.begin(), right.idx.end());
-            left.extents = cur.extents;
-            left.extents[axis + d] = mid_coord;
-            right.extents = cur.extents;
-            right.extents[axis] = mid_coord;
-            if (static_cast<double>(np) + static_cast<double>(np) * prm.overlap_quota >=
-                2.0 * static_cast<double>(prm.leaf_threshold)) {
-                queue.push_back(std::move(left));
-                queue.push_back(std::move(right));
-            } else {
-                left.internal.assign(left.idx.size(), 1);
-                right.internal.assign(right.idx.size(), 1);
-                level.leaves.push_back(std::move(left));
-                level.leaves.push_back(std::move(right));
+            std::vector<DdmDomain> next_gen;
+            for (int64_t g = 0; g < ng; ++g) {
+                if (is_leaf[g]) {
+                    level.leaves.push_back(std::move(left[g]));
+                    level.leaves.push_back(std::move(right[g]));
+                } else {
+                    next_gen.push_back(std::move(left[g]));
+                    next_gen.push_back(std::move(right[g]));
+                }
             }
+            gen.swap(next_gen);
         }
         const int64_t nl = static_cast<int64_t>(level.leaves.size());
         const int64_t num_coarse = static_cast<int64_t>(

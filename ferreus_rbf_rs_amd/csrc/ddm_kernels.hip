@@ -4,6 +4,7 @@
 // column-major, lower triangle used.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "ddm_solver.hpp"
@@ -161,6 +162,91 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
     if (tid == 0 && bad) atomicExch(fail, 1);
 }
 
+// The same factorisation for one large matrix (the coarse domain, m up to tens of thousands) spread
+// over the chip: per 32-column panel one small launch for the diagonal block, one for the panel
+// rows and one for the trailing update in 64 x 64 tiles.
+__global__ __launch_bounds__(256) void chol_big_diag_kernel(double *A, int m, int jb, int *fail) {
+    __shared__ double Ld[NB][NB + 1];
+    const int tid = threadIdx.x, nb = min(NB, m - jb);
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e % nb, c = e / nb;
+        Ld[r][c] = r >= c ? A[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+    }
+    __syncthreads();
+    for (int c = 0; c < nb; ++c) {
+        if (tid == 0) {
+            const double dd = Ld[c][c];
+            if (!(dd > 0.0)) atomicExch(fail, 1);
+            Ld[c][c] = sqrt(dd > 0.0 ? dd : 1.0);
+        }
+        __syncthreads();
+        if (tid > c && tid < nb) Ld[tid][c] /= Ld[c][c];
+        __syncthreads();
+        for (int e = tid; e < nb * nb; e += 256) {
+            const int r = e % nb, c2 = e / nb;
+            if (c2 > c && r >= c2) Ld[r][c2] -= Ld[r][c] * Ld[c2][c];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e % nb, c = e / nb;
+        if (r >= c) A[(jb + r) + static_cast<int64_t>(jb + c) * m] = Ld[r][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void chol_big_panel_kernel(double *A, int m, int jb) {
+    __shared__ double Ld[NB][NB + 1];
+    const int tid = threadIdx.x, nb = min(NB, m - jb);
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e % nb, c = e / nb;
+        Ld[r][c] = r >= c ? A[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+    }
+    __syncthreads();
+    const int r = jb + nb + blockIdx.x * 256 + tid;
+    if (r >= m) return;
+    double xr[NB];
+    for (int c = 0; c < nb; ++c) {
+        double s = A[r + static_cast<int64_t>(jb + c) * m];
+        for (int c2 = 0; c2 < c; ++c2) s -= xr[c2] * Ld[c][c2];
+        xr[c] = s / Ld[c][c];
+    }
+    for (int c = 0; c < nb; ++c) A[r + static_cast<int64_t>(jb + c) * m] = xr[c];
+}
+
+__global__ __launch_bounds__(256) void chol_big_trail_kernel(double *A, int m, int jb) {
+    const int nb = min(NB, m - jb), t0 = jb + nb;
+    const int tr = t0 + 64 * blockIdx.x, tc = t0 + 64 * blockIdx.y;
+    if (tc > tr || tr >= m) return;
+    __shared__ double Pr[64][NB + 1], Pc[64][NB + 1];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    for (int e = tid; e < 64 * nb; e += 256) {
+        const int r = e % 64, c = e / 64;
+        Pr[r][c] = (tr + r < m) ? A[(tr + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        Pc[r][c] = (tc + r < m) ? A[(tc + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+    }
+    __syncthreads();
+    double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int c = 0; c < nb; ++c) {
+        double pr[4], pc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pr[u] = Pr[4 * ty + u][c];
+            pc[u] = Pc[4 * tx + u][c];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc[u][w] += pr[u] * pc[w];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int r = tr + 4 * ty + u, c = tc + 4 * tx + w;
+            if (r < m && c < m && r >= c) A[r + static_cast<int64_t>(c) * m] -= acc[u][w];
+        }
+}
+
 // Domain::solve (domain.rs:393-475) for one right-hand side: gather, rhs = Q^T d_s + d_ns,
 // L L^T gamma = rhs, lambda = [Q gamma; gamma], scatter.
 __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__restrict__ values,
@@ -300,6 +386,19 @@ void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLe
 
 void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
     if (lv.n_dom == 0) return;
+    if (lv.n_dom == 1 && lv.max_m > 2048) { // one large matrix: the whole chip per panel step
+        const int m = lv.max_m;
+        double *A = lv.d_fac;
+        for (int jb = 0; jb < m; jb += NB) {
+            const int nb = std::min(NB, m - jb), rest = m - jb - nb;
+            hipLaunchKernelGGL(chol_big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, jb, d_fail);
+            if (rest <= 0) break;
+            hipLaunchKernelGGL(chol_big_panel_kernel, dim3((rest + 255) / 256), dim3(256), 0, s, A, m, jb);
+            const unsigned t = static_cast<unsigned>((rest + 63) / 64);
+            hipLaunchKernelGGL(chol_big_trail_kernel, dim3(t, t), dim3(256), 0, s, A, m, jb);
+        }
+        return;
+    }
     hipLaunchKernelGGL(ddm_cholesky_kernel, dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, make_view(lv), d_fail);
 }
 

@@ -7,7 +7,10 @@
 #include "../../include/ferreus_bbfmm_hip.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <new>
@@ -165,8 +168,17 @@ int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, in
         p.coarse_ratio = params->coarse_ratio;
         p.coarse_threshold = params->coarse_threshold;
     }
+    const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr; // stage times on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what, int level) {
+        if (!verbose) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm] schwarz: %-26s %2d %8.3f s\n", what, level, std::chrono::duration<double>(t1 - t_last).count());
+        t_last = t1;
+    };
     int rc = build_ddm_tree(points, n, d, ld, p, &S.ddm);
     if (rc) return rc;
+    lap("domain decomposition", -1);
     if (hipStreamCreate(&S.stream) != hipSuccess) return BBFMM_DEVICE_ERROR;
     // global monomial matrix on the cube-scaled points and its thin Q (rbf.rs:418-421, 476-495)
     double gscale[6] = {0, 0, 0, 1, 1, 1}; // translation, scale of the global monomial basis
@@ -226,6 +238,7 @@ int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, in
         rc = ddm_level_build(points, ld, d, &S.ddm.levels[li], S.ks, S.nugget, S.degree, S.basis, coarse && S.basis != 0,
                              S.stream, &S.levels[li], (coarse && S.basis != 0 && global_scaling) ? gscale : nullptr);
         if (rc) return rc;
+        lap("level prepared + factorised", static_cast<int>(li));
     }
     if (S.basis) { // rows of A for the coarse domain's special points (domain.rs:352-355)
         const DdmLevelSolver &lv = S.levels.back();

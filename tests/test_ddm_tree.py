@@ -65,3 +65,23 @@ def test_defaults_and_bad_arguments():
     assert len(t.levels[1].point_indices) <= 4096
     with pytest.raises(ValueError):
         DDMTree(np.zeros((10, 4)))
+
+
+def test_radix_argsort_path_gives_the_same_tree(monkeypatch):
+    """The first, huge splits use a threaded radix argsort; forced on small input it must reproduce the
+    comparison-sort tree (ties included: duplicated coordinates, signed zeros)."""
+    rng = np.random.default_rng(9)
+    pts = np.round(rng.random((4000, 3)), 2) - 0.5          # many equal coordinates
+    pts[::97] = 0.0
+    pts[1::97, 0] = -0.0
+    prm = DDMParams(50, 0.5, 0.125, 200)
+    monkeypatch.setenv("BBFMM_DDM_RADIX_MIN", "1000000000")
+    a = DDMTree(pts, prm)
+    monkeypatch.setenv("BBFMM_DDM_RADIX_MIN", "1")
+    b = DDMTree(pts, prm)
+    assert len(a.levels) == len(b.levels)
+    for la, lb in zip(a.levels, b.levels):
+        assert list(la.point_indices) == list(lb.point_indices) and len(la.leaf_domains) == len(lb.leaf_domains)
+        for da, db in zip(la.leaf_domains, lb.leaf_domains):
+            assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
+            assert list(da.internal_points_mask) == list(db.internal_points_mask)
