@@ -347,6 +347,116 @@ __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__
         if (all_points || v.internal[o + e]) out[v.gidx[o + e]] = w[e];
 }
 
+// ---- Domain::solve for ONE large domain (the coarse level): the substitutions run as a sequence of
+// launches over 64-column blocks so that the whole chip streams the factor instead of one workgroup.
+// Both sweeps are right-looking (a solved block updates the entries still to be solved), so every
+// output has one writer and the result is deterministic.
+constexpr int SB = 64;
+
+__global__ __launch_bounds__(256) void big_gather_kernel(View v, const double *__restrict__ values, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n) v.work[e] = values[v.gidx[e]];
+}
+
+__global__ __launch_bounds__(256) void big_rhs_kernel(View v, int k, int m) { // y += Q^T d_s
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    double s = v.work[k + j];
+    for (int a = 0; a < k; ++a) s += v.q[static_cast<int64_t>(a) * m + j] * v.work[a];
+    v.work[k + j] = s;
+}
+
+// forward step jb: z[jb..jb+nb) = L_bb^{-1} y[jb..), then y[r] -= L[r, jb..] z[jb..] for the rows below.
+// Every workgroup solves the diagonal block itself (cheaper than another launch); workgroup 0 stores it.
+__global__ __launch_bounds__(256) void big_fwd_step_kernel(const double *__restrict__ L, int m, int jb, double *y,
+                                                           double *__restrict__ z) {
+    __shared__ double Ld[SB][SB + 1];
+    __shared__ double yb[SB];
+    __shared__ double part[4][SB];
+    const int tid = threadIdx.x, nb = min(SB, m - jb);
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e % nb, c = e / nb;
+        Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+    }
+    if (tid < nb) yb[tid] = y[jb + tid];
+    __syncthreads();
+    if (tid < 64) {
+        for (int c = 0; c < nb; ++c) {
+            if (tid == c) yb[c] = yb[c] / Ld[c][c];
+            __builtin_amdgcn_wave_barrier();
+            if (tid > c && tid < nb) yb[tid] -= Ld[tid][c] * yb[c];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (blockIdx.x == 0 && tid < nb) z[jb + tid] = yb[tid];
+    }
+    __syncthreads();
+    // 64 rows per workgroup, the block's columns split over the four waves
+    const int lane = tid & 63, q = tid >> 6;
+    const int r = jb + nb + blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (r < m) {
+        const int c0 = q * 16, c1 = min(nb, c0 + 16);
+        for (int c = c0; c < c1; ++c) s += L[r + static_cast<int64_t>(jb + c) * m] * yb[c];
+    }
+    part[q][lane] = s;
+    __syncthreads();
+    if (q == 0 && r < m) y[r] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// backward step jb: g[jb..jb+nb) = L_bb^{-T} z[jb..), then z[c] -= L[jb.., c]^T g[jb..) for the columns before.
+__global__ __launch_bounds__(256) void big_bwd_step_kernel(const double *__restrict__ L, int m, int jb, double *z,
+                                                           double *__restrict__ g) {
+    __shared__ double Ld[SB][SB + 1];
+    __shared__ double yb[SB];
+    const int tid = threadIdx.x, nb = min(SB, m - jb);
+    for (int e = tid; e < nb * nb; e += 256) {
+        const int r = e % nb, c = e / nb;
+        Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+    }
+    if (tid < nb) yb[tid] = z[jb + tid];
+    __syncthreads();
+    if (tid < 64) {
+        for (int c = nb - 1; c >= 0; --c) {
+            if (tid == c) yb[c] = yb[c] / Ld[c][c];
+            __builtin_amdgcn_wave_barrier();
+            if (tid < c) yb[tid] -= Ld[c][tid] * yb[c];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (blockIdx.x == 0 && tid < nb) g[jb + tid] = yb[tid];
+    }
+    __syncthreads();
+    // 64 columns per workgroup, 16 per wave; the lanes run down the block's rows
+    const int lane = tid & 63, wave = tid >> 6;
+    const double gl = lane < nb ? yb[lane] : 0.0;
+    const int cbeg = blockIdx.x * 64 + wave * 16, cend = min(jb, cbeg + 16);
+    for (int c = cbeg; c < cend; ++c) {
+        double s = lane < nb ? L[(jb + lane) + static_cast<int64_t>(c) * m] * gl : 0.0;
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+        if (lane == 0) z[c] -= s;
+    }
+}
+
+__global__ __launch_bounds__(256) void big_special_kernel(View v, int m, const double *__restrict__ g) { // Q gamma
+    __shared__ double red[256];
+    const int a = blockIdx.x, tid = threadIdx.x;
+    double s = 0.0;
+    for (int j = tid; j < m; j += 256) s += v.q[static_cast<int64_t>(a) * m + j] * g[j];
+    red[tid] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] += red[tid + st];
+        __syncthreads();
+    }
+    if (tid == 0) v.work[a] = red[0];
+}
+
+__global__ __launch_bounds__(256) void big_scatter_kernel(View v, int n, int k, const double *__restrict__ g,
+                                                          double *__restrict__ out, int all_points) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    if (all_points || v.internal[e]) out[v.gidx[e]] = e < k ? v.work[e] : g[e - k];
+}
+
 template <class F> void dispatch_rbf_kernel(int id, F &&f) { // the kernels the solver supports (interpolant_config.rs:30-36)
     switch (id) {
     case kLinear: f(std::integral_constant<int, kLinear>{}); break;
@@ -386,7 +496,7 @@ void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLe
 
 void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
     if (lv.n_dom == 0) return;
-    if (lv.n_dom == 1 && lv.max_m > 2048) { // one large matrix: the whole chip per panel step
+    if (ddm_level_is_big(lv)) { // one large matrix: the whole chip per panel step
         const int m = lv.max_m;
         double *A = lv.d_fac;
         for (int jb = 0; jb < m; jb += NB) {
@@ -404,6 +514,23 @@ void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
 
 void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s) {
     if (lv.n_dom == 0) return;
+    if (ddm_level_is_big(lv)) { // one large domain: work = [d_s | y] (n), z (m), gamma (m)
+        const View v = make_view(lv);
+        const int n = static_cast<int>(lv.n_entries), k = lv.k[0], m = n - k;
+        double *y = lv.d_work + k, *z = lv.d_work + n, *g = z + m;
+        const double *L = lv.d_fac;
+        hipLaunchKernelGGL(big_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, d_values, n);
+        if (k) hipLaunchKernelGGL(big_rhs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, v, k, m);
+        for (int jb = 0; jb < m; jb += SB) {
+            const int rest = m - jb - std::min(SB, m - jb);
+            hipLaunchKernelGGL(big_fwd_step_kernel, dim3(std::max(1, (rest + 63) / 64)), dim3(256), 0, s, L, m, jb, y, z);
+        }
+        for (int jb = ((m - 1) / SB) * SB; jb >= 0; jb -= SB)
+            hipLaunchKernelGGL(big_bwd_step_kernel, dim3(std::max(1, (jb + 63) / 64)), dim3(256), 0, s, L, m, jb, z, g);
+        if (k) hipLaunchKernelGGL(big_special_kernel, dim3(k), dim3(256), 0, s, v, m, g);
+        hipLaunchKernelGGL(big_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, n, k, g, d_out, all_points ? 1 : 0);
+        return;
+    }
     hipLaunchKernelGGL(ddm_solve_kernel, dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, make_view(lv), d_values,
                        d_out, all_points ? 1 : 0);
 }

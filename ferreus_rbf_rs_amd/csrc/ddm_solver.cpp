@@ -250,7 +250,7 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
         DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_g), q.size() * sizeof(double)));
     }
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_fac), static_cast<size_t>(std::max<int64_t>(lv->fac_off[nd], 1)) * sizeof(double)));
-    DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_work), static_cast<size_t>(std::max<int64_t>(lv->n_entries, 1)) * sizeof(double)));
+    DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_work), static_cast<size_t>(std::max<int64_t>(lv->n_entries, 1)) * (ddm_level_is_big(*lv) ? 3 : 1) * sizeof(double)));
     int *d_fail = nullptr;
     DHIP(hipMalloc(reinterpret_cast<void **>(&d_fail), sizeof(int)));
     DHIP(hipMemsetAsync(d_fail, 0, sizeof(int), s));

@@ -45,9 +45,13 @@ struct DdmLevelSolver {
     int32_t *d_k = nullptr;
     uint8_t *d_internal = nullptr;
     double *d_q = nullptr, *d_t = nullptr, *d_g = nullptr, *d_fac = nullptr;
-    double *d_work = nullptr; // n_entries: rhs / solution per entry
+    double *d_work = nullptr; // n_entries: rhs / solution per entry (3x for one large domain: + z, gamma)
     int max_m = 0;
 };
+
+// One large domain (the coarse level above a few thousand points): factorisation and substitutions
+// run as multi-workgroup launch sequences instead of one workgroup per domain.
+inline bool ddm_level_is_big(const DdmLevelSolver &lv) { return lv.n_dom == 1 && lv.max_m > 2048; }
 
 int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const KernelSpec &ks, double nugget,
                     int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *out,

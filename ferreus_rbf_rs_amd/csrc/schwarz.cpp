@@ -38,6 +38,8 @@ struct Schwarz {
     hipStream_t stream = nullptr;
     double *d_in = nullptr, *d_out = nullptr;
     std::vector<double> res, tmp, s1;
+    double t_matvec = 0, t_solve = 0, t_host = 0; // BBFMM_VERBOSE: seconds per apply
+    std::vector<double> t_level, t_level_mv;      // per level: local solves, partial matvecs
     ~Schwarz() {
         for (auto &lv : levels) ddm_level_free(&lv);
         if (d_in) (void)hipFree(d_in);
@@ -57,9 +59,18 @@ int level_correction(Schwarz &S, size_t li, const double *rg, const double *sl, 
     const int64_t nt = S.n + S.basis;
     const DdmLevel &L = S.ddm.levels[li];
     int rc = BBFMM_OK;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double>(b - a).count();
+    };
+    auto t0 = now();
     if (sl) {
         rc = partial_matvec(S, sl, L.point_indices, S.tmp.data());
         if (rc) return rc;
+        S.t_matvec += secs(t0, now());
+        if (S.t_level_mv.size() < S.levels.size()) S.t_level_mv.resize(S.levels.size(), 0.0);
+        S.t_level_mv[li] += secs(t0, now());
+        t0 = now();
         parallel_for_chunks(nt, 1 << 16, [&](int64_t b, int64_t e) {
             for (int64_t i = b; i < e; ++i) S.res[i] = rg[i] - S.tmp[i];
         });
@@ -75,6 +86,15 @@ int level_correction(Schwarz &S, size_t li, const double *rg, const double *sl, 
         hipStreamSynchronize(S.stream) != hipSuccess)
         return BBFMM_DEVICE_ERROR;
     for (int64_t i = S.n; i < nt; ++i) S.s1[i] = 0.0;
+    S.t_solve += secs(t0, now());
+    if (S.t_level.size() < S.levels.size()) S.t_level.resize(S.levels.size(), 0.0);
+    S.t_level[li] += secs(t0, now());
+    t0 = now();
+    struct HostTime { // the rest of this function is host work
+        Schwarz &s;
+        std::chrono::steady_clock::time_point t;
+        ~HostTime() { s.t_host += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
+    } host_time{S, t0};
     if (!coarse) {
         if (S.basis) { // orthogonalise against the global polynomial basis (schwarz.rs:113-126)
             std::vector<double> proj(static_cast<size_t>(S.basis), 0.0);
@@ -317,6 +337,18 @@ int bbfmm_schwarz_apply(void *user, const double *rg, double *sl, int64_t n) {
     } else {
         if ((rc = level_correction(S, coarse, rg, sl, true, true))) return rc;
         add();
+    }
+    if (std::getenv("BBFMM_VERBOSE")) {
+        std::fprintf(stderr, "[bbfmm] schwarz apply: partial matvecs %.3f s, level solves (incl. PCIe) %.3f s, host %.3f s\n",
+                     S.t_matvec, S.t_solve, S.t_host);
+        for (size_t l = 0; l < S.t_level.size(); ++l) {
+            std::fprintf(stderr, "[bbfmm]   level %zu: %lld domains, %lld entries, max m %d: solves %.3f s, matvecs %.3f s\n", l,
+                         (long long)S.levels[l].n_dom, (long long)S.levels[l].n_entries, S.levels[l].max_m, S.t_level[l],
+                         l < S.t_level_mv.size() ? S.t_level_mv[l] : 0.0);
+            S.t_level[l] = 0;
+            if (l < S.t_level_mv.size()) S.t_level_mv[l] = 0;
+        }
+        S.t_matvec = S.t_solve = S.t_host = 0;
     }
     return BBFMM_OK;
 }

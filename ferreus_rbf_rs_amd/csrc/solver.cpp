@@ -8,6 +8,9 @@
 #include "parallel.hpp"
 
 #include <cfloat>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -110,10 +113,27 @@ int bbfmm_fgmres(int64_t n, bbfmm_apply_fn a, void *a_user, const double *b, bbf
         return BBFMM_BAD_ARGUMENT;
     const int mi = max_inner_iterations, ldh = mi + 1;
     const bool absolute = tolerance_type == BBFMM_ACCURACY_ABSOLUTE;
+    // BBFMM_VERBOSE: where the solve's wall time goes (operator, preconditioner, host vector work)
+    struct Clock {
+        double t_a = 0, t_m = 0;
+        std::chrono::steady_clock::time_point start = std::chrono::steady_clock::now();
+        ~Clock() {
+            if (!std::getenv("BBFMM_VERBOSE")) return;
+            const double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - start).count();
+            std::fprintf(stderr, "[bbfmm] fgmres: total %.3f s = operator %.3f + preconditioner %.3f + host vectors %.3f\n", total,
+                         t_a, t_m, total - t_a - t_m);
+        }
+    } clock;
+    auto timed = [](double &acc, bbfmm_apply_fn f, void *user, const double *in, double *out, int64_t len) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int r = f(user, in, out, len);
+        acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        return r;
+    };
     if (x0) std::memcpy(x, x0, static_cast<size_t>(n) * sizeof(double));
     else std::memset(x, 0, static_cast<size_t>(n) * sizeof(double));
     std::vector<double> r(static_cast<size_t>(n)), w(static_cast<size_t>(n)), wj(static_cast<size_t>(n));
-    int rc = a(a_user, x, wj.data(), n);
+    int rc = timed(clock.t_a, a, a_user, x, wj.data(), n);
     if (rc) return rc;
     sub_to(b, wj.data(), r.data(), n);
     const double beta = absolute ? norm_max(r.data(), n) : norm_l2(r.data(), n);
@@ -135,13 +155,13 @@ int bbfmm_fgmres(int64_t n, bbfmm_apply_fn a, void *a_user, const double *b, bbf
         g[0] = r_norm;
         for (int j = 0; j < mi; ++j) {
             if (m) {
-                rc = m(m_user, v[j].data(), w.data(), n);
+                rc = timed(clock.t_m, m, m_user, v[j].data(), w.data(), n);
                 if (rc) return rc;
             } else {
                 std::memcpy(w.data(), v[j].data(), static_cast<size_t>(n) * sizeof(double));
             }
             std::memcpy(z[j].data(), w.data(), static_cast<size_t>(n) * sizeof(double));
-            rc = a(a_user, w.data(), wj.data(), n);
+            rc = timed(clock.t_a, a, a_user, w.data(), wj.data(), n);
             if (rc) return rc;
             for (int i = 0; i <= j; ++i) { // modified Gram-Schmidt
                 const double hij = dot(v[i].data(), wj.data(), n);
@@ -177,7 +197,7 @@ int bbfmm_fgmres(int64_t n, bbfmm_apply_fn a, void *a_user, const double *b, bbf
             ++iteration;
         }
         add_solution(h, ldh, g, z, mi, x, n); // restart update
-        rc = a(a_user, x, wj.data(), n);
+        rc = timed(clock.t_a, a, a_user, x, wj.data(), n);
         if (rc) return rc;
         sub_to(b, wj.data(), r.data(), n);
         res_norm = absolute ? norm_max(r.data(), n) : norm_l2(r.data(), n) / beta;
