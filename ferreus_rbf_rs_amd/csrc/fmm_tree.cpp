@@ -729,6 +729,120 @@ int FmmTree::build_source_target_set() {
 
 int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
                               std::vector<int32_t> *leaves_out) {
+    static const int64_t min_rows = [] {
+        const char *e = std::getenv("BBFMM_DEVICE_TARGETS_MIN");
+        return e ? std::atoll(e) : int64_t(-1);
+    }();
+    if (m >= (min_rows >= 0 ? min_rows : device_targets_min_) && m > 0)
+        return build_target_set_device(x, m, ldx, ts, bad_point_index, leaves_out);
+    return build_target_set_host(x, m, ldx, ts, bad_point_index, leaves_out);
+}
+
+// points_to_leaves, the stable grouping by leaf and the coordinate gather as kernels (targets.hip); the
+// host keeps the per-leaf part (M2P jobs from the W lists).  Same target set as the host path.
+int FmmTree::build_target_set_device(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
+                                     std::vector<int32_t> *leaves_out) {
+    const HostTree &t = tree_;
+    if (!lk_ready_) {
+        CHK(dupload(&d_tab_keys_, t.table.raw_keys()));
+        CHK(dupload(&d_tab_vals_, t.table.raw_vals()));
+        CHK(dupload(&d_is_leaf_, t.is_leaf));
+        lk_.keys = d_tab_keys_.p;
+        lk_.vals = d_tab_vals_.p;
+        lk_.mask = t.table.mask();
+        lk_.is_leaf = d_is_leaf_.p;
+        lk_.d = d_;
+        lk_.depth = t.depth;
+        lk_.side = get_side_length(t.radius, static_cast<uint64_t>(t.depth)); // linear_tree.rs:495
+        for (int a = 0; a < d_; ++a) lk_.disp[a] = t.center[a] - t.radius;
+        lk_ready_ = true;
+    }
+    const int64_t C = t.n_cells();
+    int end_bit = 1;
+    while ((int64_t(1) << end_bit) < C) ++end_bit;
+    auto up = [](size_t b) { return (b + 255) & ~size_t(255); };
+    const size_t sm = static_cast<size_t>(m);
+    const size_t o_x = 0, o_cell = o_x + up(sm * 8 * d_), o_sorted = o_cell + up(sm * 4), o_heads = o_sorted + up(sm * 4),
+                 o_scal = o_heads + up(sm), o_temp = o_scal + 256;
+    const size_t temp_bytes = group_targets_temp_bytes(m, end_bit);
+    const size_t need = o_temp + temp_bytes;
+    if (need > d_tscratch_.n) {
+        dfree(&d_tscratch_);
+        CHK(dalloc(&d_tscratch_, need + need / 4));
+    }
+    uint8_t *base = d_tscratch_.p;
+    double *xin[3] = {nullptr, nullptr, nullptr};
+    for (int a = 0; a < d_; ++a) {
+        xin[a] = reinterpret_cast<double *>(base + o_x) + static_cast<size_t>(a) * sm;
+        HIPCHK(hipMemcpyAsync(xin[a], x + a * ldx, sm * sizeof(double), hipMemcpyHostToDevice, stream_));
+    }
+    int32_t *cell = reinterpret_cast<int32_t *>(base + o_cell), *sorted = reinterpret_cast<int32_t *>(base + o_sorted);
+    uint8_t *heads = base + o_heads;
+    unsigned long long *d_bad = reinterpret_cast<unsigned long long *>(base + o_scal);
+    int32_t *d_runs = reinterpret_cast<int32_t *>(base + o_scal + 8);
+    HIPCHK(hipMemsetAsync(d_bad, 0xFF, sizeof(unsigned long long), stream_));
+    ts->m = m;
+    const size_t cap = static_cast<size_t>(std::min<int64_t>(m, C));
+    CHK(dalloc(&ts->perm, sm));
+    CHK(dalloc(&ts->job_cell, cap));
+    CHK(dalloc(&ts->tgt_begin, cap));
+    CHK(dalloc(&ts->tgt_end, cap));
+    for (int a = 0; a < 3; ++a) {
+        if (a < d_) {
+            CHK(dalloc(&ts->xyz[a], sm));
+            ts->xyz_ptr[a] = ts->xyz[a].p;
+        } else if (sm > d_zero_axis_.n) {
+            CHK(dalloc(&ts->xyz[a], sm, true));
+            ts->xyz_ptr[a] = ts->xyz[a].p;
+        } else {
+            ts->xyz_ptr[a] = d_zero_axis_.p;
+        }
+    }
+    launch_points_to_leaves(lk_, xin[0], xin[1], xin[2], m, cell, d_bad, stream_);
+    const int grc = group_targets(cell, m, end_bit, sorted, ts->perm.p, heads, ts->job_cell.p, ts->tgt_begin.p,
+                                  ts->tgt_end.p, d_runs, base + o_temp, temp_bytes, stream_);
+    if (grc != 0) return hip_fail(static_cast<hipError_t>(grc), "group targets by leaf");
+    launch_gather_targets(xin[0], xin[1], xin[2], ts->perm.p, m, d_ > 0 ? ts->xyz[0].p : nullptr,
+                          d_ > 1 ? ts->xyz[1].p : nullptr, d_ > 2 ? ts->xyz[2].p : nullptr, stream_);
+    struct {
+        unsigned long long bad;
+        int32_t runs, pad;
+    } scal;
+    HIPCHK(hipMemcpyAsync(&scal, d_bad, 16, hipMemcpyDeviceToHost, stream_));
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (scal.bad != ~0ull) {
+        if (bad_point_index) *bad_point_index = static_cast<int64_t>(scal.bad);
+        return fail(BBFMM_POINT_OUTSIDE_TREE, "FMM evaluation failed: target point at row " + std::to_string(scal.bad) +
+                                                  " lies outside the tree extents");
+    }
+    ts->n_jobs = scal.runs;
+    std::vector<int32_t> wtb, wte;
+    std::vector<int64_t> wb, we;
+    if (leaves_out || !t.w.idx.empty()) {
+        const size_t nj = static_cast<size_t>(scal.runs);
+        std::vector<int32_t> jc(nj), tb(nj), te(nj);
+        if (nj) {
+            HIPCHK(hipMemcpyAsync(jc.data(), ts->job_cell.p, nj * 4, hipMemcpyDeviceToHost, stream_));
+            if (!t.w.idx.empty()) {
+                HIPCHK(hipMemcpyAsync(tb.data(), ts->tgt_begin.p, nj * 4, hipMemcpyDeviceToHost, stream_));
+                HIPCHK(hipMemcpyAsync(te.data(), ts->tgt_end.p, nj * 4, hipMemcpyDeviceToHost, stream_));
+            }
+            HIPCHK(hipStreamSynchronize(stream_));
+        }
+        if (!t.w.idx.empty())
+            for (size_t j = 0; j < nj; ++j) add_w_jobs(t, jc[j], tb[j], te[j], &wtb, &wte, &wb, &we);
+        if (leaves_out) leaves_out->swap(jc);
+    }
+    ts->n_w_jobs = static_cast<int>(wtb.size());
+    CHK(dupload(&ts->w_tgt_begin, wtb));
+    CHK(dupload(&ts->w_tgt_end, wte));
+    CHK(dupload(&ts->w_begin, wb));
+    CHK(dupload(&ts->w_end, we));
+    return BBFMM_OK;
+}
+
+int FmmTree::build_target_set_host(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
+                                   std::vector<int32_t> *leaves_out) {
     const HostTree &t = tree_;
     std::vector<int32_t> cell(static_cast<size_t>(m));
     const int64_t bad = points_to_leaves(t, x, m, ldx, cell.data());
@@ -737,30 +851,41 @@ int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet
         return fail(BBFMM_POINT_OUTSIDE_TREE, "FMM evaluation failed: target point at row " + std::to_string(bad) +
                                                   " lies outside the tree extents");
     }
-    // group rows by leaf, ascending rows inside a leaf (linear_tree.rs:522-534)
+    // group rows by leaf (ascending cell index), ascending rows inside a leaf (linear_tree.rs:522-534)
     const int64_t C = t.n_cells();
-    std::vector<int64_t> cnt(static_cast<size_t>(C) + 1, 0);
-    for (int64_t i = 0; i < m; ++i) ++cnt[cell[i] + 1];
-    // visit leaves in sorted-point order for locality: rank leaves by pt_begin, empty ones by key
-    std::vector<int32_t> leaves;
-    for (int64_t c = 0; c < C; ++c)
-        if (cnt[c + 1] > 0) leaves.push_back(static_cast<int32_t>(c));
-    std::vector<int64_t> start(static_cast<size_t>(C), 0);
-    int64_t cur = 0;
-    std::vector<int32_t> jc, tb, te, wtb, wte;
+    std::vector<int32_t> leaves, jc, tb, te, wtb, wte;
     std::vector<int64_t> wb, we;
-    for (int32_t c : leaves) {
-        start[c] = cur;
-        jc.push_back(c);
-        tb.push_back(static_cast<int32_t>(cur));
-        cur += cnt[c + 1];
-        te.push_back(static_cast<int32_t>(cur));
-        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
-    }
     std::vector<int32_t> perm(static_cast<size_t>(m));
-    {
-        std::vector<int64_t> pos(start);
-        for (int64_t i = 0; i < m; ++i) perm[pos[cell[i]]++] = static_cast<int32_t>(i);
+    if (m * 8 < C) { // a small batch (isosurfacing): sort the rows instead of walking all cells
+        std::iota(perm.begin(), perm.end(), 0);
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t b) { return cell[a] < cell[b]; });
+        for (int64_t i = 0; i < m;) {
+            const int32_t c = cell[perm[i]];
+            int64_t e = i + 1;
+            while (e < m && cell[perm[e]] == c) ++e;
+            leaves.push_back(c);
+            jc.push_back(c);
+            tb.push_back(static_cast<int32_t>(i));
+            te.push_back(static_cast<int32_t>(e));
+            add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
+            i = e;
+        }
+    } else {
+        std::vector<int64_t> cnt(static_cast<size_t>(C) + 1, 0);
+        for (int64_t i = 0; i < m; ++i) ++cnt[cell[i] + 1];
+        for (int64_t c = 0; c < C; ++c)
+            if (cnt[c + 1] > 0) leaves.push_back(static_cast<int32_t>(c));
+        std::vector<int64_t> start(static_cast<size_t>(C), 0);
+        int64_t cur = 0;
+        for (int32_t c : leaves) {
+            start[c] = cur;
+            jc.push_back(c);
+            tb.push_back(static_cast<int32_t>(cur));
+            cur += cnt[c + 1];
+            te.push_back(static_cast<int32_t>(cur));
+            add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
+        }
+        for (int64_t i = 0; i < m; ++i) perm[start[cell[i]]++] = static_cast<int32_t>(i);
     }
     ts->m = m;
     std::vector<double> tmp(static_cast<size_t>(m));
@@ -977,8 +1102,13 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     if (m >= (int64_t(1) << 31)) return fail(BBFMM_BAD_ARGUMENT, "more than 2^31-1 target points");
     TargetSet ts;
     std::vector<int32_t> target_leaves;
-    int rc = build_target_set(x, m, ldx, &ts, bad_point_index, &target_leaves); // points_to_keys, bbfmm.rs:455-465
-    if (rc == BBFMM_OK) rc = upload_weights(w, rows, k, ldw);
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    int rc = build_target_set(x, m, ldx, &ts, bad_point_index, leaves_only ? nullptr : &target_leaves); // points_to_keys, bbfmm.rs:455-465
+    const auto t_targets = std::chrono::steady_clock::now();
+    // w == NULL (leaves-only entry points): keep the weights already on the device, i.e. those the stored
+    // local coefficients were computed from -- no N x k host-to-device copy per batch
+    if (rc == BBFMM_OK && (w || !leaves_only)) rc = upload_weights(w, rows, k, ldw);
     DownwardPlan dplan;
     if (rc == BBFMM_OK && !leaves_only) {
         // downward pass over cells_with_targets (bbfmm.rs:468-480) when the targets are few; many
@@ -1025,6 +1155,12 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     dfree(&g_dev);
     free_target_set(&ts);
     free_downward_plan(&dplan);
+    if (verbose) {
+        const auto t_end = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm] evaluate: %lld targets, target set %.3f ms, rest (weights, passes, copies) %.3f ms\n",
+                     static_cast<long long>(m), std::chrono::duration<double, std::milli>(t_targets - t_begin).count(),
+                     std::chrono::duration<double, std::milli>(t_end - t_targets).count());
+    }
     return rc;
 }
 

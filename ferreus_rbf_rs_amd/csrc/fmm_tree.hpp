@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "device.hpp"
+#include "targets.hpp"
 #include "ferreus_bbfmm_hip.h"
 #include "kernels.hpp"
 #include "operators.hpp"
@@ -138,6 +139,11 @@ class FmmTree {
     int leaf_pass_far(const TargetSet &ts, int k, bool with_grads);
     int build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
                          std::vector<int32_t> *leaves_out = nullptr);
+    // the same on the device (targets.hip) for batches of at least device_targets_min_ rows
+    int build_target_set_device(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
+                                std::vector<int32_t> *leaves_out);
+    int build_target_set_host(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
+                              std::vector<int32_t> *leaves_out);
     int build_source_target_set();
     void free_target_set(TargetSet *ts);
     int upload_weights(const double *w, int64_t rows, int k, int64_t ldw);
@@ -209,6 +215,14 @@ class FmmTree {
     DevBuf<double> d_src_[3];
     const double *src_ptr_[3] = {nullptr, nullptr, nullptr};
     DevBuf<double> d_zero_axis_;
+    // device target grouping: the tree's key table, leaf flags, grow-only scratch
+    DevBuf<uint64_t> d_tab_keys_;
+    DevBuf<int32_t> d_tab_vals_;
+    DevBuf<uint8_t> d_is_leaf_;
+    DevBuf<uint8_t> d_tscratch_;
+    DevLeafLookup lk_;
+    bool lk_ready_ = false;
+    int64_t device_targets_min_ = 4096;
     DevBuf<int32_t> d_order_;
     DevBuf<double> d_centers_, d_lengths_;
     DevBuf<int32_t> d_pt_begin_, d_pt_end_, d_parent_, d_octant_;

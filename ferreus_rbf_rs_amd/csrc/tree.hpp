@@ -26,6 +26,11 @@ class KeyTable {
         }
     }
 
+    // raw table for the device lookup (targets.hip probes it with the same hash)
+    const std::vector<uint64_t> &raw_keys() const { return keys_; }
+    const std::vector<int32_t> &raw_vals() const { return vals_; }
+    uint64_t mask() const { return mask_; }
+
   private:
     static uint64_t hash(uint64_t x) {
         x ^= x >> 33;

@@ -207,18 +207,23 @@ class FmmTree:
                                                            w.shape[1], w.shape[0]))
 
     def _eval(self, fn, weights, target_points, grads, leaf):
-        w = _as_f64_2d(weights, "weights")
         x = _as_f64_2d(target_points, "target_points")
-        m, k = x.shape[0], w.shape[1]
+        if weights is None and leaf:
+            # leaves-only calls may reuse the weights resident on the device (header: bbfmm_evaluate_leaves)
+            wp, rows, k = None, self.n_points, self._nrhs
+        else:
+            w = _as_f64_2d(weights, "weights")
+            wp, rows, k = w.ctypes.data, w.shape[0], w.shape[1]
+        m = x.shape[0]
         out = np.zeros((m, k), order="F")
         bad = ctypes.c_int64(-1)
         if grads:
             g = np.zeros((m, k * self.dim), order="F")
-            rc = fn(self._h, w.ctypes.data, w.shape[0], k, w.shape[0], x.ctypes.data, m, max(m, 1),
+            rc = fn(self._h, wp, rows, k, rows, x.ctypes.data, m, max(m, 1),
                     out.ctypes.data, max(m, 1), g.ctypes.data, max(m, 1), ctypes.byref(bad))
             self._raise(rc, bad, leaf)
             return out, g
-        rc = fn(self._h, w.ctypes.data, w.shape[0], k, w.shape[0], x.ctypes.data, m, max(m, 1),
+        rc = fn(self._h, wp, rows, k, rows, x.ctypes.data, m, max(m, 1),
                 out.ctypes.data, max(m, 1), ctypes.byref(bad))
         self._raise(rc, bad, leaf)
         return out

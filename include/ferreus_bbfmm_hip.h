@@ -124,7 +124,11 @@ int bbfmm_evaluate_with_gradients(bbfmm_handle *h, const double *w, int64_t rows
                                   int64_t *bad_point_index);
 
 /* FmmTree::evaluate_leaves (utils.rs:465-473 -> bbfmm.rs:537-544): leaf pass only,
- * after bbfmm_set_local_coefficients. */
+ * after bbfmm_set_local_coefficients.
+ * Extension for many small batches (isosurfacing, ferreus_rmt/src/isosurface.rs:574,693): w may be
+ * NULL in the two leaves-only entry points; the weights already resident on the device (those of
+ * the last call that took weights, normally bbfmm_set_local_coefficients) are used and the N x k
+ * host-to-device copy per call is skipped.  k must still equal the set_weights column count. */
 int bbfmm_evaluate_leaves(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
                           const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo,
                           int64_t *bad_point_index);

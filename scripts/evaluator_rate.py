@@ -15,7 +15,7 @@ build = time.time() - t0
 tree.set_weights(w); tree.set_local_coefficients(w)
 out = {"sources": n, "build_s": round(build, 2)}
 for m in (1000, 100_000, 2_000_000):
-    x = rng.random((m, 3)) * 2 - 1
+    x = np.asfortranarray(rng.random((m, 3)) * 2 - 1)   # column-major, as the C ABI takes it (no wrapper copy)
     for name, fn in (("evaluate", tree.evaluate), ("evaluate_leaves", tree.evaluate_leaves),
                      ("evaluate_leaves_with_gradients", tree.evaluate_leaves_with_gradients)):
         fn(w, x)
@@ -24,4 +24,10 @@ for m in (1000, 100_000, 2_000_000):
         for _ in range(reps): fn(w, x)
         dt = (time.perf_counter() - t0) / reps
         out[f"{name}_{m}"] = {"ms": round(dt * 1e3, 3), "Mtargets_per_s": round(m / dt * 1e-6, 3)}
+    tree.evaluate_leaves(None, x)                       # weights left on the device (header: bbfmm_evaluate_leaves)
+    reps = 50 if m <= 1000 else 3
+    t0 = time.perf_counter()
+    for _ in range(reps): tree.evaluate_leaves(None, x)
+    dt = (time.perf_counter() - t0) / reps
+    out[f"evaluate_leaves_resident_weights_{m}"] = {"ms": round(dt * 1e3, 3), "Mtargets_per_s": round(m / dt * 1e-6, 3)}
 print(json.dumps(out))

@@ -103,6 +103,14 @@ def test_evaluator_flow_non_sparse_extents_arbitrary_targets():
     y, g = t.evaluate_leaves_with_gradients(w, x)
     yr, gr = r.evaluate_leaves_with_gradients(w, x)
     assert relerr(y, yr) < TOL and relerr(g, gr) < 1e-9 and g.shape == (1000, 6)
+    # weights left on the device (w = NULL, header: bbfmm_evaluate_leaves): same result without the upload
+    y0, g0 = t.evaluate_leaves_with_gradients(None, x)
+    assert relerr(t.evaluate_leaves(None, x), t.evaluate_leaves(w, x)) < 1e-14   # M2P adds atomically: not bitwise
+    assert relerr(y0, y) < 1e-14 and relerr(g0, g) < 1e-14
+    xl = rng.random((6000, 3)) * 4 - 2                                          # device grouping path
+    assert relerr(t.evaluate_leaves(None, xl), r.evaluate_leaves(w, xl)) < TOL
+    with pytest.raises((TypeError, ValueError)):
+        t.evaluate(None, x)                                                     # only the leaves-only calls accept NULL
     assert t.evaluate(w, np.zeros((0, 3))).shape == (0, 2)                   # empty target set
 
 
@@ -270,3 +278,46 @@ def test_partial_matvec_plans_and_restricted_evaluate():
     t.evaluate(w2, x[:10])
     assert relerr(t.evaluate_leaves(w2, x), a) < 1e-14       # (M2P adds with atomics: order may differ)
     assert relerr(a, r.evaluate_leaves(w2, x)) < TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [1, 2, 3])
+def test_device_target_grouping_equals_host_grouping(d):
+    # targets.hip (points_to_leaves + stable grouping on the device, batches >= 4096 rows) against the
+    # host path (smaller batches): same leaves (linear_tree.rs:487-534), same values and gradients,
+    # and the smallest row outside the tree is the one reported (linear_tree.rs:514-517)
+    rng = np.random.default_rng(100 + d)
+    n = 30000
+    pts = clustered_points(rng, n, d)
+    t = F.FmmTree(pts, 5, F.KernelParams(F.FmmKernelType.CubicRbf), True, False,
+                  extents=[-1.0] * d + [2.0] * d)
+    w = rng.standard_normal((n, 1))
+    t.set_weights(w)
+    m = 9000
+    x = rng.random((m, d)) * 2.5 - 0.75
+    big, gbig = t.evaluate_with_gradients(w, x)
+    parts = [t.evaluate_with_gradients(w, x[i:i + 3000]) for i in range(0, m, 3000)]
+    small = np.vstack([p[0] for p in parts]); gsmall = np.vstack([p[1] for p in parts])
+    assert np.abs(big - small).max() <= 1e-13 * np.abs(small).max()
+    assert np.abs(gbig - gsmall).max() <= 1e-13 * np.abs(gsmall).max()
+    assert np.array_equal(t.evaluate(w, x), big) or np.abs(t.evaluate(w, x) - big).max() <= 1e-13 * np.abs(big).max()
+    # rows far outside: whatever the host path decides (the 16-bit anchor masks of morton.rs:58-119 can
+    # alias such a row into the tree) the device path must decide too, and report the same first row
+    xb = x.copy(); xb[7000] = 50.0; xb[8123] = -50.0
+
+    def first_bad(arr):
+        try:
+            t.evaluate(w, arr)
+            return None
+        except F.PointOutsideTree as e:
+            return e.point_index
+    host = [first_bad(xb[i:i + 3000]) for i in range(0, m, 3000)]
+    expect = next((i * 3000 + b for i, b in enumerate(host) if b is not None), None)
+    assert first_bad(xb) == expect
+    if d > 1:
+        assert expect == 7000
+    # sparse tree, targets = a permutation of the sources: every row has a leaf, grouping must undo the shuffle
+    ts = F.FmmTree(pts, 5, F.KernelParams(F.FmmKernelType.CubicRbf), True, True)
+    ts.set_weights(w)
+    perm = rng.permutation(n)
+    assert relerr(ts.evaluate(w, pts[perm]), ts.evaluate(w, pts)[perm]) < 1e-13
