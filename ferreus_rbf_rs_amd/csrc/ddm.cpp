@@ -6,6 +6,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -81,13 +83,20 @@ int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmPar
         !(prm.coarse_ratio > 0.0) || prm.overlap_quota < 0.0)
         return BBFMM_BAD_ARGUMENT;
     const Pts P{pts, ld, d};
-    // domains at least this large are argsorted by the threaded radix sort (BBFMM_DDM_RADIX_MIN overrides; tests)
-    const int64_t radix_min = std::getenv("BBFMM_DDM_RADIX_MIN") ? std::atoll(std::getenv("BBFMM_DDM_RADIX_MIN")) : (int64_t(1) << 20);
     out->d = d;
     out->levels.clear();
     std::vector<int64_t> active(static_cast<size_t>(n));
     std::iota(active.begin(), active.end(), int64_t(0));
 
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what, size_t level_no) {
+        if (!verbose) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm]   decomposition level %zu: %-28s %7.3f s\n", level_no, what,
+                     std::chrono::duration<double>(t - t_last).count());
+        t_last = t;
+    };
     while (static_cast<int64_t>(active.size()) > prm.coarse_threshold) {
         DdmLevel level;
         level.point_indices = active;
@@ -116,34 +125,43 @@ int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmPar
                         best = ext[a + d] - ext[a];
                         axis = a;
                     }
-                std::vector<int64_t> order(static_cast<size_t>(np));
-                std::iota(order.begin(), order.end(), int64_t(0));
-                if (np >= radix_min && ng <= 8) {
-                    // the few huge domains of the first generations: threaded stable radix sort on an
-                    // order-preserving integer image of the coordinate (same order as the comparison sort)
-                    std::vector<uint64_t> keys(static_cast<size_t>(np));
-                    for (int64_t k = 0; k < np; ++k) {
-                        double v = P.at(cur.idx[k], axis);
-                        if (v == 0.0) v = 0.0; // -0.0 == +0.0 for the comparison
-                        uint64_t b;
-                        std::memcpy(&b, &v, sizeof b);
-                        keys[k] = (b >> 63) ? ~b : (b | (uint64_t(1) << 63));
-                    }
-                    parallel_radix_sort_pairs(&keys, &order, 64);
-                } else {
-                    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { // argsort: stable
-                        return P.at(cur.idx[x], axis) < P.at(cur.idx[y], axis);
-                    });
-                }
+                // The reference argsorts the coordinate (stable) and cuts at np/2 (:118-147); only the two halves
+                // as index sets (then sorted) and the coordinate of the first element of the upper half are
+                // used.  The lower half of a stable argsort = every point below the median value v plus the
+                // first ties (in position order) that fill it up, so one selection and one ordered pass
+                // give the same sets -- already sorted, since cur.idx is ascending.
                 const int64_t mid = np / 2;
+                std::vector<double> vals(static_cast<size_t>(np));
+                for (int64_t k = 0; k < np; ++k) vals[k] = P.at(cur.idx[k], axis);
+                double v;
+                {
+                    std::vector<double> sel(vals);
+                    std::nth_element(sel.begin(), sel.begin() + mid, sel.end());
+                    v = sel[mid];
+                }
+                int64_t below = 0;
+                for (int64_t k = 0; k < np; ++k) below += vals[k] < v;
+                int64_t ties_left = mid - below; // ties that still belong to the lower half
                 DdmDomain &l = left[g], &r = right[g];
                 l.idx.reserve(static_cast<size_t>(mid));
                 r.idx.reserve(static_cast<size_t>(np - mid));
-                for (int64_t k = 0; k < mid; ++k) l.idx.push_back(cur.idx[order[k]]);
-                for (int64_t k = mid; k < np; ++k) r.idx.push_back(cur.idx[order[k]]);
-                const double mid_coord = P.at(cur.idx[order[mid]], axis);
-                std::sort(l.idx.begin(), l.idx.end());
-                std::sort(r.idx.begin(), r.idx.end());
+                double mid_coord = v;
+                bool have_mid = false;
+                for (int64_t k = 0; k < np; ++k) {
+                    const double x = vals[k];
+                    if (x < v) {
+                        l.idx.push_back(cur.idx[k]);
+                    } else if (x == v && ties_left > 0) {
+                        l.idx.push_back(cur.idx[k]);
+                        --ties_left;
+                    } else {
+                        if (x == v && !have_mid) { // element `mid` of the stable order (keeps the sign of a zero)
+                            mid_coord = x;
+                            have_mid = true;
+                        }
+                        r.idx.push_back(cur.idx[k]);
+                    }
+                }
                 l.extents = cur.extents;
                 l.extents[axis + d] = mid_coord;
                 r.extents = cur.extents;
@@ -168,6 +186,7 @@ int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmPar
             }
             gen.swap(next_gen);
         }
+        lap("median splits", out->levels.size());
         const int64_t nl = static_cast<int64_t>(level.leaves.size());
         const int64_t num_coarse = static_cast<int64_t>(
             std::ceil(std::ceil(static_cast<double>(active.size()) * prm.coarse_ratio) / static_cast<double>(nl))); // :165-168
@@ -227,12 +246,17 @@ int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmPar
                 }
                 bd[k] = std::sqrt(s);
             }
+            // the first `take` of the stable argsort by distance (:289-296): order by (distance, position),
+            // select that prefix, sort only it
             std::vector<int64_t> ord(cand.size());
             std::iota(ord.begin(), ord.end(), int64_t(0));
-            std::stable_sort(ord.begin(), ord.end(), [&](int64_t x, int64_t y) { return bd[x] < bd[y]; });
             const size_t take = std::min<size_t>(static_cast<size_t>(n_overlap[i]), cand.size());
+            auto before = [&](int64_t x, int64_t y) { return bd[x] < bd[y] || (bd[x] == bd[y] && x < y); };
+            if (take < ord.size()) std::nth_element(ord.begin(), ord.begin() + take, ord.end(), before);
+            std::sort(ord.begin(), ord.begin() + take, before);
             for (size_t k = 0; k < take; ++k) overlap[i].push_back(cand[ord[k]]);
         });
+        lap("coarse points + overlap", out->levels.size());
         std::vector<int64_t> next;
         for (int64_t i = 0; i < nl; ++i) {
             DdmDomain &dom = level.leaves[i];
@@ -241,6 +265,7 @@ int build_ddm_tree(const double *pts, int64_t n, int d, int64_t ld, const DdmPar
             next.insert(next.end(), coarse[i].begin(), coarse[i].end());
         }
         std::sort(next.begin(), next.end());
+        lap("merge", out->levels.size());
         out->levels.push_back(std::move(level));
         active.swap(next);
     }

@@ -197,6 +197,15 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     *lv = DdmLevelSolver();
     lv->d = d;
     lv->solve_for_poly = solve_for_poly;
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what, bool sync) { // BBFMM_VERBOSE: stage times (with a stream sync per stage)
+        if (!verbose) return;
+        if (sync) (void)hipStreamSynchronize(s);
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm]   level build: %-22s %8.3f s\n", what, std::chrono::duration<double>(t - t_last).count());
+        t_last = t;
+    };
     const int64_t nd = static_cast<int64_t>(level->leaves.size());
     lv->n_dom = nd;
     lv->prep.resize(static_cast<size_t>(nd));
@@ -206,6 +215,7 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     });
     for (int rc : rcs)
         if (rc != BBFMM_OK) return rc;
+    lap("host prep (QR, Q)", false);
     lv->dom_off.assign(static_cast<size_t>(nd) + 1, 0);
     lv->q_off.assign(static_cast<size_t>(nd) + 1, 0);
     lv->fac_off.assign(static_cast<size_t>(nd) + 1, 0);
@@ -235,6 +245,7 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
         }
         std::copy(lv->prep[i].q.begin(), lv->prep[i].q.end(), q.begin() + lv->q_off[i]);
     });
+    lap("host pack", false);
     int rc;
     for (int a = 0; a < 3; ++a)
         if ((rc = up(&lv->d_xyz[a], xyz[a], s)) != BBFMM_OK) return rc;
@@ -254,9 +265,12 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     int *d_fail = nullptr;
     DHIP(hipMalloc(reinterpret_cast<void **>(&d_fail), sizeof(int)));
     DHIP(hipMemsetAsync(d_fail, 0, sizeof(int), s));
+    lap("alloc + upload", true);
     launch_ddm_prep(ks, nugget, d, *lv, s);
     launch_ddm_assemble(ks, nugget, d, *lv, s);
+    lap("assemble", true);
     launch_ddm_cholesky(*lv, d_fail, s);
+    lap("cholesky", true);
     int fail = 0;
     DHIP(hipMemcpyAsync(&fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, s));
     DHIP(hipStreamSynchronize(s));

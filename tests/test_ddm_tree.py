@@ -27,6 +27,20 @@ def _clustered(rng, n, d):
     return np.clip(c[rng.integers(0, 6, n)] + 0.05 * rng.standard_normal((n, d)), 0.0, 1.0)
 
 
+def _same_tree(tree, ref):
+    assert len(tree.levels) == len(ref) >= 2
+    for lv, (a, b) in enumerate(zip(tree.levels, ref)):
+        assert list(a.point_indices) == list(b.point_indices), f"level {lv}"
+        assert len(a.leaf_domains) == len(b.leaf_domains)
+        for da, db in zip(a.leaf_domains, b.leaf_domains):
+            k = len(db.overlapping_point_indices)
+            assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
+            assert list(da.internal_points_mask) == [bool(m) for m in db.internal_points_mask[:k]]
+            if db.extents is not None:            # (the reference leaves the coarse domain's extents empty)
+                np.testing.assert_array_equal(da.extents, db.extents)
+                assert np.array_equal(np.signbit(da.extents), np.signbit(db.extents))
+
+
 @pytest.mark.parametrize("dim,n,prm,clustered", [
     (1, 700, DDMParams(20, 0.5, 0.25, 60), False),
     (2, 3000, DDMParams(50, 0.5, 0.125, 200), False),
@@ -38,17 +52,7 @@ def test_decomposition_equals_the_restatement(dim, n, prm, clustered):
     rng = np.random.default_rng(100 * dim + n)
     pts = _clustered(rng, n, dim) if clustered else rng.random((n, dim))
     tree = DDMTree(pts, prm)
-    ref = _oracle_levels(pts, prm)
-    assert len(tree.levels) == len(ref) >= 2
-    for lv, (a, b) in enumerate(zip(tree.levels, ref)):
-        assert list(a.point_indices) == list(b.point_indices), f"level {lv}"
-        assert len(a.leaf_domains) == len(b.leaf_domains)
-        for da, db in zip(a.leaf_domains, b.leaf_domains):
-            k = len(db.overlapping_point_indices)
-            assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
-            assert list(da.internal_points_mask) == [bool(m) for m in db.internal_points_mask[:k]]
-            if db.extents is not None:            # (the reference leaves the coarse domain's extents empty)
-                np.testing.assert_array_equal(da.extents, db.extents)
+    _same_tree(tree, _oracle_levels(pts, prm))
     # the reference's structural test (domain_decomposition.rs:378-596) on the product tree
     for lvl in tree.levels:
         union = sorted(int(g) for dm in lvl.leaf_domains
@@ -67,21 +71,13 @@ def test_defaults_and_bad_arguments():
         DDMTree(np.zeros((10, 4)))
 
 
-def test_radix_argsort_path_gives_the_same_tree(monkeypatch):
-    """The first, huge splits use a threaded radix argsort; forced on small input it must reproduce the
-    comparison-sort tree (ties included: duplicated coordinates, signed zeros)."""
+def test_median_selection_split_equals_the_stable_argsort_with_ties():
+    """ddm.cpp cuts a domain by selecting the median value and filling the lower half with the first ties
+    in position order; that must be the stable argsort cut of the reference (domain_decomposition.rs:118-147)
+    as the restatement does it -- duplicated coordinates and signed zeros included."""
     rng = np.random.default_rng(9)
     pts = np.round(rng.random((4000, 3)), 2) - 0.5          # many equal coordinates
     pts[::97] = 0.0
     pts[1::97, 0] = -0.0
     prm = DDMParams(50, 0.5, 0.125, 200)
-    monkeypatch.setenv("BBFMM_DDM_RADIX_MIN", "1000000000")
-    a = DDMTree(pts, prm)
-    monkeypatch.setenv("BBFMM_DDM_RADIX_MIN", "1")
-    b = DDMTree(pts, prm)
-    assert len(a.levels) == len(b.levels)
-    for la, lb in zip(a.levels, b.levels):
-        assert list(la.point_indices) == list(lb.point_indices) and len(la.leaf_domains) == len(lb.leaf_domains)
-        for da, db in zip(la.leaf_domains, lb.leaf_domains):
-            assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
-            assert list(da.internal_points_mask) == list(db.internal_points_mask)
+    _same_tree(DDMTree(pts, prm), _oracle_levels(pts, prm))
