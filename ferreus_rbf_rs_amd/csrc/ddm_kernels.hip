@@ -57,6 +57,12 @@ template <int KID> __global__ __launch_bounds__(256) void ddm_prep_kernel(Kernel
 }
 
 // lhs[i][j] (i >= j) = phi(x_i, x_j) + nugget [i == j] + sum_a (Q[a][i] G[a][j] + T[a][i] Q[a][j])
+// Factors are stored packed: the lower triangle column by column, column c = rows c..m-1
+// (m(m+1)/2 doubles; the reference packs too, LltRfp linalg.rs:37-72).  Element (r, c), r >= c:
+__device__ __forceinline__ int64_t pk(int r, int c, int m) {
+    return static_cast<int64_t>(c) * m - (static_cast<int64_t>(c) * (c - 1)) / 2 + (r - c);
+}
+
 template <int KID> __global__ __launch_bounds__(256) void ddm_assemble_kernel(KernelSpec ks, double nugget, View v) {
     const int dom = blockIdx.x;
     const int64_t o = v.dom_off[dom];
@@ -68,7 +74,7 @@ template <int KID> __global__ __launch_bounds__(256) void ddm_assemble_kernel(Ke
         for (int i = j + threadIdx.x; i < m; i += 256) {
             double s = phi<KID>(ks, v, o + k + i, o + k + j) + (i == j ? nugget : 0.0);
             for (int a = 0; a < k; ++a) s += Q[a * m + i] * G[a * m + j] + T[a * m + i] * Q[a * m + j];
-            A[i + static_cast<int64_t>(j) * m] = s;
+            A[pk(i, j, m)] = s;
         }
 }
 
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
         __syncthreads();
         for (int e = tid; e < nb * nb; e += 256) {
             const int r = e % nb, c = e / nb;
-            Ld[r][c] = r >= c ? A[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+            Ld[r][c] = r >= c ? A[pk(jb + r, jb + c, m)] : 0.0;
         }
         __syncthreads();
         for (int c = 0; c < nb; ++c) { // unblocked factorisation of the diagonal block
@@ -109,17 +115,17 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
         }
         for (int e = tid; e < nb * nb; e += 256) {
             const int r = e % nb, c = e / nb;
-            if (r >= c) A[(jb + r) + static_cast<int64_t>(jb + c) * m] = Ld[r][c];
+            if (r >= c) A[pk(jb + r, jb + c, m)] = Ld[r][c];
         }
         // panel: rows below the block, X L11^T = A21
         for (int r = jb + nb + tid; r < m; r += 256) {
             double xr[NB];
             for (int c = 0; c < nb; ++c) {
-                double s = A[r + static_cast<int64_t>(jb + c) * m];
+                double s = A[pk(r, jb + c, m)];
                 for (int c2 = 0; c2 < c; ++c2) s -= xr[c2] * Ld[c][c2];
                 xr[c] = s / Ld[c][c];
             }
-            for (int c = 0; c < nb; ++c) A[r + static_cast<int64_t>(jb + c) * m] = xr[c];
+            for (int c = 0; c < nb; ++c) A[pk(r, jb + c, m)] = xr[c];
         }
         __threadfence_block();
         __syncthreads();
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
                 __syncthreads();
                 for (int e = tid; e < 64 * nb; e += 256) {
                     const int r = e % 64, c = e / 64;
-                    Pr[r][c] = (tr + r < m) ? A[(tr + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
-                    Pc[r][c] = (tc + r < m) ? A[(tc + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+                    Pr[r][c] = (tr + r < m) ? A[pk(tr + r, jb + c, m)] : 0.0;
+                    Pc[r][c] = (tc + r < m) ? A[pk(tc + r, jb + c, m)] : 0.0;
                 }
                 __syncthreads();
                 double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const int r = tr + 4 * ty + u, c = tc + 4 * tx + w;
-                        if (r < m && c < m && r >= c) A[r + static_cast<int64_t>(c) * m] -= acc[u][w];
+                        if (r < m && c < m && r >= c) A[pk(r, c, m)] -= acc[u][w];
                     }
             }
         __threadfence_block();
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256) void chol_big_diag_kernel(double *A, int m, in
     const int tid = threadIdx.x, nb = min(NB, m - jb);
     for (int e = tid; e < nb * nb; e += 256) {
         const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? A[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        Ld[r][c] = r >= c ? A[pk(jb + r, jb + c, m)] : 0.0;
     }
     __syncthreads();
     for (int c = 0; c < nb; ++c) {
@@ -190,7 +196,7 @@ __global__ __launch_bounds__(256) void chol_big_diag_kernel(double *A, int m, in
     }
     for (int e = tid; e < nb * nb; e += 256) {
         const int r = e % nb, c = e / nb;
-        if (r >= c) A[(jb + r) + static_cast<int64_t>(jb + c) * m] = Ld[r][c];
+        if (r >= c) A[pk(jb + r, jb + c, m)] = Ld[r][c];
     }
 }
 
@@ -199,18 +205,18 @@ __global__ __launch_bounds__(256) void chol_big_panel_kernel(double *A, int m, i
     const int tid = threadIdx.x, nb = min(NB, m - jb);
     for (int e = tid; e < nb * nb; e += 256) {
         const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? A[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        Ld[r][c] = r >= c ? A[pk(jb + r, jb + c, m)] : 0.0;
     }
     __syncthreads();
     const int r = jb + nb + blockIdx.x * 256 + tid;
     if (r >= m) return;
     double xr[NB];
     for (int c = 0; c < nb; ++c) {
-        double s = A[r + static_cast<int64_t>(jb + c) * m];
+        double s = A[pk(r, jb + c, m)];
         for (int c2 = 0; c2 < c; ++c2) s -= xr[c2] * Ld[c][c2];
         xr[c] = s / Ld[c][c];
     }
-    for (int c = 0; c < nb; ++c) A[r + static_cast<int64_t>(jb + c) * m] = xr[c];
+    for (int c = 0; c < nb; ++c) A[pk(r, jb + c, m)] = xr[c];
 }
 
 __global__ __launch_bounds__(256) void chol_big_trail_kernel(double *A, int m, int jb) {
@@ -221,8 +227,8 @@ __global__ __launch_bounds__(256) void chol_big_trail_kernel(double *A, int m, i
     const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     for (int e = tid; e < 64 * nb; e += 256) {
         const int r = e % 64, c = e / 64;
-        Pr[r][c] = (tr + r < m) ? A[(tr + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
-        Pc[r][c] = (tc + r < m) ? A[(tc + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        Pr[r][c] = (tr + r < m) ? A[pk(tr + r, jb + c, m)] : 0.0;
+        Pc[r][c] = (tc + r < m) ? A[pk(tc + r, jb + c, m)] : 0.0;
     }
     __syncthreads();
     double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(256) void chol_big_trail_kernel(double *A, int m, i
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const int r = tr + 4 * ty + u, c = tc + 4 * tx + w;
-            if (r < m && c < m && r >= c) A[r + static_cast<int64_t>(c) * m] -= acc[u][w];
+            if (r < m && c < m && r >= c) A[pk(r, c, m)] -= acc[u][w];
         }
 }
 
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__
         const int nb = min(NB, m - jb);
         for (int e = tid; e < nb * nb; e += 256) {
             const int r = e % nb, c = e / nb;
-            Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+            Ld[r][c] = r >= c ? L[pk(jb + r, jb + c, m)] : 0.0;
         }
         if (tid < nb) yb[tid] = y[jb + tid];
         __syncthreads();
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__
         __syncthreads();
         for (int r = jb + nb + tid; r < m; r += 256) {
             double s = y[r];
-            for (int c = 0; c < nb; ++c) s -= L[r + static_cast<int64_t>(jb + c) * m] * yb[c];
+            for (int c = 0; c < nb; ++c) s -= L[pk(r, jb + c, m)] * yb[c];
             y[r] = s;
         }
         __threadfence_block();
@@ -307,11 +313,11 @@ __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__
         const int nb = min(NB, m - jb);
         for (int e = tid; e < nb * nb; e += 256) {
             const int r = e % nb, c = e / nb;
-            Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+            Ld[r][c] = r >= c ? L[pk(jb + r, jb + c, m)] : 0.0;
         }
         for (int c = wave; c < nb; c += 4) {
             double s = 0.0;
-            for (int r = jb + nb + lane; r < m; r += 64) s += L[r + static_cast<int64_t>(jb + c) * m] * y[r];
+            for (int r = jb + nb + lane; r < m; r += 64) s += L[pk(r, jb + c, m)] * y[r];
             for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
             if (lane == 0) yb[c] = y[jb + c] - s;
         }
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void big_fwd_step_kernel(const double *__restr
     const int tid = threadIdx.x, nb = min(SB, m - jb);
     for (int e = tid; e < nb * nb; e += 256) {
         const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        Ld[r][c] = r >= c ? L[pk(jb + r, jb + c, m)] : 0.0;
     }
     if (tid < nb) yb[tid] = y[jb + tid];
     __syncthreads();
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(256) void big_fwd_step_kernel(const double *__restr
     double s = 0.0;
     if (r < m) {
         const int c0 = q * 16, c1 = min(nb, c0 + 16);
-        for (int c = c0; c < c1; ++c) s += L[r + static_cast<int64_t>(jb + c) * m] * yb[c];
+        for (int c = c0; c < c1; ++c) s += L[pk(r, jb + c, m)] * yb[c];
     }
     part[q][lane] = s;
     __syncthreads();
@@ -411,7 +417,7 @@ __global__ __launch_bounds__(256) void big_bwd_step_kernel(const double *__restr
     const int tid = threadIdx.x, nb = min(SB, m - jb);
     for (int e = tid; e < nb * nb; e += 256) {
         const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? L[(jb + r) + static_cast<int64_t>(jb + c) * m] : 0.0;
+        Ld[r][c] = r >= c ? L[pk(jb + r, jb + c, m)] : 0.0;
     }
     if (tid < nb) yb[tid] = z[jb + tid];
     __syncthreads();
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void big_bwd_step_kernel(const double *__restr
     const double gl = lane < nb ? yb[lane] : 0.0;
     const int cbeg = blockIdx.x * 64 + wave * 16, cend = min(jb, cbeg + 16);
     for (int c = cbeg; c < cend; ++c) {
-        double s = lane < nb ? L[(jb + lane) + static_cast<int64_t>(c) * m] * gl : 0.0;
+        double s = lane < nb ? L[pk(jb + lane, c, m)] * gl : 0.0;
         for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
         if (lane == 0) z[c] -= s;
     }

@@ -226,7 +226,7 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
         lv->k[i] = static_cast<int32_t>(kk);
         lv->dom_off[i + 1] = lv->dom_off[i] + n;
         lv->q_off[i + 1] = lv->q_off[i] + kk * m;
-        lv->fac_off[i + 1] = lv->fac_off[i] + m * m;
+        lv->fac_off[i + 1] = lv->fac_off[i] + m * (m + 1) / 2; // packed lower triangle (ddm_kernels.hip pk)
         lv->max_m = std::max<int>(lv->max_m, static_cast<int>(m));
     }
     lv->n_entries = lv->dom_off[nd];

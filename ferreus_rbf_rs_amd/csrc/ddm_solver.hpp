@@ -35,7 +35,7 @@ struct DdmLevelSolver {
     std::vector<int64_t> dom_off;  // n_dom + 1: first entry (point) of a domain
     std::vector<int32_t> k;        // special points per domain
     std::vector<int64_t> q_off;    // n_dom + 1: offsets into q / scratch (k*m doubles each)
-    std::vector<int64_t> fac_off;  // n_dom + 1: offsets into fac (m*m doubles each)
+    std::vector<int64_t> fac_off;  // n_dom + 1: offsets into fac (packed lower triangles, m(m+1)/2 doubles each)
     std::vector<DomainPrep> prep;  // host copies (polynomial recovery of the coarse domain)
     std::vector<int64_t> gidx_h;   // global index per entry
     bool solve_for_poly = false;
