@@ -82,12 +82,36 @@ constexpr int NB = 32; // panel width of the one-large-matrix path and of the su
 constexpr int CB = 64; // block-column width of the per-domain factorisation
 
 // In-place lower Cholesky, one workgroup per matrix, LEFT-looking over 64-column block columns: a
-// block column is first brought up to date with everything left of it (64 x 64 tiles, 4 x 4 per thread,
-// the two factor panels staged through LDS 32 columns at a time, the accumulator kept in registers
-// over the whole sweep so that a tile is read and written once), then its diagonal block is
-// factorised in LDS and the rows below are solved against it.  The right-looking order with 32-column
-// panels re-read and re-wrote the whole trailing matrix per panel (0.45 GB per 1,220-point domain,
-// HBM bound); this order reads 0.08 GB.
+// block column is first brought up to date with everything left of it (64 x 64 tiles on
+// v_mfma_f64_16x16x4: each of the four waves owns a 32 x 32 quadrant = 2 x 2 MFMA tiles; the two factor
+// panels are staged through LDS 32 columns at a time and the accumulators stay in registers over the
+// whole sweep, so a tile is read and written once), then its diagonal block is factorised in LDS,
+// inverted there in place, and the rows below are a product with that inverse on the same tiles.
+// (The right-looking order with 32-column panels re-read and re-wrote the whole trailing matrix per
+// panel: 0.45 GB per 1,220-point domain, HBM bound; this order reads 0.08 GB.)
+//
+// MFMA operand map (cdna_hip_programming.md): lane l supplies A[l&15][l>>4] and B[l>>4][l&15], and
+// holds D[(l>>4) + 4v][l&15], v = 0..3.  The tiles are computed transposed, D' = Pc Pr^T, so that
+// the sixteen lanes of a result register walk down a column of the packed factor (contiguous).
+using d4 = __attribute__((ext_vector_type(4))) double;
+
+// acc[ci][ri] += Pc[cb + 16ci + .][k0..k0+32) Pr[rb + 16ri + .][k0..)^T for the wave's quadrant
+template <int LDC, int LDR>
+__device__ __forceinline__ void quad_mfma32(const double (*Pc)[LDC], int ck0, const double (*Pr)[LDR], int cb, int rb,
+                                            int lane, d4 (&acc)[2][2]) {
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int s4 = 0; s4 < NB / 4; ++s4) {
+        const int kk = 4 * s4 + lk;
+        const double a0 = Pc[cb + li][ck0 + kk], a1 = Pc[cb + 16 + li][ck0 + kk];
+        const double b0 = Pr[rb + li][kk], b1 = Pr[rb + 16 + li][kk];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
     const int dom = blockIdx.x;
     const int64_t o = v.dom_off[dom];
@@ -97,14 +121,16 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
     __shared__ double Pr[64][NB + 1], Pc[64][NB + 1];
     __shared__ double colj[CB];
     __shared__ int bad;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1); // the wave's quadrant of a 64 x 64 tile
+    const int li = lane & 15, lk = lane >> 4;
     if (tid == 0) bad = 0;
     for (int jb = 0; jb < m; jb += CB) {
         const int nb = min(CB, m - jb);
         // 1. A[jb.., jb..jb+nb) -= L[jb.., 0..jb) L[jb..jb+nb, 0..jb)^T
         if (jb > 0)
             for (int tr = jb; tr < m; tr += 64) {
-                double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+                d4 acc[2][2] = {};
                 for (int kc = 0; kc < jb; kc += NB) { // jb is a multiple of 64: full chunks
                     __syncthreads();
                     for (int e = tid; e < 64 * NB; e += 256) {
@@ -113,34 +139,24 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
                         Pc[r][c] = (r < nb) ? A[pk(jb + r, kc + c, m)] : 0.0;
                     }
                     __syncthreads();
-#pragma unroll 8
-                    for (int c = 0; c < NB; ++c) {
-                        double pr[4], pc[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) {
-                            pr[u] = Pr[4 * ty + u][c];
-                            pc[u] = Pc[4 * tx + u][c];
-                        }
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int w = 0; w < 4; ++w) acc[u][w] += pr[u] * pc[w];
-                    }
+                    quad_mfma32(Pc, 0, Pr, cb, rb, lane, acc);
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const int r = tr + 4 * ty + u, c = jb + 4 * tx + w;
-                        if (r < m && c < jb + nb && r >= c) A[pk(r, c, m)] -= acc[u][w];
-                    }
+                    for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int r = tr + rb + 16 * ri + li, c = jb + cb + 16 * ci + lk + 4 * q;
+                            if (r < m && c < jb + nb && r >= c) A[pk(r, c, m)] -= acc[ci][ri][q];
+                        }
             }
         __threadfence_block();
         __syncthreads();
-        // 2. diagonal block
-        for (int e = tid; e < nb * nb; e += 256) {
-            const int r = e % nb, c = e / nb;
-            Ld[r][c] = r >= c ? A[pk(jb + r, jb + c, m)] : 0.0;
+        // 2. diagonal block, always handled as 64 x 64 (a short last block is padded with the identity)
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int r = e & (CB - 1), c = e >> 6;
+            Ld[r][c] = (r < nb && c < nb) ? (r >= c ? A[pk(jb + r, jb + c, m)] : 0.0) : (r == c ? 1.0 : 0.0);
         }
         __syncthreads();
         for (int c = 0; c < nb; ++c) {
@@ -150,25 +166,23 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
                 Ld[c][c] = sqrt(dd > 0.0 ? dd : 1.0);
             }
             __syncthreads();
-            if (tid > c && tid < nb) Ld[tid][c] /= Ld[c][c];
+            if (tid > c && tid < CB) Ld[tid][c] /= Ld[c][c];
             __syncthreads();
-            for (int e = tid; e < nb * nb; e += 256) {
-                const int r = e % nb, c2 = e / nb;
-                if (c2 > c && r >= c2) Ld[r][c2] -= Ld[r][c] * Ld[c2][c];
+            // rank-1 update of the columns right of c: thread = (row, one of four column phases)
+            {
+                const int r = tid & (CB - 1);
+                const double lrc = Ld[r][c];
+                for (int c2 = c + 1 + (tid >> 6); c2 <= r; c2 += 4) Ld[r][c2] -= lrc * Ld[c2][c];
             }
             __syncthreads();
         }
-        for (int e = tid; e < nb * nb; e += 256) {
-            const int r = e % nb, c = e / nb;
-            if (r >= c) A[pk(jb + r, jb + c, m)] = Ld[r][c];
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int r = e & (CB - 1), c = e >> 6;
+            if (r >= c && r < nb) A[pk(jb + r, jb + c, m)] = Ld[r][c];
         }
         if (jb + nb >= m) break;
         // 3. rows below the block: X = A21 L11^{-T}.  L11 is inverted in place in LDS (column by column from
-        // the right, as LAPACK's trti2), then X is a product with the same 4 x 4 register tiles.
-        for (int e = tid; e < CB * CB; e += 256) { // pad a short last block to the identity
-            const int r = e % CB, c = e / CB;
-            if (r >= nb || c >= nb) Ld[r][c] = (r == c) ? 1.0 : 0.0;
-        }
+        // the right, as LAPACK's trti2), then X is a product on the same MFMA tiles.
         __syncthreads();
         for (int j = CB - 1; j >= 0; --j) {
             if (tid < CB) colj[tid] = Ld[tid][j];
@@ -183,7 +197,7 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
             __syncthreads();
         }
         for (int tr = jb + nb; tr < m; tr += 64) {
-            double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+            d4 acc[2][2] = {};
             for (int kh = 0; kh < CB; kh += NB) {
                 __syncthreads();
                 for (int e = tid; e < 64 * NB; e += 256) {
@@ -191,28 +205,18 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
                     Pr[r][c] = (tr + r < m && kh + c < nb) ? A[pk(tr + r, jb + kh + c, m)] : 0.0;
                 }
                 __syncthreads();
-#pragma unroll 8
-                for (int c = 0; c < NB; ++c) {
-                    double pr[4], pc[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        pr[u] = Pr[4 * ty + u][c];
-                        pc[u] = Ld[4 * tx + u][kh + c]; // inv(L11)[column of X][k]
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-#pragma unroll
-                        for (int w = 0; w < 4; ++w) acc[u][w] += pr[u] * pc[w];
-                }
+                quad_mfma32(Ld, kh, Pr, cb, rb, lane, acc); // inv(L11)[column of X][k]
             }
             __syncthreads(); // every read of this row tile is done before it is overwritten
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const int r = tr + 4 * ty + u, c = 4 * tx + w;
-                    if (r < m && c < nb) A[pk(r, jb + c, m)] = acc[u][w];
-                }
+                for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = tr + rb + 16 * ri + li, c = cb + 16 * ci + lk + 4 * q;
+                        if (r < m && c < nb) A[pk(r, jb + c, m)] = acc[ci][ri][q];
+                    }
         }
         __threadfence_block();
         __syncthreads();
