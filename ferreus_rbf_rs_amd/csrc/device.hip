@@ -994,8 +994,10 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     // stage 1: the workgroup walks the column blocks zb0 .. zb1 of kM2lS1Block stacked rows (g16_0
     // selects a chunk inside a block); stage 2: one block, g16_0 selects the nodes
     const int n_zb = STAGE == 1 ? cls.r_pad16 / kM2lS1Block : 1;
-    const int zb0 = STAGE == 1 ? (int)((int64_t)n_zb * blockIdx.z / gridDim.z) : 0;
-    const int zb1 = STAGE == 1 ? (int)((int64_t)n_zb * (blockIdx.z + 1) / gridDim.z) : 1;
+    // (a tile of a sparse plan, pad == 2, names its own column blocks: q_first, q_count)
+    const bool own_blocks = STAGE == 1 && tile.pad == 2;
+    const int zb0 = STAGE == 1 ? (own_blocks ? tile.q_first : (int)((int64_t)n_zb * blockIdx.z / gridDim.z)) : 0;
+    const int zb1 = STAGE == 1 ? (own_blocks ? tile.q_first + tile.q_count : (int)((int64_t)n_zb * (blockIdx.z + 1) / gridDim.z)) : 1;
     const int ld = STAGE == 1 ? cls.r_pad16 : n_pad;            // operator leading dimension
     // contraction steps of 16: all of them in stage 1; in stage 2 only those for which some cell
     // of the tile has a V-list entry (tile.q_first/q_count index the compact list qlist)
@@ -1496,7 +1498,7 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
 // blockIdx.z walks the column blocks, the chunk plan splits a block.
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
-                       hipStream_t s) {
+                       hipStream_t s, bool own_blocks) {
     if (n_tiles == 0) return;
     int slot_t = 16; // LDS slot-table width: power of two covering the transfer vectors of any block
     while (slot_t < max_slot_t) slot_t *= 2;
@@ -1507,7 +1509,7 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
         const int v = e ? std::atoi(e) : 2;
         return v >= 1 && v <= 16 ? v : 2;
     }();
-    const int n_colblocks = zsplit;
+    const int n_colblocks = own_blocks ? 1 : zsplit; // tiles that name their own blocks are not split further
     m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, slot_t, tile_idx, s);
 }
 

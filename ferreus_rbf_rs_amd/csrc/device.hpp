@@ -63,7 +63,8 @@ struct M2lTileDesc { // one workgroup of stage 1 or stage 2
     int32_t count;       // <= kM2lTile
     int32_t q_first;     // stage 2: first entry / number of entries of the tile's active-step list
     int32_t q_count;
-    int32_t pad;
+    int32_t pad;         // 0: cells first..first+count of the class; 1: first indexes tile_idx (class positions);
+                         // 2: as 1, and a stage-1 tile covers only the column blocks q_first..q_first+q_count
 };
 
 // ---- launchers (all asynchronous on `s`) ----
@@ -89,7 +90,7 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
 // (tile.first indexes tile_idx; a partition's compact source tiles)
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf,
-                       int64_t cbuf_len, hipStream_t s);
+                       int64_t cbuf_len, hipStream_t s, bool own_blocks = false);
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
                        const uint16_t *qlist, double *L, hipStream_t s);

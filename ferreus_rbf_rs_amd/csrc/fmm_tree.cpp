@@ -449,14 +449,18 @@ int FmmTree::build_m2l_tables() {
             hc.tgt_tv = tgt_list[o];
             hc.tgt_off = off_tgt[o];
             int row = 0;
+            hc.src_row0.assign(src_list[o].size(), 0);
+            hc.src_row1.assign(src_list[o].size(), 0);
             for (size_t pos = 0; pos < src_list[o].size(); ++pos) {
                 const int tv = src_list[o][pos];
                 const int oc = target_class(o, tv);
                 const int base_off = off_tgt[oc][tpos_tgt[oc][tv]];
+                hc.src_row0[pos] = row;
                 for (int kk = 0; kk < rank_of(tv); ++kk, ++row) {
                     hc.row_tpos[row] = static_cast<int32_t>(pos);
                     hc.row_off[row] = base_off + kk;
                 }
+                hc.src_row1[pos] = row;
                 row = round_up(row, 2); // the padding row keeps tpos -1 (never stored on its own)
             }
             // per column block: first transfer-vector position, and the packed row table
@@ -991,7 +995,7 @@ int FmmTree::downward(int k, const DownwardPlan *dp) {
     phase_begin();
     if (dp)
         launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles1_h.size()),
-                          cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
+                          cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_, dp->tiles1_own_blocks);
     else
         launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles_.p, nullptr, n_all, cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p,
                           d_cbuf_.p, cbuf_len_, stream_);
@@ -1377,6 +1381,82 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         }
     }
     split_tile_tail(&dp->tiles2_h, n_cu_);
+    // Sparse target sets: a needed source cell still needs only the column blocks (kM2lS1Block stacked
+    // rows = a few transfer vectors) that hold a transfer vector towards an ACTIVE target.  When that is
+    // well under the whole operator, stage 1 runs one tile per (column block, the sources it needs).
+    int64_t n_active = 0;
+    for (uint8_t a : active) n_active += a;
+    if (n_active * 4 < C) { // (denser sets need nearly every block of every source: skip the analysis)
+        std::vector<int32_t> cls_of(static_cast<size_t>(C), -1), pos_of(static_cast<size_t>(C), -1);
+        std::vector<int64_t> bm_off(m2l_host_.size() + 1, 0); // per class: n_blk x n_cells flags
+        for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+            const HostM2lClass &hc = m2l_host_[lc];
+            for (size_t i = 0; i < hc.cells.size(); ++i) {
+                cls_of[hc.cells[i]] = static_cast<int32_t>(lc);
+                pos_of[hc.cells[i]] = static_cast<int32_t>(i);
+            }
+            bm_off[lc + 1] = bm_off[lc] + static_cast<int64_t>(hc.r_pad16 / kM2lS1Block) * static_cast<int64_t>(hc.cells.size());
+        }
+        std::vector<uint8_t> bm(static_cast<size_t>(bm_off.back()), 0);
+        std::vector<std::vector<int32_t>> spos(m2l_host_.size());
+        for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+            spos[lc].assign(static_cast<size_t>(ops_.n_vec), -1);
+            for (size_t pos = 0; pos < m2l_host_[lc].src_tv.size(); ++pos) spos[lc][m2l_host_[lc].src_tv[pos]] = static_cast<int32_t>(pos);
+        }
+        for (int64_t B = 0; B < C; ++B) {
+            if (!active[B] || t.level[B] < 2) continue;
+            for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
+                const int32_t S = t.v.idx[q];
+                const int tv = t.v_tidx[q];
+                const int32_t lc = cls_of[S];
+                if (lc < 0 || tv < 0 || tv >= ops_.n_vec) continue;
+                const int32_t sp = spos[lc][tv];
+                if (sp < 0) continue;
+                const HostM2lClass &hc = m2l_host_[lc];
+                if (hc.src_row1[sp] <= hc.src_row0[sp]) continue;
+                const int64_t nc = static_cast<int64_t>(hc.cells.size());
+                for (int zb = hc.src_row0[sp] / kM2lS1Block; zb <= (hc.src_row1[sp] - 1) / kM2lS1Block; ++zb)
+                    bm[static_cast<size_t>(bm_off[lc] + zb * nc + pos_of[S])] = 1;
+            }
+        }
+        int64_t whole = 0, part = 0; // cell-blocks of work: needed cells x all blocks, against the flagged ones
+        for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+            const HostM2lClass &hc = m2l_host_[lc];
+            int64_t nn = 0;
+            for (int32_t c : hc.cells) nn += needed[c];
+            whole += nn * (hc.r_pad16 / kM2lS1Block);
+        }
+        for (uint8_t f : bm) part += f;
+        static const double max_ratio = [] {
+            const char *e = std::getenv("BBFMM_M2L_SPARSE_RATIO");
+            return e ? std::atof(e) : 0.6;
+        }();
+        dp->tiles1_own_blocks = whole > 0 && static_cast<double>(part) < max_ratio * static_cast<double>(whole);
+        if (dp->tiles1_own_blocks) {
+            dp->tiles1_h.clear();
+            for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+                const HostM2lClass &hc = m2l_host_[lc];
+                const int64_t nc = static_cast<int64_t>(hc.cells.size());
+                for (int zb = 0; zb < hc.r_pad16 / kM2lS1Block; ++zb) {
+                    const size_t start = dp->tile_idx_h.size();
+                    const uint8_t *f = &bm[static_cast<size_t>(bm_off[lc] + zb * nc)];
+                    for (int64_t i = 0; i < nc; ++i)
+                        if (f[i]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
+                    for (size_t fst = start; fst < dp->tile_idx_h.size(); fst += kM2lTile) {
+                        M2lTileDesc td;
+                        std::memset(&td, 0, sizeof td);
+                        td.level_class = static_cast<int32_t>(lc);
+                        td.first = static_cast<int32_t>(fst);
+                        td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - fst));
+                        td.q_first = zb;
+                        td.q_count = 1;
+                        td.pad = 2;
+                        dp->tiles1_h.push_back(td);
+                    }
+                }
+            }
+        }
+    }
     std::vector<int32_t> xc, xruns;
     std::vector<int64_t> xptr(1, 0);
     for (int32_t c : x_cells_) {
@@ -1450,8 +1530,15 @@ int FmmTree::subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out) {
         });
     std::vector<int32_t> leaves;
     int64_t bad = -1;
+    const auto t_0 = std::chrono::steady_clock::now();
     int rc = build_target_set(x.data(), m, std::max<int64_t>(m, 1), &sp->ts, &bad, &leaves);
+    const auto t_1 = std::chrono::steady_clock::now();
     if (rc == BBFMM_OK) rc = build_downward_plan(leaves, &sp->dp);
+    if (std::getenv("BBFMM_VERBOSE"))
+        std::fprintf(stderr, "[bbfmm] subset plan: %lld rows, target set %.3f s, downward plan %.3f s (%zu stage-1 tiles%s)\n",
+                     static_cast<long long>(m), std::chrono::duration<double>(t_1 - t_0).count(),
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_1).count(), sp->dp.tiles1_h.size(),
+                     sp->dp.tiles1_own_blocks ? ", one column block each" : "");
     if (rc == BBFMM_OK) rc = dalloc(&sp->ts.out, static_cast<size_t>(std::max<int64_t>(m, 1)));
     if (rc != BBFMM_OK) {
         free_target_set(&sp->ts);

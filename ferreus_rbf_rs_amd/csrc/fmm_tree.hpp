@@ -37,6 +37,7 @@ struct HostM2lClass {
     std::vector<double> vt_all, u_all; // kept only on BBFMM_FLAG_HOST_ONLY handles
     std::vector<int> src_tv, tgt_tv, tgt_off; // transfer vectors (source / target side), slot offsets
     std::vector<int32_t> row_tpos, row_off, row_dst, blk_t0, cells, cslot;
+    std::vector<int32_t> src_row0, src_row1; // stacked rows [row0, row1) of each source-side transfer vector
     std::vector<int64_t> cbase;
 };
 
@@ -59,6 +60,7 @@ struct DownwardPlan {
     std::vector<uint8_t> active;            // cells with targets (leaves and their ancestors)
     std::vector<M2lTileDesc> tiles2_h;      // compact stage-2 tiles over the active cells (tail split)
     std::vector<M2lTileDesc> tiles1_h;      // compact stage-1 tiles over the V-list sources of active cells
+    bool tiles1_own_blocks = false;         // sparse plan: a stage-1 tile per (column block, sources that block needs)
     std::vector<int32_t> tile_idx_h;        // class positions of the cells of both tile lists
     std::vector<uint16_t> qlist_h;          // active contraction steps of the stage-2 tiles
     int n_x_jobs = 0;
