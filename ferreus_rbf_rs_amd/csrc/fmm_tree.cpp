@@ -1119,7 +1119,8 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
         // targets touch every cell anyway and the whole-tree pass needs no plan.  Once
         // set_local_coefficients has stored the whole-tree expansions (Leaves mode, rbf.rs:836-838)
         // the whole-tree pass is kept, so that evaluate_leaves stays valid afterwards.
-        const bool restricted = m * 4 < tree_.n_points && !locals_requested_;
+        // (planning costs host time per call: measured break-even near N/100 targets at 10M sources)
+        const bool restricted = m * 128 < tree_.n_points && !locals_requested_;
         if (restricted) rc = build_downward_plan(target_leaves, &dplan);
         if (rc == BBFMM_OK) rc = downward(k, restricted ? &dplan : nullptr);
     }
@@ -1326,16 +1327,18 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
     }
     const std::vector<uint8_t> &active = dp->active;
     std::vector<uint8_t> needed(static_cast<size_t>(C), 0);
-    for (int64_t B = 0; B < C; ++B) {
-        if (!active[B] || t.level[B] < 2) continue;
-        for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) needed[t.v.idx[q]] = 1;
-    }
+    auto flag = [](uint8_t *p) { __atomic_store_n(p, uint8_t(1), __ATOMIC_RELAXED); }; // threads may set the same flag
+    parallel_for_chunks(C, 4096, [&](int64_t lo, int64_t hi) {
+        for (int64_t B = lo; B < hi; ++B) {
+            if (!active[B] || t.level[B] < 2) continue;
+            for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) flag(&needed[t.v.idx[q]]);
+        }
+    });
     dp->tiles2_h.clear();
     dp->tiles1_h.clear();
     dp->tile_idx_h.clear();
     dp->qlist_h.clear();
     std::vector<int> tpos_of(static_cast<size_t>(ops_.n_vec));
-    std::vector<uint8_t> act;
     for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
         const HostM2lClass &hc = m2l_host_[lc];
         if (hc.cells.empty()) continue;
@@ -1361,9 +1364,11 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         for (size_t pos = 0; pos < hc.tgt_tv.size(); ++pos) tpos_of[hc.tgt_tv[pos]] = static_cast<int>(pos);
         const auto &lops = ops_.m2l[hc.level];
         const int nq = hc.k_pad / 16;
-        for (size_t ti = t2; ti < dp->tiles2_h.size(); ++ti) {
-            M2lTileDesc &td = dp->tiles2_h[ti];
-            act.assign(static_cast<size_t>(nq), 0);
+        const int64_t n_t2 = static_cast<int64_t>(dp->tiles2_h.size() - t2);
+        std::vector<std::vector<uint16_t>> tile_q(static_cast<size_t>(n_t2));
+        parallel_for(n_t2, 4, [&](int64_t k) {
+            const M2lTileDesc &td = dp->tiles2_h[t2 + static_cast<size_t>(k)];
+            std::vector<uint8_t> act_k(static_cast<size_t>(nq), 0);
             for (int32_t i = 0; i < td.count; ++i) {
                 const int64_t B = hc.cells[dp->tile_idx_h[td.first + i]];
                 for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
@@ -1371,12 +1376,16 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
                     const int pos = tv >= 0 && tv < ops_.n_vec ? tpos_of[tv] : -1;
                     if (pos < 0) continue;
                     const int a = hc.tgt_off[pos], b = a + lops[ops_.ref_lookup[tv]].rank;
-                    for (int sq = a / 16; sq <= (b - 1) / 16; ++sq) act[sq] = 1;
+                    for (int sq = a / 16; sq <= (b - 1) / 16; ++sq) act_k[sq] = 1;
                 }
             }
-            td.q_first = static_cast<int32_t>(dp->qlist_h.size());
             for (int sq = 0; sq < nq; ++sq)
-                if (act[sq]) dp->qlist_h.push_back(static_cast<uint16_t>(sq));
+                if (act_k[sq]) tile_q[static_cast<size_t>(k)].push_back(static_cast<uint16_t>(sq));
+        });
+        for (int64_t k = 0; k < n_t2; ++k) {
+            M2lTileDesc &td = dp->tiles2_h[t2 + static_cast<size_t>(k)];
+            td.q_first = static_cast<int32_t>(dp->qlist_h.size());
+            dp->qlist_h.insert(dp->qlist_h.end(), tile_q[static_cast<size_t>(k)].begin(), tile_q[static_cast<size_t>(k)].end());
             td.q_count = static_cast<int32_t>(dp->qlist_h.size()) - td.q_first;
         }
     }
@@ -1403,22 +1412,24 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
             spos[lc].assign(static_cast<size_t>(ops_.n_vec), -1);
             for (size_t pos = 0; pos < m2l_host_[lc].src_tv.size(); ++pos) spos[lc][m2l_host_[lc].src_tv[pos]] = static_cast<int32_t>(pos);
         }
-        for (int64_t B = 0; B < C; ++B) {
-            if (!active[B] || t.level[B] < 2) continue;
-            for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
-                const int32_t S = t.v.idx[q];
-                const int tv = t.v_tidx[q];
-                const int32_t lc = cls_of[S];
-                if (lc < 0 || tv < 0 || tv >= ops_.n_vec) continue;
-                const int32_t sp = spos[lc][tv];
-                if (sp < 0) continue;
-                const HostM2lClass &hc = m2l_host_[lc];
-                if (hc.src_row1[sp] <= hc.src_row0[sp]) continue;
-                const int64_t nc = static_cast<int64_t>(hc.cells.size());
-                for (int zb = hc.src_row0[sp] / kM2lS1Block; zb <= (hc.src_row1[sp] - 1) / kM2lS1Block; ++zb)
-                    bm[static_cast<size_t>(bm_off[lc] + zb * nc + pos_of[S])] = 1;
+        parallel_for_chunks(C, 4096, [&](int64_t lo, int64_t hi) {
+            for (int64_t B = lo; B < hi; ++B) {
+                if (!active[B] || t.level[B] < 2) continue;
+                for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
+                    const int32_t S = t.v.idx[q];
+                    const int tv = t.v_tidx[q];
+                    const int32_t lc = cls_of[S];
+                    if (lc < 0 || tv < 0 || tv >= ops_.n_vec) continue;
+                    const int32_t sp = spos[lc][tv];
+                    if (sp < 0) continue;
+                    const HostM2lClass &hc = m2l_host_[lc];
+                    if (hc.src_row1[sp] <= hc.src_row0[sp]) continue;
+                    const int64_t nc = static_cast<int64_t>(hc.cells.size());
+                    for (int zb = hc.src_row0[sp] / kM2lS1Block; zb <= (hc.src_row1[sp] - 1) / kM2lS1Block; ++zb)
+                        flag(&bm[static_cast<size_t>(bm_off[lc] + zb * nc + pos_of[S])]);
+                }
             }
-        }
+        });
         int64_t whole = 0, part = 0; // cell-blocks of work: needed cells x all blocks, against the flagged ones
         for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
             const HostM2lClass &hc = m2l_host_[lc];
