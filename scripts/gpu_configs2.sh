@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-run() { echo "== $*"; timeout 900 python scripts/check_config.py "$@" 2>/dev/null | python3 -c "
+run() { echo "== $*"; timeout 900 python tests/checks/check_config.py "$@" 2>/dev/null | python3 -c "
 import sys,json
 for l in sys.stdin:
     if l.startswith('{'):

@@ -3,7 +3,7 @@
 set -x
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-python scripts/gpu_first.py selftest parity timings > gpurun_out/gpu_first_stdout.txt 2>&1
+python tests/checks/gpu_first.py selftest parity timings > gpurun_out/gpu_first_stdout.txt 2>&1
 tail -40 gpurun_out/gpu_first.log
 python bench.py --points 1000000 --steps 5 --warmup 1 > gpurun_out/bench_1m.json 2> gpurun_out/bench_1m.err
 tail -3 gpurun_out/bench_1m.err; cat gpurun_out/bench_1m.json

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """One BASELINE.json config on the GPU: matvec timing + sampled rows against the dense direct sum.
 
-  python scripts/check_config.py --points 10000000 --kernel ThinPlateSplineRbf --order 9 --nrhs 1
+  python tests/checks/check_config.py --points 10000000 --kernel ThinPlateSplineRbf --order 9 --nrhs 1
 """
 import argparse, json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--points", type=int, default=1_000_000)

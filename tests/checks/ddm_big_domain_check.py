@@ -1,5 +1,5 @@
 import numpy as np, sys, os
-root=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+root=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root,"tests"))
 import ferreus_rbf_rs_amd as F
 from ferreus_rbf_rs_amd.ddm import DDMParams, InterpolantSettings, SchwarzPreconditioner

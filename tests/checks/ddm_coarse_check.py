@@ -3,7 +3,7 @@
 on the coarse points must reproduce r there (the coarse solve is a direct solve of that block)."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ferreus_rbf_rs_amd as F
 from ferreus_rbf_rs_amd.ddm import DDMParams, InterpolantSettings, SchwarzPreconditioner
 n = int(sys.argv[1]); ct = int(sys.argv[2]); kid = int(sys.argv[3]) if len(sys.argv) > 3 else 1

@@ -2,7 +2,7 @@
 Writes gpurun_out/gpu_first.log.  (Development aid; the real tests live in tests/.)"""
 import os, sys, time, traceback, json
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import ferreus_rbf_rs_amd as F
 from oracle import bbfmm_oracle as O
 

@@ -3,7 +3,7 @@
 linearity of the whole pipeline (device-resident matvec)."""
 import json, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import ferreus_rbf_rs_amd as F
 from oracle import bbfmm_oracle as O
