@@ -19,11 +19,13 @@ struct View {
     const uint8_t *internal;
     const double *q;
     double *t, *g, *fac, *work;
+    const uint8_t *mode; // per domain: 0 = Cholesky factor, 1 = packed symmetric inverse (host fallback); may be null
+    double *tmp;         // n_entries scratch of the fallback path
 };
 
 View make_view(const DdmLevelSolver &lv) {
     return View{lv.d_xyz[0], lv.d_xyz[1], lv.d_xyz[2], lv.d_gidx, lv.d_dom_off, lv.d_q_off, lv.d_fac_off,
-                lv.d_k,      lv.d_internal, lv.d_q, lv.d_t, lv.d_g, lv.d_fac, lv.d_work};
+                lv.d_k,      lv.d_internal, lv.d_q, lv.d_t, lv.d_g, lv.d_fac, lv.d_work, lv.d_mode, lv.d_tmp};
 }
 
 template <int KID> __device__ inline double phi(const KernelSpec &ks, const View &v, int64_t a, int64_t b) {
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
         __threadfence_block();
         __syncthreads();
     }
-    if (tid == 0 && bad) atomicExch(fail, 1);
+    if (tid == 0 && bad) fail[dom] = 1; // per-domain flag: the host refactorises that domain (ddm_solver.cpp)
 }
 
 // The same factorisation for one large matrix (the coarse domain, m up to tens of thousands) spread
@@ -334,6 +336,22 @@ __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__
     }
     __threadfence_block();
     __syncthreads();
+    if (v.mode && v.mode[dom]) {
+        // the domain's Cholesky failed and the host stored the symmetric inverse instead (the reference
+        // falls back to an LBL^T solve, domain.rs:60-75): gamma = inv * rhs on the packed lower triangle
+        double *tp = v.tmp + o;
+        for (int i = tid; i < m; i += 256) {
+            double s = 0.0;
+            for (int j = 0; j < i; ++j) s += L[pk(i, j, m)] * y[j];
+            for (int j = i; j < m; ++j) s += L[pk(j, i, m)] * y[j];
+            tp[i] = s;
+        }
+        __threadfence_block();
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) y[i] = tp[i];
+        __threadfence_block();
+        __syncthreads();
+    } else {
     // forward substitution L z = rhs, 32 columns at a time: the diagonal block goes to LDS and is solved
     // by one wave (column sweep, lane r owns row r), the rows below are updated by all threads
     for (int jb = 0; jb < m; jb += NB) {
@@ -390,6 +408,7 @@ __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__
         __threadfence_block();
         __syncthreads();
     }
+    } // (Cholesky path)
     // lambda of the special points = Q gamma
     for (int a = 0; a < k; ++a) {
         double s = 0.0;

@@ -191,6 +191,70 @@ template <class T> static int up(T **dst, const std::vector<T> &v, hipStream_t s
     return BBFMM_OK;
 }
 
+// Fallback for a local system whose Cholesky factorisation fails: the reference switches that domain to a
+// Bunch-Kaufman LBL^T solve (DomainSolver::new, domain.rs:60-68; linalg.rs:514-616).  Here the host
+// assembles the same Q^T A Q (the formula of ddm_assemble_kernel), inverts it by Gauss-Jordan
+// elimination with partial pivoting and stores the symmetrised inverse packed like a factor; the solve
+// kernel multiplies by it.  Meant for the occasional small domain, not for speed.
+static int host_domain_inverse(const std::vector<double> *xyz, int64_t o, int k, int m, const double *q,
+                               const KernelSpec &ks, double nugget, std::vector<double> *packed) {
+    auto phi = [&](int64_t a, int64_t b) {
+        const double dx = xyz[0][a] - xyz[0][b], dy = xyz[1][a] - xyz[1][b], dz = xyz[2][a] - xyz[2][b];
+        return kernel_value_r2_rt(ks, dx * dx + dy * dy + dz * dz);
+    };
+    const size_t M = static_cast<size_t>(m);
+    std::vector<double> T(static_cast<size_t>(k) * M), G(static_cast<size_t>(k) * M), a11(static_cast<size_t>(k) * k);
+    for (int a = 0; a < k; ++a) {
+        for (int b = 0; b < k; ++b) a11[static_cast<size_t>(a) * k + b] = phi(o + a, o + b) + (a == b ? nugget : 0.0);
+        for (int j = 0; j < m; ++j) T[a * M + j] = phi(o + a, o + k + j);
+    }
+    for (int a = 0; a < k; ++a)
+        for (int j = 0; j < m; ++j) {
+            double g = T[a * M + j];
+            for (int b = 0; b < k; ++b) g += a11[static_cast<size_t>(a) * k + b] * q[b * M + j];
+            G[a * M + j] = g;
+        }
+    std::vector<double> A(M * M), inv(M * M, 0.0);
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = phi(o + k + i, o + k + j) + (i == j ? nugget : 0.0);
+            for (int a = 0; a < k; ++a) s += q[a * M + i] * G[a * M + j] + T[a * M + i] * q[a * M + j];
+            A[i * M + j] = s;
+            A[j * M + i] = s;
+        }
+    for (int i = 0; i < m; ++i) inv[i * M + i] = 1.0;
+    for (int c = 0; c < m; ++c) {
+        int p = c;
+        for (int r = c + 1; r < m; ++r)
+            if (std::fabs(A[r * M + c]) > std::fabs(A[p * M + c])) p = r;
+        if (!(std::fabs(A[p * M + c]) > 0.0)) return BBFMM_UNSUPPORTED; // singular local system
+        if (p != c)
+            for (int j = 0; j < m; ++j) {
+                std::swap(A[p * M + j], A[c * M + j]);
+                std::swap(inv[p * M + j], inv[c * M + j]);
+            }
+        const double piv = 1.0 / A[c * M + c];
+        for (int j = 0; j < m; ++j) {
+            A[c * M + j] *= piv;
+            inv[c * M + j] *= piv;
+        }
+        for (int r = 0; r < m; ++r) {
+            if (r == c) continue;
+            const double f = A[r * M + c];
+            if (f == 0.0) continue;
+            for (int j = 0; j < m; ++j) {
+                A[r * M + j] -= f * A[c * M + j];
+                inv[r * M + j] -= f * inv[c * M + j];
+            }
+        }
+    }
+    packed->resize(M * (M + 1) / 2);
+    size_t e = 0;
+    for (int c = 0; c < m; ++c) // packed lower triangle, column by column (ddm_kernels.hip pk)
+        for (int r = c; r < m; ++r) (*packed)[e++] = 0.5 * (inv[r * M + c] + inv[c * M + r]);
+    return BBFMM_OK;
+}
+
 int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const KernelSpec &ks, double nugget,
                     int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *lv,
                     const double *scaling) {
@@ -262,21 +326,47 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     }
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_fac), static_cast<size_t>(std::max<int64_t>(lv->fac_off[nd], 1)) * sizeof(double)));
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_work), static_cast<size_t>(std::max<int64_t>(lv->n_entries, 1)) * (ddm_level_is_big(*lv) ? 3 : 1) * sizeof(double)));
-    int *d_fail = nullptr;
-    DHIP(hipMalloc(reinterpret_cast<void **>(&d_fail), sizeof(int)));
-    DHIP(hipMemsetAsync(d_fail, 0, sizeof(int), s));
+    int *d_fail = nullptr; // one flag per domain
+    DHIP(hipMalloc(reinterpret_cast<void **>(&d_fail), static_cast<size_t>(std::max<int64_t>(nd, 1)) * sizeof(int)));
+    DHIP(hipMemsetAsync(d_fail, 0, static_cast<size_t>(std::max<int64_t>(nd, 1)) * sizeof(int), s));
     lap("alloc + upload", true);
     launch_ddm_prep(ks, nugget, d, *lv, s);
     launch_ddm_assemble(ks, nugget, d, *lv, s);
     lap("assemble", true);
     launch_ddm_cholesky(*lv, d_fail, s);
     lap("cholesky", true);
-    int fail = 0;
-    DHIP(hipMemcpyAsync(&fail, d_fail, sizeof(int), hipMemcpyDeviceToHost, s));
+    std::vector<int> fail(static_cast<size_t>(std::max<int64_t>(nd, 1)), 0);
+    DHIP(hipMemcpyAsync(fail.data(), d_fail, fail.size() * sizeof(int), hipMemcpyDeviceToHost, s));
     DHIP(hipStreamSynchronize(s));
     (void)hipFree(d_fail);
     DHIP(hipGetLastError());
-    return fail ? BBFMM_UNSUPPORTED : BBFMM_OK; // a local system that is not positive definite
+    std::vector<int64_t> failed;
+    for (int64_t i = 0; i < nd; ++i)
+        if (fail[static_cast<size_t>(i)]) failed.push_back(i);
+    if (failed.empty()) return BBFMM_OK;
+    // local systems that are not positive definite: host fallback per domain (not for the one large coarse
+    // matrix, which would take the host hours)
+    if (ddm_level_is_big(*lv)) return BBFMM_UNSUPPORTED;
+    lv->n_fallback = static_cast<int>(failed.size());
+    std::vector<uint8_t> mode(static_cast<size_t>(nd), 0);
+    std::vector<int> frc(failed.size(), BBFMM_OK);
+    std::vector<std::vector<double>> inv(failed.size());
+    parallel_for(static_cast<int64_t>(failed.size()), 1, [&](int64_t f) {
+        const int64_t i = failed[static_cast<size_t>(f)];
+        const int kk = lv->k[i], m = static_cast<int>(lv->dom_off[i + 1] - lv->dom_off[i]) - kk;
+        frc[f] = host_domain_inverse(xyz, lv->dom_off[i], kk, m, q.data() + lv->q_off[i], ks, nugget, &inv[f]);
+    });
+    for (size_t f = 0; f < failed.size(); ++f) {
+        if (frc[f] != BBFMM_OK) return frc[f];
+        const int64_t i = failed[f];
+        mode[static_cast<size_t>(i)] = 1;
+        DHIP(hipMemcpyAsync(lv->d_fac + lv->fac_off[i], inv[f].data(), inv[f].size() * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    if ((rc = up(&lv->d_mode, mode, s)) != BBFMM_OK) return rc;
+    DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_tmp), static_cast<size_t>(std::max<int64_t>(lv->n_entries, 1)) * sizeof(double)));
+    DHIP(hipStreamSynchronize(s));
+    lap("host fallback (LBLT role)", false);
+    return BBFMM_OK;
 }
 
 void ddm_level_free(DdmLevelSolver *lv) {
@@ -292,6 +382,8 @@ void ddm_level_free(DdmLevelSolver *lv) {
     (void)hipFree(lv->d_g);
     (void)hipFree(lv->d_fac);
     (void)hipFree(lv->d_work);
+    (void)hipFree(lv->d_mode);
+    (void)hipFree(lv->d_tmp);
     *lv = DdmLevelSolver();
 }
 

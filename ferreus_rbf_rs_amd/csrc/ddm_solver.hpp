@@ -45,6 +45,9 @@ struct DdmLevelSolver {
     int32_t *d_k = nullptr;
     uint8_t *d_internal = nullptr;
     double *d_q = nullptr, *d_t = nullptr, *d_g = nullptr, *d_fac = nullptr;
+    uint8_t *d_mode = nullptr; // per domain: 1 = fac holds the packed symmetric inverse (host fallback)
+    double *d_tmp = nullptr;   // n_entries scratch for those domains
+    int n_fallback = 0;
     double *d_work = nullptr; // n_entries: rhs / solution per entry (3x for one large domain: + z, gamma)
     int max_m = 0;
 };

@@ -169,7 +169,15 @@ class Domain:
                 self.special_monomials = sp_m.copy()
         else:
             lhs = a_matrix(dom, st)
-        self.chol = sla.cho_factor(0.5 * (lhs + lhs.T), lower=True)                      # LltRfp, linalg.rs
+        sym = 0.5 * (lhs + lhs.T)
+        try:
+            self.chol = sla.cho_factor(sym, lower=True)                                  # LltRfp, linalg.rs
+            self.indefinite = None
+        except np.linalg.LinAlgError:
+            # DomainSolver::new (domain.rs:60-68): a failed Cholesky switches the domain to the Bunch-Kaufman
+            # LBL^T solver (linalg.rs:514-616), restated by its meaning: a stable symmetric indefinite solve
+            self.chol = None
+            self.indefinite = sym
 
     def solve(self, values):
         """domain.rs:393-475; values: global (n_total x k).  Returns (point coefficients in the
@@ -181,7 +189,7 @@ class Domain:
             rhs = self.q_top.T @ d[:ns] + d[ns:]
         else:
             rhs = d
-        gamma = sla.cho_solve(self.chol, rhs)
+        gamma = sla.cho_solve(self.chol, rhs) if self.chol is not None else np.linalg.solve(self.indefinite, rhs)
         if self.q_top is not None:
             coef = np.vstack([self.q_top @ gamma, gamma])
         else:

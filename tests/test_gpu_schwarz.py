@@ -81,3 +81,52 @@ def test_fgmres_with_schwarz_preconditioner_solves_the_interpolation_problem(kid
     assert hist0[-1][1] > 10 * hist[min(len(hist), len(hist0)) - 1][1]           # the preconditioner is why
     fitted = op(x)[:n]
     assert np.abs(fitted - vals).max() < 1e-4 * np.abs(vals).max()
+
+
+def _oracle_level_solve(levels, lv, r, n, ost, ortho):
+    """one level's correction as schwarz.rs computes it (solve_fine_level / solve_coarse_level)"""
+    if lv < len(levels) - 1:
+        s1 = np.zeros_like(r)
+        for dom in levels[lv].leaf_domains:
+            coef, _ = dom.solve(r[:, None])
+            for local, (g, m) in enumerate(zip(dom.overlapping_point_indices, dom.internal_points_mask)):
+                if m:
+                    s1[g] = coef[local, 0]
+        if ost.basis_size:
+            s1[:n] -= ortho @ (ortho.T @ s1[:n])
+        return s1
+    dom = levels[lv].leaf_domains[0]
+    coef, poly = dom.solve(r[:, None])
+    s1 = np.zeros_like(r)
+    s1[np.asarray(dom.overlapping_point_indices)] = coef[:, 0]
+    if poly is not None:
+        s1[n:] = poly[:, 0]
+    return s1
+
+
+@pytest.mark.parametrize("kid,drift", [(3, None), (3, 1)])
+def test_local_systems_that_are_not_positive_definite_take_the_fallback(kid, drift):
+    """DomainSolver::new (domain.rs:60-68): when the Cholesky factorisation of a domain fails the reference
+    solves that domain with a Bunch-Kaufman LBL^T factorisation; here the host inverts such a system and
+    the device multiplies by the inverse.  A negative nugget makes the local systems indefinite."""
+    rng = np.random.default_rng(77)
+    n, dim, nugget, br = 2000, 3, -0.02, 0.3
+    pts = rng.random((n, dim))
+    prm = (80, 0.5, 0.125, 250)
+    st = InterpolantSettings(kid, dim, drift=drift, nugget=nugget, base_range=br, total_sill=br)
+    ost = D.InterpolantSettings(kid, dim, drift=drift, nugget=nugget, base_range=br, total_sill=br)
+    tree = F.FmmTree(pts, 6, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=br), True, True)
+    pre = SchwarzPreconditioner(tree, pts, st, DDMParams(*prm))
+    levels = D.build_ddm_tree(pts, ost, D.DDMParams(*prm))
+    n_indef = sum(dom.indefinite is not None for lvl in levels for dom in lvl.leaf_domains)
+    assert n_indef > 0                                   # the case really exercises the fallback
+    ortho = None
+    if ost.basis_size:
+        tr, sc = D.cheb_cube_scaling_factors(pts)
+        _, ortho = D.orthonormal_poly(pts, ost, tr, sc)
+    r = rng.standard_normal(n + ost.basis_size)
+    r[n:] = 0.0
+    for lv in range(len(levels)):
+        z = pre.debug_level_solve(lv, r, True)
+        zo = _oracle_level_solve(levels, lv, r, n, ost, ortho)
+        assert np.abs(z - zo).max() < 1e-7 * np.abs(zo).max(), f"level {lv}"

@@ -124,3 +124,20 @@ def test_schwarz_preconditioned_fgmres_converges_to_the_dense_solution(kid, dim,
     assert np.abs(fitted - vals).max() < 1e3 * tol * max(1.0, np.abs(vals).max())
     if m:
         assert np.abs(P.T @ x[:n]).max() < 1e-6 * np.abs(x[:n]).max()
+
+
+def test_indefinite_local_system_takes_the_symmetric_indefinite_solver():
+    """DomainSolver::new (domain.rs:60-68): a failed Cholesky falls back to the LBL^T solver; the domain
+    solve still equals the naive solve of the same (now indefinite) system."""
+    rng = np.random.default_rng(17)
+    pts = rng.random((120, 3))
+    st = D.InterpolantSettings(3, 3, nugget=-0.05, base_range=0.3, total_sill=0.3)
+    dom = D.Domain(range(120))
+    dom.internal_points_mask = [True] * 120
+    dom.factorise(pts, st, False)
+    assert dom.indefinite is not None and dom.chol is None
+    vals = rng.standard_normal((120, 1))
+    coef, poly = dom.solve(vals)
+    lam = np.zeros((120, 1))
+    lam[np.asarray(dom.overlapping_point_indices)] = coef
+    np.testing.assert_allclose(lam, np.linalg.solve(D.a_matrix(pts, st), vals), rtol=1e-8, atol=1e-10)
