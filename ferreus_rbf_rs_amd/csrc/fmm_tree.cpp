@@ -1395,7 +1395,7 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
     // well under the whole operator, stage 1 runs one tile per (column block, the sources it needs).
     int64_t n_active = 0;
     for (uint8_t a : active) n_active += a;
-    if (n_active * 4 < C) { // (denser sets need nearly every block of every source: skip the analysis)
+    if (n_active * 2 < C) { // (denser sets need nearly every block of every source: skip the analysis)
         std::vector<int32_t> cls_of(static_cast<size_t>(C), -1), pos_of(static_cast<size_t>(C), -1);
         std::vector<int64_t> bm_off(m2l_host_.size() + 1, 0); // per class: n_blk x n_cells flags
         for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
@@ -1440,7 +1440,7 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         for (uint8_t f : bm) part += f;
         static const double max_ratio = [] {
             const char *e = std::getenv("BBFMM_M2L_SPARSE_RATIO");
-            return e ? std::atof(e) : 0.6;
+            return e ? std::atof(e) : 0.9;
         }();
         dp->tiles1_own_blocks = whole > 0 && static_cast<double>(part) < max_ratio * static_cast<double>(whole);
         if (dp->tiles1_own_blocks) {
