@@ -130,3 +130,29 @@ def test_local_systems_that_are_not_positive_definite_take_the_fallback(kid, dri
         z = pre.debug_level_solve(lv, r, True)
         zo = _oracle_level_solve(levels, lv, r, n, ost, ortho)
         assert np.abs(z - zo).max() < 1e-7 * np.abs(zo).max(), f"level {lv}"
+
+
+@pytest.mark.parametrize("kid", [1, 0])
+def test_reference_sized_domains_and_a_large_coarse_domain(kid):
+    """The reference's default leaf size (1024 -> here domains of 750 points: the blocked MFMA Cholesky runs a
+    dozen block columns) and a coarse domain of more than 2,048 points (factorised and solved as multi-workgroup
+    launch sequences): every level's correction against the restatement, no FMM in between."""
+    rng = np.random.default_rng(5 + kid)
+    n, dim = 24000, 3
+    pts = rng.random((n, dim))
+    prm = (1024, 0.5, 0.125, 3200)
+    st = InterpolantSettings(kid, dim)
+    ost = D.InterpolantSettings(kid, dim)
+    tree = F.FmmTree(pts, 5, F.KernelParams(F.KernelType(kid)), True, True)
+    pre = SchwarzPreconditioner(tree, pts, st, DDMParams(*prm))
+    levels = D.build_ddm_tree(pts, ost, D.DDMParams(*prm))
+    assert pre.num_levels == len(levels) == 2
+    assert len(levels[1].point_indices) > 2048 and len(levels[0].leaf_domains[0].overlapping_point_indices) > 700
+    tr, sc = D.cheb_cube_scaling_factors(pts)
+    _, ortho = D.orthonormal_poly(pts, ost, tr, sc)
+    r = rng.standard_normal(n + ost.basis_size)
+    r[n:] = 0.0
+    for lv in range(2):
+        z = pre.debug_level_solve(lv, r, True)
+        zo = _oracle_level_solve(levels, lv, r, n, ost, ortho)
+        assert np.abs(z - zo).max() < 1e-8 * np.abs(zo).max(), f"level {lv}"
