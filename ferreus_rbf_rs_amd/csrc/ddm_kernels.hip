@@ -119,10 +119,14 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
     const int64_t o = v.dom_off[dom];
     const int m = static_cast<int>(v.dom_off[dom + 1] - o) - v.k[dom];
     double *A = v.fac + v.fac_off[dom];
-    __shared__ double Ld[CB][CB + 1];
-    __shared__ double Pr[64][NB + 1], Pc[64][NB + 1];
+    // LDS: the diagonal block (steps 2, 3) and the column-panel chunk of step 1 share one buffer -- 50 KB per
+    // workgroup, three workgroups per CU
+    __shared__ double Ldbuf[CB * (CB + 1)];
+    __shared__ double Pr[64][NB + 1];
     __shared__ double colj[CB];
     __shared__ int bad;
+    double(*Ld)[CB + 1] = reinterpret_cast<double(*)[CB + 1]>(Ldbuf);
+    double(*Pc)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(Ldbuf);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1); // the wave's quadrant of a 64 x 64 tile
     const int li = lane & 15, lk = lane >> 4;
