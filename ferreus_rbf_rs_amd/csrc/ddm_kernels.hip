@@ -230,89 +230,115 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
     if (tid == 0 && bad) fail[dom] = 1; // per-domain flag: the host refactorises that domain (ddm_solver.cpp)
 }
 
-// The same factorisation for one large matrix (the coarse domain, m up to tens of thousands) spread
-// over the chip: per 32-column panel one small launch for the diagonal block, one for the panel
-// rows and one for the trailing update in 64 x 64 tiles.
-__global__ __launch_bounds__(256) void chol_big_diag_kernel(double *A, int m, int jb, int *fail) {
-    __shared__ double Ld[NB][NB + 1];
-    const int tid = threadIdx.x, nb = min(NB, m - jb);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? A[pk(jb + r, jb + c, m)] : 0.0;
+// The same factorisation for ONE large matrix (the coarse domain, m up to tens of thousands) spread over
+// the chip, right-looking over 128-column panels so that the trailing matrix is read and written once per
+// 128 columns (m/128 passes over m^2/2 doubles).  A panel is two 64-column halves; per half one workgroup
+// factorises the 64 x 64 diagonal block and stores its inverse, a launch over the rows below multiplies
+// them by that inverse; the second half is first updated with the first (K = 64); the trailing update
+// uses both (K = 128).  All products run on the MFMA tiles of the per-domain kernel.
+__global__ __launch_bounds__(256) void big_diag_kernel(double *A, int m, int jb, double *Linv, int *fail) {
+    __shared__ double Ld[CB][CB + 1];
+    __shared__ double colj[CB];
+    const int tid = threadIdx.x, nb = min(CB, m - jb);
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e & (CB - 1), c = e >> 6;
+        Ld[r][c] = (r < nb && c < nb) ? (r >= c ? A[pk(jb + r, jb + c, m)] : 0.0) : (r == c ? 1.0 : 0.0);
     }
     __syncthreads();
     for (int c = 0; c < nb; ++c) {
         if (tid == 0) {
             const double dd = Ld[c][c];
-            if (!(dd > 0.0)) atomicExch(fail, 1);
+            if (!(dd > 0.0)) fail[0] = 1;
             Ld[c][c] = sqrt(dd > 0.0 ? dd : 1.0);
         }
         __syncthreads();
-        if (tid > c && tid < nb) Ld[tid][c] /= Ld[c][c];
+        if (tid > c && tid < CB) Ld[tid][c] /= Ld[c][c];
         __syncthreads();
-        for (int e = tid; e < nb * nb; e += 256) {
-            const int r = e % nb, c2 = e / nb;
-            if (c2 > c && r >= c2) Ld[r][c2] -= Ld[r][c] * Ld[c2][c];
+        {
+            const int r = tid & (CB - 1);
+            const double lrc = Ld[r][c];
+            for (int c2 = c + 1 + (tid >> 6); c2 <= r; c2 += 4) Ld[r][c2] -= lrc * Ld[c2][c];
         }
         __syncthreads();
     }
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e % nb, c = e / nb;
-        if (r >= c) A[pk(jb + r, jb + c, m)] = Ld[r][c];
-    }
-}
-
-__global__ __launch_bounds__(256) void chol_big_panel_kernel(double *A, int m, int jb) {
-    __shared__ double Ld[NB][NB + 1];
-    const int tid = threadIdx.x, nb = min(NB, m - jb);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? A[pk(jb + r, jb + c, m)] : 0.0;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e & (CB - 1), c = e >> 6;
+        if (r >= c && r < nb) A[pk(jb + r, jb + c, m)] = Ld[r][c];
     }
     __syncthreads();
-    const int r = jb + nb + blockIdx.x * 256 + tid;
-    if (r >= m) return;
-    double xr[NB];
-    for (int c = 0; c < nb; ++c) {
-        double s = A[pk(r, jb + c, m)];
-        for (int c2 = 0; c2 < c; ++c2) s -= xr[c2] * Ld[c][c2];
-        xr[c] = s / Ld[c][c];
+    for (int j = CB - 1; j >= 0; --j) { // in-place inverse, column by column from the right
+        if (tid < CB) colj[tid] = Ld[tid][j];
+        __syncthreads();
+        const double dj = 1.0 / colj[j];
+        if (tid == j) Ld[j][j] = dj;
+        if (tid > j && tid < CB) {
+            double sacc = 0.0;
+            for (int k = j + 1; k <= tid; ++k) sacc += Ld[tid][k] * colj[k];
+            Ld[tid][j] = -dj * sacc;
+        }
+        __syncthreads();
     }
-    for (int c = 0; c < nb; ++c) A[pk(r, jb + c, m)] = xr[c];
+    for (int e = tid; e < CB * CB; e += 256) Linv[e] = Ld[e >> 6][e & (CB - 1)]; // row-major [column of X][k]
 }
 
-__global__ __launch_bounds__(256) void chol_big_trail_kernel(double *A, int m, int jb) {
-    const int nb = min(NB, m - jb), t0 = jb + nb;
-    const int tr = t0 + 64 * blockIdx.x, tc = t0 + 64 * blockIdx.y;
-    if (tc > tr || tr >= m) return;
+// rows r0 + 64 * blockIdx.x ..: X = A[rows, jb..jb+64) inv(L11)^T
+__global__ __launch_bounds__(256) void big_panel_kernel(double *A, int m, int jb, int r0, const double *__restrict__ Linv) {
+    __shared__ double Ld[CB][CB + 1];
+    __shared__ double Pr[64][NB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1), li = lane & 15, lk = lane >> 4;
+    const int tr = r0 + 64 * blockIdx.x, nb = min(CB, m - jb);
+    for (int e = tid; e < CB * CB; e += 256) Ld[e >> 6][e & (CB - 1)] = Linv[e];
+    d4 acc[2][2] = {};
+    for (int kh = 0; kh < CB; kh += NB) {
+        __syncthreads();
+        for (int e = tid; e < 64 * NB; e += 256) {
+            const int r = e & 63, c = e >> 6;
+            Pr[r][c] = (tr + r < m && kh + c < nb) ? A[pk(tr + r, jb + kh + c, m)] : 0.0;
+        }
+        __syncthreads();
+        quad_mfma32(Ld, kh, Pr, cb, rb, lane, acc);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ci = 0; ci < 2; ++ci)
+#pragma unroll
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = tr + rb + 16 * ri + li, c = cb + 16 * ci + lk + 4 * q;
+                if (r < m && c < nb) A[pk(r, jb + c, m)] = acc[ci][ri][q];
+            }
+}
+
+// A[tile] -= L[rows, k0..k0+K) L[cols, k0..k0+K)^T for the 64 x 64 tiles (tr, tc), tr = r0 + 64 bx,
+// tc = c0 + 64 by, tc <= tr, columns below c1 (K a multiple of 32)
+__global__ __launch_bounds__(256) void big_syrk_kernel(double *A, int m, int k0, int K, int r0, int c0, int c1) {
+    const int tr = r0 + 64 * blockIdx.x, tc = c0 + 64 * blockIdx.y;
+    if (tc > tr || tr >= m || tc >= c1) return;
     __shared__ double Pr[64][NB + 1], Pc[64][NB + 1];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-    for (int e = tid; e < 64 * nb; e += 256) {
-        const int r = e % 64, c = e / 64;
-        Pr[r][c] = (tr + r < m) ? A[pk(tr + r, jb + c, m)] : 0.0;
-        Pc[r][c] = (tc + r < m) ? A[pk(tc + r, jb + c, m)] : 0.0;
-    }
-    __syncthreads();
-    double acc[4][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int c = 0; c < nb; ++c) {
-        double pr[4], pc[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            pr[u] = Pr[4 * ty + u][c];
-            pc[u] = Pc[4 * tx + u][c];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1), li = lane & 15, lk = lane >> 4;
+    d4 acc[2][2] = {};
+    for (int kc = 0; kc < K; kc += NB) {
+        __syncthreads();
+        for (int e = tid; e < 64 * NB; e += 256) {
+            const int r = e & 63, c = e >> 6;
+            Pr[r][c] = (tr + r < m) ? A[pk(tr + r, k0 + kc + c, m)] : 0.0;
+            Pc[r][c] = (tc + r < c1) ? A[pk(tc + r, k0 + kc + c, m)] : 0.0;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) acc[u][w] += pr[u] * pc[w];
+        __syncthreads();
+        quad_mfma32(Pc, 0, Pr, cb, rb, lane, acc);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int ci = 0; ci < 2; ++ci)
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const int r = tr + 4 * ty + u, c = tc + 4 * tx + w;
-            if (r < m && c < m && r >= c) A[pk(r, c, m)] -= acc[u][w];
-        }
+        for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = tr + rb + 16 * ri + li, c = tc + cb + 16 * ci + lk + 4 * q;
+                if (r < m && c < c1 && r >= c) A[pk(r, c, m)] -= acc[ci][ri][q];
+            }
 }
 
 // Domain::solve (domain.rs:393-475) for one right-hand side: gather, rhs = Q^T d_s + d_ns,
@@ -581,16 +607,22 @@ void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLe
 
 void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
     if (lv.n_dom == 0) return;
-    if (ddm_level_is_big(lv)) { // one large matrix: the whole chip per panel step
+    if (ddm_level_is_big(lv)) { // one large matrix: the whole chip per step (d_work is free here: the inverse goes there)
         const int m = lv.max_m;
-        double *A = lv.d_fac;
-        for (int jb = 0; jb < m; jb += NB) {
-            const int nb = std::min(NB, m - jb), rest = m - jb - nb;
-            hipLaunchKernelGGL(chol_big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, jb, d_fail);
-            if (rest <= 0) break;
-            hipLaunchKernelGGL(chol_big_panel_kernel, dim3((rest + 255) / 256), dim3(256), 0, s, A, m, jb);
-            const unsigned t = static_cast<unsigned>((rest + 63) / 64);
-            hipLaunchKernelGGL(chol_big_trail_kernel, dim3(t, t), dim3(256), 0, s, A, m, jb);
+        double *A = lv.d_fac, *Linv = lv.d_work;
+        auto tiles = [](int rows) { return static_cast<unsigned>((rows + 63) / 64); };
+        for (int jb = 0; jb < m; jb += 2 * CB) {
+            const int h1 = jb + CB, end = std::min(m, jb + 2 * CB); // second half [h1, end), trailing part from end
+            hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, jb, Linv, d_fail);
+            if (h1 >= m) break;
+            hipLaunchKernelGGL(big_panel_kernel, dim3(tiles(m - h1)), dim3(256), 0, s, A, m, jb, h1, Linv);
+            // second half of the panel brought up to date with the first (K = 64)
+            hipLaunchKernelGGL(big_syrk_kernel, dim3(tiles(m - h1), 1), dim3(256), 0, s, A, m, jb, CB, h1, h1, end);
+            hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, h1, Linv, d_fail);
+            if (end >= m) break;
+            hipLaunchKernelGGL(big_panel_kernel, dim3(tiles(m - end)), dim3(256), 0, s, A, m, h1, end, Linv);
+            const unsigned t = tiles(m - end);
+            hipLaunchKernelGGL(big_syrk_kernel, dim3(t, t), dim3(256), 0, s, A, m, jb, 2 * CB, end, end, m);
         }
         return;
     }
