@@ -66,7 +66,43 @@ template <class T> int FmmTree::dupload(DevBuf<T> *b, const std::vector<T> &v) {
     if (!v.empty()) HIPCHK(hipMemcpy(b->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return BBFMM_OK;
 }
+template <class T> int FmmTree::talloc(DevBuf<T> *b, size_t n, bool zero) {
+    if (!arena_active_) return dalloc(b, n, zero);
+    const size_t bytes = (std::max<size_t>(n, 1) * sizeof(T) + 255) & ~size_t(255);
+    arena_need_ += bytes;
+    if (arena_used_ + bytes > arena_.n) return dalloc(b, n, zero); // this call overflows: the arena grows afterwards
+    b->p = reinterpret_cast<T *>(arena_.p + arena_used_);
+    b->n = n;
+    b->borrowed = true;
+    arena_used_ += bytes;
+    if (zero) HIPCHK(hipMemsetAsync(b->p, 0, std::max<size_t>(n, 1) * sizeof(T), stream_));
+    return BBFMM_OK;
+}
+template <class T> int FmmTree::tupload(DevBuf<T> *b, const std::vector<T> &v) {
+    CHK(talloc(b, v.size()));
+    if (!v.empty()) HIPCHK(hipMemcpy(b->p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BBFMM_OK;
+}
+void FmmTree::arena_begin() {
+    arena_active_ = true;
+    arena_used_ = 0;
+    arena_need_ = 0;
+}
+int FmmTree::arena_end() { // every borrowed buffer has been released by now
+    arena_active_ = false;
+    if (arena_need_ > arena_.n) {
+        dfree(&arena_);
+        CHK(dalloc(&arena_, arena_need_ + arena_need_ / 4));
+    }
+    return BBFMM_OK;
+}
 template <class T> void FmmTree::dfree(DevBuf<T> *b) {
+    if (b->borrowed) {
+        b->p = nullptr;
+        b->n = 0;
+        b->borrowed = false;
+        return;
+    }
     if (b->p) {
         auto it = std::find(owned_.begin(), owned_.end(), static_cast<void *>(b->p));
         if (it != owned_.end()) owned_.erase(it);
@@ -787,16 +823,16 @@ int FmmTree::build_target_set_device(const double *x, int64_t m, int64_t ldx, Ta
     HIPCHK(hipMemsetAsync(d_bad, 0xFF, sizeof(unsigned long long), stream_));
     ts->m = m;
     const size_t cap = static_cast<size_t>(std::min<int64_t>(m, C));
-    CHK(dalloc(&ts->perm, sm));
-    CHK(dalloc(&ts->job_cell, cap));
-    CHK(dalloc(&ts->tgt_begin, cap));
-    CHK(dalloc(&ts->tgt_end, cap));
+    CHK(talloc(&ts->perm, sm));
+    CHK(talloc(&ts->job_cell, cap));
+    CHK(talloc(&ts->tgt_begin, cap));
+    CHK(talloc(&ts->tgt_end, cap));
     for (int a = 0; a < 3; ++a) {
         if (a < d_) {
-            CHK(dalloc(&ts->xyz[a], sm));
+            CHK(talloc(&ts->xyz[a], sm));
             ts->xyz_ptr[a] = ts->xyz[a].p;
         } else if (sm > d_zero_axis_.n) {
-            CHK(dalloc(&ts->xyz[a], sm, true));
+            CHK(talloc(&ts->xyz[a], sm, true));
             ts->xyz_ptr[a] = ts->xyz[a].p;
         } else {
             ts->xyz_ptr[a] = d_zero_axis_.p;
@@ -838,10 +874,10 @@ int FmmTree::build_target_set_device(const double *x, int64_t m, int64_t ldx, Ta
         if (leaves_out) leaves_out->swap(jc);
     }
     ts->n_w_jobs = static_cast<int>(wtb.size());
-    CHK(dupload(&ts->w_tgt_begin, wtb));
-    CHK(dupload(&ts->w_tgt_end, wte));
-    CHK(dupload(&ts->w_begin, wb));
-    CHK(dupload(&ts->w_end, we));
+    CHK(tupload(&ts->w_tgt_begin, wtb));
+    CHK(tupload(&ts->w_tgt_end, wte));
+    CHK(tupload(&ts->w_begin, wb));
+    CHK(tupload(&ts->w_end, we));
     return BBFMM_OK;
 }
 
@@ -896,27 +932,27 @@ int FmmTree::build_target_set_host(const double *x, int64_t m, int64_t ldx, Targ
     for (int a = 0; a < 3; ++a) {
         if (a < d_) {
             for (int64_t i = 0; i < m; ++i) tmp[i] = x[a * ldx + perm[i]];
-            CHK(dupload(&ts->xyz[a], tmp));
+            CHK(tupload(&ts->xyz[a], tmp));
             ts->xyz_ptr[a] = ts->xyz[a].p;
         } else {
             if (static_cast<size_t>(m) > d_zero_axis_.n) {
-                CHK(dalloc(&ts->xyz[a], static_cast<size_t>(m), true));
+                CHK(talloc(&ts->xyz[a], static_cast<size_t>(m), true));
                 ts->xyz_ptr[a] = ts->xyz[a].p;
             } else {
                 ts->xyz_ptr[a] = d_zero_axis_.p;
             }
         }
     }
-    CHK(dupload(&ts->perm, perm));
+    CHK(tupload(&ts->perm, perm));
     ts->n_jobs = static_cast<int>(jc.size());
     ts->n_w_jobs = static_cast<int>(wtb.size());
-    CHK(dupload(&ts->job_cell, jc));
-    CHK(dupload(&ts->tgt_begin, tb));
-    CHK(dupload(&ts->tgt_end, te));
-    CHK(dupload(&ts->w_tgt_begin, wtb));
-    CHK(dupload(&ts->w_tgt_end, wte));
-    CHK(dupload(&ts->w_begin, wb));
-    CHK(dupload(&ts->w_end, we));
+    CHK(tupload(&ts->job_cell, jc));
+    CHK(tupload(&ts->tgt_begin, tb));
+    CHK(tupload(&ts->tgt_end, te));
+    CHK(tupload(&ts->w_tgt_begin, wtb));
+    CHK(tupload(&ts->w_tgt_end, wte));
+    CHK(tupload(&ts->w_begin, wb));
+    CHK(tupload(&ts->w_end, we));
     if (leaves_out) leaves_out->swap(leaves);
     return BBFMM_OK;
 }
@@ -1106,6 +1142,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     if (m >= (int64_t(1) << 31)) return fail(BBFMM_BAD_ARGUMENT, "more than 2^31-1 target points");
     TargetSet ts;
     std::vector<int32_t> target_leaves;
+    arena_begin();
     static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     int rc = build_target_set(x, m, ldx, &ts, bad_point_index, leaves_only ? nullptr : &target_leaves); // points_to_keys, bbfmm.rs:455-465
@@ -1129,10 +1166,10 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
                   "FMM evaluation failed: gradient evaluation requested but kernel does not support gradients");
     DevBuf<double> o_dev, g_dev;
     if (rc == BBFMM_OK && m > 0) {
-        rc = dalloc(&ts.out, static_cast<size_t>(k) * m);
-        if (rc == BBFMM_OK && with_grads) rc = dalloc(&ts.grad, static_cast<size_t>(k) * d_ * m);
+        rc = talloc(&ts.out, static_cast<size_t>(k) * m);
+        if (rc == BBFMM_OK && with_grads) rc = talloc(&ts.grad, static_cast<size_t>(k) * d_ * m);
         if (rc == BBFMM_OK) rc = leaf_pass(ts, k, with_grads);
-        if (rc == BBFMM_OK) rc = dalloc(&o_dev, static_cast<size_t>(k) * m);
+        if (rc == BBFMM_OK) rc = talloc(&o_dev, static_cast<size_t>(k) * m);
         if (rc == BBFMM_OK) {
             phase_begin();
             launch_scatter_output(ts.out.p, m, k, ts.perm.p, o_dev.p, m, 0, stream_);
@@ -1142,7 +1179,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
             if (e != hipSuccess) rc = hip_fail(e, "copy values to host");
         }
         if (rc == BBFMM_OK && with_grads) {
-            rc = dalloc(&g_dev, static_cast<size_t>(k) * d_ * m);
+            rc = talloc(&g_dev, static_cast<size_t>(k) * d_ * m);
             if (rc == BBFMM_OK) {
                 launch_scatter_output(ts.grad.p, m, k * d_, ts.perm.p, g_dev.p, m, 0, stream_);
                 hipError_t e = hipMemcpy2DAsync(grad, ldg * sizeof(double), g_dev.p, m * sizeof(double),
@@ -1160,6 +1197,10 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     dfree(&g_dev);
     free_target_set(&ts);
     free_downward_plan(&dplan);
+    {
+        const int arc = arena_end();
+        if (rc == BBFMM_OK) rc = arc;
+    }
     if (verbose) {
         const auto t_end = std::chrono::steady_clock::now();
         std::fprintf(stderr, "[bbfmm] evaluate: %lld targets, target set %.3f ms, rest (weights, passes, copies) %.3f ms\n",
@@ -1481,14 +1522,14 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
     }
     dp->n_x_jobs = static_cast<int>(xc.size());
     if (host_only_) return BBFMM_OK;
-    CHK(dupload(&dp->d_active, dp->active));
-    CHK(dupload(&dp->d_tiles2, dp->tiles2_h));
-    CHK(dupload(&dp->d_tiles1, dp->tiles1_h));
-    CHK(dupload(&dp->d_tile_idx, dp->tile_idx_h));
-    CHK(dupload(&dp->d_qlist, dp->qlist_h));
-    CHK(dupload(&dp->d_x_cells, xc));
-    CHK(dupload(&dp->d_x_ptr, xptr));
-    CHK(dupload(&dp->d_x_runs, xruns));
+    CHK(tupload(&dp->d_active, dp->active));
+    CHK(tupload(&dp->d_tiles2, dp->tiles2_h));
+    CHK(tupload(&dp->d_tiles1, dp->tiles1_h));
+    CHK(tupload(&dp->d_tile_idx, dp->tile_idx_h));
+    CHK(tupload(&dp->d_qlist, dp->qlist_h));
+    CHK(tupload(&dp->d_x_cells, xc));
+    CHK(tupload(&dp->d_x_ptr, xptr));
+    CHK(tupload(&dp->d_x_runs, xruns));
     return BBFMM_OK;
 }
 

@@ -28,6 +28,7 @@ static_assert(kNumPhases == BBFMM_N_PHASES, "phase table");
 template <class T> struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    bool borrowed = false; // carved from the per-call arena of evaluate(): nothing to free
 };
 
 // Host copy of one (level, octant class) M2L table set; see device.hpp M2lClass.
@@ -210,6 +211,12 @@ class FmmTree {
     std::vector<void *> owned_; // every hipMalloc'd pointer, freed in the destructor
     template <class T> int dalloc(DevBuf<T> *b, size_t n, bool zero = false);
     template <class T> int dupload(DevBuf<T> *b, const std::vector<T> &v);
+    // per-call buffers of evaluate(): from a grow-only arena while one is active (no hipMalloc / hipFree per
+    // call, no scrubbing of re-used memory by the driver), else as dalloc / dupload
+    template <class T> int talloc(DevBuf<T> *b, size_t n, bool zero = false);
+    template <class T> int tupload(DevBuf<T> *b, const std::vector<T> &v);
+    void arena_begin();
+    int arena_end();
     template <class T> void dfree(DevBuf<T> *b);
 
     ChebRef cheb_{};
@@ -217,6 +224,9 @@ class FmmTree {
     DevBuf<double> d_src_[3];
     const double *src_ptr_[3] = {nullptr, nullptr, nullptr};
     DevBuf<double> d_zero_axis_;
+    DevBuf<uint8_t> arena_;
+    size_t arena_used_ = 0, arena_need_ = 0;
+    bool arena_active_ = false;
     // device target grouping: the tree's key table, leaf flags, grow-only scratch
     DevBuf<uint64_t> d_tab_keys_;
     DevBuf<int32_t> d_tab_vals_;
