@@ -85,6 +85,7 @@ SIGNATURES = {
                                                 c_p, c_p, c_p, c_p, c_p]),
     "bbfmm_rbf_system_apply": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
     "bbfmm_ddm_params_defaults": (None, [c_p]),
+    "bbfmm_ddm_params_for_points": (None, [c_i64, c_p]),
     "bbfmm_ddm_build": (ctypes.c_int, [c_p, c_i64, c_i32, c_i64, c_p, c_p]),
     "bbfmm_ddm_destroy": (None, [c_p]),
     "bbfmm_ddm_num_levels": (c_i32, [c_p]),

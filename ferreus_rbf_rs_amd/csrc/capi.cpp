@@ -336,6 +336,12 @@ void bbfmm_ddm_params_defaults(bbfmm_ddm_params *out) {
     out->coarse_ratio = p.coarse_ratio;
     out->coarse_threshold = p.coarse_threshold;
 }
+
+void bbfmm_ddm_params_for_points(int64_t n, bbfmm_ddm_params *out) {
+    if (!out) return;
+    bbfmm_ddm_params_defaults(out);
+    out->coarse_threshold = std::max<int64_t>(out->coarse_threshold, n / 512 + 1);
+}
 int bbfmm_ddm_build(const double *points, int64_t n, int32_t d, int64_t ld, const bbfmm_ddm_params *params,
                     bbfmm_ddm **out) {
     if (!out) return BBFMM_BAD_ARGUMENT;

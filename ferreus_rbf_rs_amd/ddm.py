@@ -1,8 +1,8 @@
 """Domain decomposition hierarchy of ferreus_rbf's Schwarz preconditioner (host part):
 `DDMTree` mirrors ferreus_rbf::preconditioning::domain_decomposition::DDMTree -- levels from finest to
 coarsest, each with its leaf domains (overlapping point indices, internal mask, extents).  Built by
-libferreus_bbfmm_hip.so (`bbfmm_ddm_build`); the local factorisations and the apply are not part of
-this package yet."""
+libferreus_bbfmm_hip.so (`bbfmm_ddm_build`).  `SchwarzPreconditioner` = decomposition + local factorisations
+on the device + the level sweep of schwarz.rs as an FGMRES callback (`bbfmm_schwarz_*`)."""
 from __future__ import annotations
 
 import ctypes
@@ -25,6 +25,14 @@ class DDMParams:
 
     def _c(self) -> L.DdmParams:
         return L.DdmParams(self.leaf_threshold, self.overlap_quota, self.coarse_ratio, self.coarse_threshold)
+
+    @staticmethod
+    def for_points(n: int) -> "DDMParams":
+        """Extension (bbfmm_ddm_params_for_points): the defaults with coarse_threshold raised so that at most
+        three fine levels are built over n points."""
+        c = L.DdmParams()
+        L.load().bbfmm_ddm_params_for_points(int(n), ctypes.byref(c))
+        return DDMParams(c.leaf_threshold, c.overlap_quota, c.coarse_ratio, c.coarse_threshold)
 
 
 class Domain:

@@ -313,6 +313,11 @@ typedef struct bbfmm_ddm_params { /* DDMParams, config.rs:42-69 */
     int64_t coarse_threshold; /* 4096 */
 } bbfmm_ddm_params;
 void bbfmm_ddm_params_defaults(bbfmm_ddm_params *out);
+/* Extension (not in the reference): the defaults with coarse_threshold raised so that the hierarchy over
+ * n points keeps at most three fine levels, coarse_threshold = max(4096, n/512 + 1).  With the plain
+ * defaults a fourth fine level appears above about 2.1M points and leaves one coarse point per ~7 level-0
+ * domains, where the sweep of schwarz.rs stalls for the thin-plate spline. */
+void bbfmm_ddm_params_for_points(int64_t n, bbfmm_ddm_params *out);
 /* points: n x d column-major (ld); params NULL -> defaults */
 int bbfmm_ddm_build(const double *points, int64_t n, int32_t d, int64_t ld, const bbfmm_ddm_params *params,
                     bbfmm_ddm **out);

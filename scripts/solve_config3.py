@@ -15,7 +15,8 @@ ap.add_argument("--kernel", default="ThinPlateSplineRbf")
 ap.add_argument("--order", type=int, default=9)
 ap.add_argument("--tol", type=float, default=1e-6)
 ap.add_argument("--nugget", type=float, default=0.0)
-ap.add_argument("--coarse-threshold", type=int, default=4096)
+ap.add_argument("--coarse-threshold", type=int, default=4096,
+                help="0: DDMParams.for_points(n) (the extension that keeps three fine levels)")
 ap.add_argument("--leaf-threshold", type=int, default=1024)
 ap.add_argument("--precon-order", type=int, default=0,
                 help="interpolation order of a second tree that serves only the preconditioner's partial matvecs "
@@ -35,7 +36,8 @@ ptree = tree
 if a.precon_order and a.precon_order != a.order:
     # FGMRES is flexible: the preconditioner may use cheaper (less accurate) products than the operator
     ptree = F.FmmTree(pts, a.precon_order, F.KernelParams(F.KernelType(kid)), True, True)
-pre = SchwarzPreconditioner(ptree, pts, st, DDMParams(leaf_threshold=a.leaf_threshold, coarse_threshold=a.coarse_threshold))
+ct = a.coarse_threshold or DDMParams.for_points(n).coarse_threshold
+pre = SchwarzPreconditioner(ptree, pts, st, DDMParams(leaf_threshold=a.leaf_threshold, coarse_threshold=ct))
 t_ddm = time.time() - t0
 op = S.RbfSystemOperator(tree, st.basis_size, pre.monomial_matrix, a.nugget)
 rhs = np.concatenate([vals, np.zeros(st.basis_size)])

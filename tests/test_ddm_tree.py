@@ -81,3 +81,14 @@ def test_median_selection_split_equals_the_stable_argsort_with_ties():
     pts[1::97, 0] = -0.0
     prm = DDMParams(50, 0.5, 0.125, 200)
     _same_tree(DDMTree(pts, prm), _oracle_levels(pts, prm))
+
+
+def test_params_for_points_keep_three_fine_levels():
+    """bbfmm_ddm_params_for_points (extension): defaults below ~2.1M points, above that a coarse threshold of
+    n/512 + 1, so that n -> n/8 -> n/64 -> n/512 ends the hierarchy after three fine levels."""
+    for n in (10, 5000, 2_000_000):
+        p = DDMParams.for_points(n)
+        assert (p.leaf_threshold, p.overlap_quota, p.coarse_ratio, p.coarse_threshold) == (1024, 0.5, 0.125, 4096)
+    for n in (3_000_000, 10_000_000, 40_000_000):
+        p = DDMParams.for_points(n)
+        assert p.coarse_threshold == n // 512 + 1 and n / 8 ** 3 <= p.coarse_threshold < n / 8 ** 2
