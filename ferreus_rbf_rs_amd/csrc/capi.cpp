@@ -340,7 +340,8 @@ void bbfmm_ddm_params_defaults(bbfmm_ddm_params *out) {
 void bbfmm_ddm_params_for_points(int64_t n, bbfmm_ddm_params *out) {
     if (!out) return;
     bbfmm_ddm_params_defaults(out);
-    out->coarse_threshold = std::max<int64_t>(out->coarse_threshold, n / 512 + 1);
+    // per level at most N (1/8 + 1/341) points survive (rounding up per leaf, leaves of more than 341 points)
+    out->coarse_threshold = std::max<int64_t>(out->coarse_threshold, n / 470 + 1);
 }
 int bbfmm_ddm_build(const double *points, int64_t n, int32_t d, int64_t ld, const bbfmm_ddm_params *params,
                     bbfmm_ddm **out) {

@@ -314,7 +314,8 @@ typedef struct bbfmm_ddm_params { /* DDMParams, config.rs:42-69 */
 } bbfmm_ddm_params;
 void bbfmm_ddm_params_defaults(bbfmm_ddm_params *out);
 /* Extension (not in the reference): the defaults with coarse_threshold raised so that the hierarchy over
- * n points keeps at most three fine levels, coarse_threshold = max(4096, n/512 + 1).  With the plain
+ * n points keeps at most three fine levels, coarse_threshold = max(4096, n/470 + 1): a level keeps
+ * ceil(ceil(N/8)/leaves) points per leaf, at most N (1/8 + 1/341), so three levels leave at most n/478.  With the plain
  * defaults a fourth fine level appears above about 2.1M points and leaves one coarse point per ~7 level-0
  * domains, where the sweep of schwarz.rs stalls for the thin-plate spline. */
 void bbfmm_ddm_params_for_points(int64_t n, bbfmm_ddm_params *out);

@@ -85,10 +85,17 @@ def test_median_selection_split_equals_the_stable_argsort_with_ties():
 
 def test_params_for_points_keep_three_fine_levels():
     """bbfmm_ddm_params_for_points (extension): defaults below ~2.1M points, above that a coarse threshold of
-    n/512 + 1, so that n -> n/8 -> n/64 -> n/512 ends the hierarchy after three fine levels."""
-    for n in (10, 5000, 2_000_000):
+    n/470 + 1 (a level keeps at most N (1/8 + 1/341) points), so that the hierarchy ends after three fine levels."""
+    for n in (10, 5000, 1_900_000):
         p = DDMParams.for_points(n)
         assert (p.leaf_threshold, p.overlap_quota, p.coarse_ratio, p.coarse_threshold) == (1024, 0.5, 0.125, 4096)
     for n in (3_000_000, 10_000_000, 40_000_000):
         p = DDMParams.for_points(n)
-        assert p.coarse_threshold == n // 512 + 1 and n / 8 ** 3 <= p.coarse_threshold < n / 8 ** 2
+        assert p.coarse_threshold == n // 470 + 1 and n * (1 / 8 + 1 / 341) ** 3 <= p.coarse_threshold < n / 8 ** 2
+
+
+def test_params_for_points_on_a_real_hierarchy():
+    n = 2_400_000 // 8                                   # 300k points: defaults give 3 levels either way
+    pts = np.random.default_rng(3).random((n, 3))
+    t = DDMTree(pts, DDMParams.for_points(n))
+    assert len(t.levels) <= 4 and len(t.levels[-1].leaf_domains) == 1
