@@ -1573,8 +1573,8 @@ int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
     if (hipMalloc(&dA, sizeof hA) != hipSuccess) return 1;
     if (hipMalloc(&dB, sizeof hB) != hipSuccess) return 1;
     if (hipMalloc(&dD, sizeof hD) != hipSuccess) return 1;
-    hipMemcpy(dA, hA, sizeof hA, hipMemcpyHostToDevice);
-    hipMemcpy(dB, hB, sizeof hB, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dA, hA, sizeof hA, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dB, hB, sizeof hB, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(mfma_layout_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dD);
     if (hipMemcpy(hD, dD, sizeof hD, hipMemcpyDeviceToHost) != hipSuccess) return 1;
     int errs = 0;
@@ -1587,22 +1587,22 @@ int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
     //   [4] TFLOP/s at 1 wave/SIMD                          [5] TFLOP/s at 2 waves/SIMD
     const int iters = 4096;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0);
-    hipEventCreate(&e1);
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
     unsigned long long *dS = nullptr;
     const int max_blocks = 2048;
-    hipMalloc(&dS, sizeof(unsigned long long) * 2 * 4 * max_blocks);
+    (void)hipMalloc(&dS, sizeof(unsigned long long) * 2 * 4 * max_blocks);
     std::vector<unsigned long long> hS(2 * 4 * max_blocks);
     auto run = [&](int blocks, int threads, double *cyc, double *mhz) {
         hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(threads), 0, 0, dD, 16, nullptr); // warm-up
-        hipEventRecord(e0, 0);
+        (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(threads), 0, 0, dD, iters, dS);
-        hipEventRecord(e1, 0);
-        hipEventSynchronize(e1);
+        (void)hipEventRecord(e1, 0);
+        (void)hipEventSynchronize(e1);
         float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         const int waves = blocks * (threads / 64);
-        hipMemcpy(hS.data(), dS, sizeof(unsigned long long) * 2 * 4 * blocks, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(hS.data(), dS, sizeof(unsigned long long) * 2 * 4 * blocks, hipMemcpyDeviceToHost);
         double sc = 0, sr = 0;
         for (int b = 0; b < blocks; ++b)
             for (int w = 0; w < threads / 64; ++w) {
@@ -1622,12 +1622,12 @@ int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
     if (info) {
         info[0] = i0; info[1] = i1; info[2] = i2; info[3] = i3; info[4] = tf1; info[5] = tf2;
     }
-    hipFree(dS);
-    hipEventDestroy(e0);
-    hipEventDestroy(e1);
-    hipFree(dA);
-    hipFree(dB);
-    hipFree(dD);
+    (void)hipFree(dS);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(dA);
+    (void)hipFree(dB);
+    (void)hipFree(dD);
     return 0;
 }
 

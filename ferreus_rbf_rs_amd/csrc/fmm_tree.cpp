@@ -371,7 +371,7 @@ static void split_tile_tail(std::vector<M2lTileDesc> *tiles, int n_cu) {
 
 int FmmTree::build_m2l_tables() {
     const HostTree &t = tree_;
-    const int d = d_, n = ops_.n, n_pad = round_up(n, 32);
+    const int d = d_, n = ops_.n;
     const int ncls = 1 << d, nvec = ops_.n_vec;
     const bool compressed = ops_.compression != kCompressionNone;
     m2l_host_.clear();
@@ -1608,7 +1608,7 @@ int FmmTree::subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out) {
 int FmmTree::set_partition(int rank, int world) {
     if (world < 1 || rank < 0 || rank >= world) return fail(BBFMM_BAD_ARGUMENT, "bad rank/world");
     const HostTree &t = tree_;
-    const int64_t N = t.n_points, C = t.n_cells();
+    const int64_t N = t.n_points;
     part_rank_ = rank;
     part_world_ = world;
     if (have_part_) {

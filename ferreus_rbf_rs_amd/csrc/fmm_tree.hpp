@@ -256,7 +256,6 @@ class FmmTree {
     double *h_pin_ = nullptr; // pinned staging for the host-buffer matvec (N doubles up, N down)
     size_t h_pin_n_ = 0;
     int ensure_pinned(size_t n);
-    int64_t w_in_rows_ = 0;
     TargetSet src_targets_;  // targets = sources (the matvec)
     TargetSet part_targets_; // sources owned by this rank (multi-GPU)
     bool have_part_ = false;
