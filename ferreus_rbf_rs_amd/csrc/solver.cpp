@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
+#include <memory>
 #include <vector>
 
 namespace {
@@ -66,8 +67,9 @@ double progress_from_rel(double cur, double start, double target) { // progress.
 }
 
 // get_solution (iterative_solvers.rs:174-183): x += Z[:, :i] (H[:i,:i]^-1 g[:i])
-void add_solution(const std::vector<double> &h, int ldh, const std::vector<double> &g,
-                  const std::vector<std::vector<double>> &z, int i, double *x, int64_t n) {
+template <class ZBasis>
+void add_solution(const std::vector<double> &h, int ldh, const std::vector<double> &g, const ZBasis &z, int i, double *x,
+                  int64_t n) {
     std::vector<double> y(g.begin(), g.begin() + i);
     for (int r = i - 1; r >= 0; --r) {
         double s = y[r];
@@ -141,8 +143,20 @@ int bbfmm_fgmres(int64_t n, bbfmm_apply_fn a, void *a_user, const double *b, bbf
     double res_norm = absolute ? beta : 1.0;
     if (iterations) *iterations = 0;
     if (final_residual) *final_residual = res_norm;
-    std::vector<std::vector<double>> v(static_cast<size_t>(mi + 1), std::vector<double>(static_cast<size_t>(n)));
-    std::vector<std::vector<double>> z(static_cast<size_t>(mi), std::vector<double>(static_cast<size_t>(n)));
+    // Krylov and preconditioned bases: allocated without initialisation -- every vector is written in full
+    // (threaded) before it is read, so the pages are first touched in parallel instead of by one thread
+    struct Basis {
+        std::vector<std::unique_ptr<double[]>> col;
+        Basis(int count, int64_t len) {
+            for (int i = 0; i < count; ++i) col.emplace_back(new double[static_cast<size_t>(len)]);
+        }
+        struct Col {
+            double *p;
+            double *data() const { return p; }
+        };
+        Col operator[](size_t i) const { return Col{col[i].get()}; }
+    };
+    Basis v(mi + 1, n), z(mi, n);
     std::vector<double> h(static_cast<size_t>(ldh) * mi), g(static_cast<size_t>(mi + 1)), cs(mi), sn(mi);
     for (int outer = 0; outer < max_outer_iterations; ++outer) {
         std::fill(h.begin(), h.end(), 0.0);
@@ -185,7 +199,7 @@ int bbfmm_fgmres(int64_t n, bbfmm_apply_fn a, void *a_user, const double *b, bbf
             g[j] = temp;
             cs[j] = c, sn[j] = s;
             if (norm != 0.0) scale_to(1.0 / norm, wj.data(), v[j + 1].data(), n);
-            else std::fill(v[j + 1].begin(), v[j + 1].end(), 0.0);
+            else scale_to(0.0, wj.data(), v[j + 1].data(), n);
             res_norm = absolute ? std::fabs(g[j + 1]) : std::fabs(g[j + 1]) / beta;
             if (iterations) *iterations = iteration;
             if (final_residual) *final_residual = res_norm;
