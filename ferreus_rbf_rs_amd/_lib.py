@@ -55,6 +55,7 @@ SIGNATURES = {
                                                             c_i64, c_i64, c_p, c_i64, c_p, c_i64,
                                                             c_p]),
     "bbfmm_source_points": (ctypes.c_int, [c_p, c_p, c_i64]),
+    "bbfmm_prepare_target_subset": (ctypes.c_int, [c_p, c_p, c_i64]),
     "bbfmm_fast_matrix_vector_product": (ctypes.c_int, [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p,
                                                         c_i64, c_f64, c_p]),
     "bbfmm_matvec_device": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_i64, c_i32]),

@@ -133,6 +133,11 @@ int bbfmm_fast_matrix_vector_product(bbfmm_handle *h, const double *w, int64_t r
     END_GUARD(h)
 }
 
+int bbfmm_prepare_target_subset(bbfmm_handle *h, const int64_t *target_indices, int64_t n_target_indices) {
+    GUARD(h) return h->tree.prepare_target_subset(target_indices, n_target_indices);
+    END_GUARD(h)
+}
+
 int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_out, int64_t ldo,
                         int32_t sync) {
     GUARD(h) return h->tree.matvec_device(d_w, ldw, k, d_out, ldo, sync != 0);

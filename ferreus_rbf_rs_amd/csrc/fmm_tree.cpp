@@ -1265,6 +1265,15 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
     return BBFMM_OK;
 }
 
+int FmmTree::prepare_target_subset(const int64_t *target_indices, int64_t n_target_indices) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (!target_indices || n_target_indices < 0) return fail(BBFMM_BAD_ARGUMENT, "bad target index array");
+    CHK(ensure_pinned(static_cast<size_t>(2 * tree_.n_points)));
+    CHK(ensure_rhs_capacity(1));
+    SubsetPlan *sp = nullptr;
+    return subset_plan(target_indices, n_target_indices, &sp);
+}
+
 int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t basis_size,
                                         const int64_t *target_indices, int64_t n_target_indices, const double *poly,
                                         int64_t ldp, double nugget, double *result) {

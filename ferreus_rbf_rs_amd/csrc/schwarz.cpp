@@ -281,6 +281,12 @@ int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, in
     S.res.assign(static_cast<size_t>(n + S.basis), 0.0);
     S.tmp.assign(static_cast<size_t>(n + S.basis), 0.0);
     S.s1.assign(static_cast<size_t>(n + S.basis), 0.0);
+    // the target-subset plans of the levels' partial matvecs belong to the setup, not to the first apply
+    for (const DdmLevel &L : S.ddm.levels) {
+        rc = bbfmm_prepare_target_subset(tree, L.point_indices.data(), static_cast<int64_t>(L.point_indices.size()));
+        if (rc) return rc;
+    }
+    lap("target-subset plans", -1);
     *out = h.release();
     return BBFMM_OK;
 }

@@ -156,6 +156,12 @@ int bbfmm_fast_matrix_vector_product(bbfmm_handle *h, const double *w, int64_t r
                                      int64_t n_target_indices, const double *poly, int64_t ldp,
                                      double nugget, double *result);
 
+/* Builds (and caches) what a later bbfmm_fast_matrix_vector_product with these target_indices needs -- the
+ * sorted targets and the restricted downward pass -- without running a product; also allocates the
+ * pinned staging buffer.  Optional: the first product with an index set does the same.  The Schwarz
+ * preconditioner calls it for its levels at creation, so that setup cost does not land in the solve. */
+int bbfmm_prepare_target_subset(bbfmm_handle *h, const int64_t *target_indices, int64_t n_target_indices);
+
 /*
  * Device-resident form of the same product for the case target_indices = all,
  * basis_size = 0, nugget = 0 generalised to k right-hand sides:
