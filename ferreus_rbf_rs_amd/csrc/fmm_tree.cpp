@@ -2,6 +2,7 @@
 #include "fmm_tree.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -1265,11 +1266,26 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
     return BBFMM_OK;
 }
 
+// target_indices = 0, 1, ..., N-1 (the finest Schwarz level): the plain all-rows product serves it
+bool FmmTree::is_identity_subset(const int64_t *idx, int64_t n_idx) const {
+    if (n_idx != tree_.n_points) return false;
+    std::atomic<bool> same{true};
+    parallel_for_chunks(n_idx, int64_t(1) << 18, [&](int64_t b, int64_t e) {
+        for (int64_t j = b; j < e; ++j)
+            if (idx[j] != j) {
+                same.store(false, std::memory_order_relaxed);
+                return;
+            }
+    });
+    return same.load();
+}
+
 int FmmTree::prepare_target_subset(const int64_t *target_indices, int64_t n_target_indices) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     if (!target_indices || n_target_indices < 0) return fail(BBFMM_BAD_ARGUMENT, "bad target index array");
     CHK(ensure_pinned(static_cast<size_t>(2 * tree_.n_points)));
     CHK(ensure_rhs_capacity(1));
+    if (is_identity_subset(target_indices, n_target_indices)) return BBFMM_OK;
     SubsetPlan *sp = nullptr;
     return subset_plan(target_indices, n_target_indices, &sp);
 }
@@ -1282,6 +1298,7 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
     if (!w || !result || basis_size < 0 || rows != N + basis_size)
         return fail(BBFMM_BAD_ARGUMENT, "weights must have N + basis_size rows");
     if (poly && ldp < N) return fail(BBFMM_BAD_ARGUMENT, "polynomial matrix needs N rows");
+    if (target_indices && is_identity_subset(target_indices, n_target_indices)) target_indices = nullptr; // all rows in order
     if (!target_indices) {
         // All sources (the FGMRES matvec, rbf.rs:105-117): the targets already live on the device.
         // Host traffic goes through one pinned staging buffer (pageable copies run at a fraction of

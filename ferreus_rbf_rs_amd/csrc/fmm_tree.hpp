@@ -97,6 +97,7 @@ class FmmTree {
                  double *out, int64_t ldo, double *grad, int64_t ldg, bool with_grads, bool leaves_only,
                  int64_t *bad_point_index);                                             // bbfmm.rs:444-616
     int prepare_target_subset(const int64_t *target_indices, int64_t n_target_indices);
+    bool is_identity_subset(const int64_t *idx, int64_t n_idx) const;
     int fast_matrix_vector_product(const double *w, int64_t rows, int64_t basis_size, const int64_t *target_indices,
                                    int64_t n_target_indices, const double *poly, int64_t ldp, double nugget,
                                    double *result);                                     // rbf.rs:1338-1379

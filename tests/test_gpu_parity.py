@@ -174,6 +174,11 @@ def test_fast_matrix_vector_product_semantics():
     mask = np.ones(n + 4, bool)
     mask[sub] = False
     assert np.all(part[mask] == 0.0) and relerr(part[sub], full[sub]) < TOL
+    # every row, in order, given as an index set (the finest Schwarz level): served by the all-rows product
+    allrows = t.fast_matrix_vector_product(wf, 4, np.arange(n), P, 0.01)
+    assert relerr(allrows, full) < 1e-14 and np.all(allrows[n:] == 0.0)
+    perm = rng.permutation(n)                     # every row, shuffled: an ordinary subset plan, same values
+    assert relerr(t.fast_matrix_vector_product(wf, 4, perm, P, 0.01), full) < TOL
 
 
 def test_device_resident_matvec_and_partition_union():
