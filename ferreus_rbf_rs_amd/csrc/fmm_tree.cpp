@@ -298,11 +298,24 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
 // Stacked operators of one (level, class): VtAll (n_pad x r_pad16) and UAll (k_pad x n_pad).
 void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<double> *vt_all,
                                        std::vector<double> *u_all) const {
+    const int n_pad = round_up(ops_.n, 32);
+    vt_all->resize(static_cast<size_t>(n_pad) * hc.r_pad16);
+    u_all->resize(static_cast<size_t>(hc.k_pad) * n_pad);
+    fill_m2l_operator_arrays(hc, vt_all->data(), u_all->data());
+}
+
+// vt_all: n_pad x r_pad16, u_all: k_pad x n_pad (both overwritten, padding zeroed)
+void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, double *vt_all, double *u_all) const {
     const int n = ops_.n, n_pad = round_up(n, 32);
     const bool compressed = ops_.compression != kCompressionNone;
     const auto &lops = ops_.m2l[hc.level];
-    vt_all->assign(static_cast<size_t>(n_pad) * hc.r_pad16, 0.0);
-    u_all->assign(static_cast<size_t>(hc.k_pad) * n_pad, 0.0);
+    auto zero = [](double *p, size_t len) {
+        parallel_for_chunks(static_cast<int64_t>(len), int64_t(1) << 18, [&](int64_t b, int64_t e) {
+            std::memset(p + b, 0, static_cast<size_t>(e - b) * sizeof(double));
+        });
+    };
+    zero(vt_all, static_cast<size_t>(n_pad) * hc.r_pad16);
+    zero(u_all, static_cast<size_t>(hc.k_pad) * n_pad);
     struct RowSrc {
         const M2lOperator *op;
         const int32_t *inv;
@@ -317,7 +330,7 @@ void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<doubl
     }
     // c[kk] = sum_m Vt[kk][invperm[m]] * M_V[m]   (bbfmm.rs:924-930 folded)
     parallel_for(n, 8, [&](int64_t m) {
-        double *dst = vt_all->data() + static_cast<size_t>(m) * hc.r_pad16;
+        double *dst = vt_all + static_cast<size_t>(m) * hc.r_pad16;
         for (const RowSrc &rs : row_src) {
             const int r = rs.op->rank;
             const int im = rs.inv[m];
@@ -335,7 +348,7 @@ void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<doubl
         const M2lOperator &op = lops[ops_.ref_lookup[tv]];
         const int32_t *inv = &ops_.invperm[static_cast<size_t>(ops_.perm_lookup[tv]) * n];
         for (int kk = 0; kk < op.rank; ++kk) {
-            double *dst = u_all->data() + static_cast<size_t>(hc.tgt_off[pos] + kk) * n_pad;
+            double *dst = u_all + static_cast<size_t>(hc.tgt_off[pos] + kk) * n_pad;
             const double *ucol = &op.u[static_cast<size_t>(kk) * n];
             for (int i = 0; i < n; ++i) dst[i] = ucol[inv[i]];
         }
@@ -666,7 +679,25 @@ int FmmTree::upload() {
     }
     // M2L tables
     m2l_classes_h_.resize(m2l_host_.size());
-    std::vector<double> vt_scratch, u_scratch; // reused: page-faulting fresh host memory is slow
+    // the stacked operators (GBs at p = 9) are filled straight into two halves of the pinned staging buffer:
+    // the fill of one class runs beside the DMA of the previous one
+    size_t max_vt = 0, max_u = 0;
+    for (const HostM2lClass &h : m2l_host_) {
+        if (h.cells.empty()) continue;
+        max_vt = std::max(max_vt, static_cast<size_t>(cheb_.n_pad) * h.r_pad16);
+        max_u = std::max(max_u, static_cast<size_t>(h.k_pad) * cheb_.n_pad);
+    }
+    CHK(ensure_pinned(2 * (max_vt + max_u)));
+    hipEvent_t ev_buf[2] = {nullptr, nullptr};
+    for (hipEvent_t &e : ev_buf) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    struct EvGuard {
+        hipEvent_t *e;
+        ~EvGuard() {
+            for (int i = 0; i < 2; ++i)
+                if (e[i]) (void)hipEventDestroy(e[i]);
+        }
+    } ev_guard{ev_buf};
+    int n_filled = 0;
     for (size_t i = 0; i < m2l_host_.size(); ++i) {
         HostM2lClass &h = m2l_host_[i];
         M2lClass &c = m2l_classes_h_[i];
@@ -680,9 +711,19 @@ int FmmTree::upload() {
         DevBuf<double> vt, ua;
         DevBuf<int32_t> rt, ro, ce, cs;
         DevBuf<int64_t> cb;
-        fill_m2l_operator_arrays(h, &vt_scratch, &u_scratch);
-        CHK(dupload(&vt, vt_scratch));
-        CHK(dupload(&ua, u_scratch));
+        {
+            const int b = n_filled & 1;
+            double *pvt = h_pin_ + static_cast<size_t>(b) * (max_vt + max_u), *pu = pvt + max_vt;
+            if (n_filled >= 2) HIPCHK(hipEventSynchronize(ev_buf[b])); // the copy that last read this half is done
+            fill_m2l_operator_arrays(h, pvt, pu);
+            const size_t nvt = static_cast<size_t>(cheb_.n_pad) * h.r_pad16, nu = static_cast<size_t>(h.k_pad) * cheb_.n_pad;
+            CHK(dalloc(&vt, nvt));
+            CHK(dalloc(&ua, nu));
+            HIPCHK(hipMemcpyAsync(vt.p, pvt, nvt * sizeof(double), hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipMemcpyAsync(ua.p, pu, nu * sizeof(double), hipMemcpyHostToDevice, stream_));
+            HIPCHK(hipEventRecord(ev_buf[b], stream_));
+            ++n_filled;
+        }
         CHK(dupload(&rt, h.row_dst));
         CHK(dupload(&ro, h.blk_t0));
         CHK(dupload(&ce, h.cells));
@@ -697,6 +738,7 @@ int FmmTree::upload() {
         c.cbase = cb.p;
         std::vector<int32_t>().swap(h.cslot); // only needed for uploading
     }
+    HIPCHK(hipStreamSynchronize(stream_)); // the last operator copies have left the staging buffer
     CHK(dupload(&d_m2l_classes_, m2l_classes_h_));
     CHK(dupload(&d_m2l_tiles_, m2l_tiles_h_));
     m2l_tiles2_h_ = m2l_tiles_h_;

@@ -136,6 +136,7 @@ class FmmTree {
     int build_m2l_tables();
     void fill_m2l_operator_arrays(const HostM2lClass &hc, std::vector<double> *vt_all,
                                   std::vector<double> *u_all) const;
+    void fill_m2l_operator_arrays(const HostM2lClass &hc, double *vt_all, double *u_all) const;
     int ensure_rhs_capacity(int k);
     int upward(int k);                                  // P2M + M2M from w_sorted_
     int downward(int k, const DownwardPlan *dp = nullptr); // M2L + P2L + L2L into L_ (restricted by a plan)
