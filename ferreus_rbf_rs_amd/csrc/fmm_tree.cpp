@@ -542,47 +542,70 @@ int FmmTree::build_m2l_tables() {
             hc.cslot.assign(hc.cells.size() * static_cast<size_t>(hc.n_t), -1);
         }
         // cslot: for every V pair (B <- V, t) the slot of B as seen from V
-        for (int64_t B = t.level_ptr[level]; B < t.level_ptr[level + 1]; ++B) {
-            const HostM2lClass &hb = m2l_host_[first_class + t.octant[B]];
-            const int64_t base = hb.cbase[pos_in_class[B]];
-            for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
-                const int32_t V = t.v.idx[q];
-                const int tv = t.v_tidx[q];
-                HostM2lClass &hv = m2l_host_[first_class + t.octant[V]];
-                const int ps = (tv >= 0 && tv < nvec) ? tpos_src[t.octant[V]][tv] : -1;
-                if (ps < 0 || t.level[V] != level || tpos_tgt[t.octant[B]][tv] < 0) {
-                    ++bad_pairs;
-                    continue;
+        // (threaded: every (V, t) slot has exactly one writer; flop and error counts are reduced per chunk)
+        {
+            const int64_t b0 = t.level_ptr[level], nb_cells = t.level_ptr[level + 1] - b0;
+            constexpr int64_t kChunkB = 2048;
+            const int64_t nch = (nb_cells + kChunkB - 1) / kChunkB;
+            std::vector<double> flops_part(static_cast<size_t>(std::max<int64_t>(nch, 1)), 0.0);
+            std::vector<int64_t> bad_part(static_cast<size_t>(std::max<int64_t>(nch, 1)), 0);
+            parallel_for_chunks(nb_cells, kChunkB, [&](int64_t lo, int64_t hi) {
+                double fl = 0.0;
+                int64_t bad = 0;
+                for (int64_t B = b0 + lo; B < b0 + hi; ++B) {
+                    const HostM2lClass &hb = m2l_host_[first_class + t.octant[B]];
+                    const int64_t base = hb.cbase[pos_in_class[B]];
+                    for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
+                        const int32_t V = t.v.idx[q];
+                        const int tv = t.v_tidx[q];
+                        HostM2lClass &hv = m2l_host_[first_class + t.octant[V]];
+                        const int ps = (tv >= 0 && tv < nvec) ? tpos_src[t.octant[V]][tv] : -1;
+                        if (ps < 0 || t.level[V] != level || tpos_tgt[t.octant[B]][tv] < 0) {
+                            ++bad;
+                            continue;
+                        }
+                        hv.cslot[static_cast<size_t>(pos_in_class[V]) * hv.n_t + ps] = static_cast<int32_t>(base / 2);
+                        const int r = rank_of(tv);
+                        fl += compressed ? 4.0 * n * r : 2.0 * n * static_cast<double>(n);
+                    }
                 }
-                hv.cslot[static_cast<size_t>(pos_in_class[V]) * hv.n_t + ps] = static_cast<int32_t>(base / 2);
-                const int r = rank_of(tv);
-                m2l_flops_k1_ += compressed ? 4.0 * n * r : 2.0 * n * static_cast<double>(n);
-            }
+                flops_part[static_cast<size_t>(lo / kChunkB)] = fl;
+                bad_part[static_cast<size_t>(lo / kChunkB)] = bad;
+            });
+            for (double f : flops_part) m2l_flops_k1_ += f; // fixed order: same total on every run
+            for (int64_t b : bad_part) bad_pairs += b;
         }
         for (int o = 0; o < ncls; ++o) {
             const HostM2lClass &hc = m2l_host_[first_class + o];
             const int nq = hc.k_pad / 16;
-            for (int32_t first = 0; first < static_cast<int32_t>(hc.cells.size()); first += kM2lTile) {
-                M2lTileDesc td;
-                td.level_class = static_cast<int32_t>(first_class + o);
-                td.first = first;
-                td.count = std::min<int32_t>(kM2lTile, static_cast<int32_t>(hc.cells.size()) - first);
-                td.pad = 0;
+            const int64_t n_tiles_cls = (static_cast<int64_t>(hc.cells.size()) + kM2lTile - 1) / kM2lTile;
+            std::vector<std::vector<uint16_t>> tile_q(static_cast<size_t>(n_tiles_cls));
+            parallel_for(n_tiles_cls, 4, [&](int64_t ti) {
+                const int32_t first = static_cast<int32_t>(ti * kM2lTile);
+                const int32_t count = std::min<int32_t>(kM2lTile, static_cast<int32_t>(hc.cells.size()) - first);
                 // contraction steps (16 slot entries each) that hold at least one V-list entry of the tile
                 std::vector<uint8_t> act(static_cast<size_t>(nq), 0);
-                for (int32_t i = 0; i < td.count; ++i) {
+                for (int32_t i = 0; i < count; ++i) {
                     const int64_t B = hc.cells[first + i];
                     for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
                         const int tv = t.v_tidx[q];
                         const int pos = tpos_tgt[o][tv];
                         if (pos < 0) continue;
                         const int a = off_tgt[o][pos], b = a + rank_of(tv);
-                        for (int s = a / 16; s <= (b - 1) / 16; ++s) act[s] = 1;
+                        for (int sq = a / 16; sq <= (b - 1) / 16; ++sq) act[sq] = 1;
                     }
                 }
+                for (int sq = 0; sq < nq; ++sq)
+                    if (act[sq]) tile_q[static_cast<size_t>(ti)].push_back(static_cast<uint16_t>(sq));
+            });
+            for (int64_t ti = 0; ti < n_tiles_cls; ++ti) {
+                M2lTileDesc td;
+                td.level_class = static_cast<int32_t>(first_class + o);
+                td.first = static_cast<int32_t>(ti * kM2lTile);
+                td.count = std::min<int32_t>(kM2lTile, static_cast<int32_t>(hc.cells.size()) - td.first);
+                td.pad = 0;
                 td.q_first = static_cast<int32_t>(m2l_qlist_h_.size());
-                for (int s = 0; s < nq; ++s)
-                    if (act[s]) m2l_qlist_h_.push_back(static_cast<uint16_t>(s));
+                m2l_qlist_h_.insert(m2l_qlist_h_.end(), tile_q[static_cast<size_t>(ti)].begin(), tile_q[static_cast<size_t>(ti)].end());
                 td.q_count = static_cast<int32_t>(m2l_qlist_h_.size()) - td.q_first;
                 m2l_tiles_h_.push_back(td);
             }
