@@ -205,6 +205,7 @@ class FmmTree:
         w = _as_f64_2d(weights, "weights")
         self._raise(self._lib.bbfmm_set_local_coefficients(self._h, w.ctypes.data, w.shape[0],
                                                            w.shape[1], w.shape[0]))
+        self._nrhs = w.shape[1]           # (the column count may also have been fixed by a matvec on the C side)
 
     def _eval(self, fn, weights, target_points, grads, leaf):
         x = _as_f64_2d(target_points, "target_points")
@@ -263,12 +264,14 @@ class FmmTree:
             poly.ctypes.data if poly is not None else None,
             poly.shape[0] if poly is not None else 0, float(nugget), res.ctypes.data)
         self._raise(rc)
+        self._nrhs = 1
         return res
 
     # -- device-resident matvec (what bench.py times); d_w / d_out are device pointers
     def matvec_device(self, d_w_ptr: int, ldw: int, k: int, d_out_ptr: int, ldo: int, sync=True):
         self._raise(self._lib.bbfmm_matvec_device(self._h, d_w_ptr, ldw, k, d_out_ptr, ldo,
                                                   int(sync)))
+        self._nrhs = int(k)
 
     def stream(self) -> int:
         return int(self._lib.bbfmm_stream(self._h) or 0)
