@@ -267,6 +267,11 @@ class FmmTree:
         self._nrhs = 1
         return res
 
+    def prepare_target_subset(self, target_indices) -> None:
+        """bbfmm_prepare_target_subset: build and cache the plan of a later partial product ahead of time."""
+        idx = np.ascontiguousarray(np.asarray(target_indices, dtype=np.int64))
+        self._raise(self._lib.bbfmm_prepare_target_subset(self._h, idx.ctypes.data, len(idx)))
+
     # -- device-resident matvec (what bench.py times); d_w / d_out are device pointers
     def matvec_device(self, d_w_ptr: int, ldw: int, k: int, d_out_ptr: int, ldo: int, sync=True):
         self._raise(self._lib.bbfmm_matvec_device(self._h, d_w_ptr, ldw, k, d_out_ptr, ldo,

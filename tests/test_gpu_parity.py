@@ -262,6 +262,9 @@ def test_partial_matvec_plans_and_restricted_evaluate():
     full = t.fast_matrix_vector_product(w, nugget=0.25)
     subsets = [np.sort(rng.choice(n, m, replace=False)).astype(np.int64) for m in (7, 300, 5000, 20000)]
     subsets += [rng.choice(n, 50, replace=True).astype(np.int64) for _ in range(7)]   # > 8 plans: eviction
+    t.prepare_target_subset(subsets[2])                                               # plan built ahead of the first product
+    with pytest.raises(ValueError):
+        t.prepare_target_subset(np.array([0, n], dtype=np.int64))                     # index out of range
     for rep in range(2):                                                              # second round: cached or rebuilt
         for idx in subsets:
             y = t.fast_matrix_vector_product(w, target_indices=idx, nugget=0.25)
