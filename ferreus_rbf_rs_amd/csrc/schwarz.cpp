@@ -18,6 +18,7 @@
 
 #include "ddm.hpp"
 #include "ddm_solver.hpp"
+#include "device.hpp"
 #include "parallel.hpp"
 
 namespace {
@@ -37,6 +38,11 @@ struct Schwarz {
     std::vector<double> coarse_xyz; // coarse domain points (domain order), 3 x n_c
     hipStream_t stream = nullptr;
     double *d_in = nullptr, *d_out = nullptr;
+    // levels well under N points exchange only their own rows with the device: per level the point indices on
+    // the device, one pinned buffer [values in | coefficients out] and its device twin
+    std::vector<int32_t *> d_lidx;
+    double *h_comp = nullptr, *d_comp = nullptr;
+    int64_t comp_cap = 0;
     std::vector<double> res, tmp, s1;
     double t_matvec = 0, t_solve = 0, t_host = 0; // BBFMM_VERBOSE: seconds per apply
     std::vector<double> t_level, t_level_mv;      // per level: local solves, partial matvecs
@@ -44,6 +50,10 @@ struct Schwarz {
         for (auto &lv : levels) ddm_level_free(&lv);
         if (d_in) (void)hipFree(d_in);
         if (d_out) (void)hipFree(d_out);
+        for (int32_t *p : d_lidx)
+            if (p) (void)hipFree(p);
+        if (d_comp) (void)hipFree(d_comp);
+        if (h_comp) (void)hipHostFree(h_comp);
         if (stream) (void)hipStreamDestroy(stream);
     }
 };
@@ -71,21 +81,54 @@ int level_correction(Schwarz &S, size_t li, const double *rg, const double *sl, 
         if (S.t_level_mv.size() < S.levels.size()) S.t_level_mv.resize(S.levels.size(), 0.0);
         S.t_level_mv[li] += secs(t0, now());
         t0 = now();
-        parallel_for_chunks(nt, 1 << 16, [&](int64_t b, int64_t e) {
-            for (int64_t i = b; i < e; ++i) S.res[i] = rg[i] - S.tmp[i];
-        });
-    } else { // debug entry: solve the level for rg itself
-        std::copy(rg, rg + nt, S.res.begin());
     }
-    if (hipMemcpyAsync(S.d_in, S.res.data(), static_cast<size_t>(S.n) * sizeof(double), hipMemcpyHostToDevice, S.stream) != hipSuccess ||
-        hipMemsetAsync(S.d_out, 0, static_cast<size_t>(S.n) * sizeof(double), S.stream) != hipSuccess)
-        return BBFMM_DEVICE_ERROR;
-    rc = ddm_level_solve(S.levels[li], S.d_in, S.d_out, coarse, S.stream);
-    if (rc) return rc;
-    if (hipMemcpyAsync(S.s1.data(), S.d_out, static_cast<size_t>(S.n) * sizeof(double), hipMemcpyDeviceToHost, S.stream) != hipSuccess ||
-        hipStreamSynchronize(S.stream) != hipSuccess)
-        return BBFMM_DEVICE_ERROR;
-    for (int64_t i = S.n; i < nt; ++i) S.s1[i] = 0.0;
+    const int64_t nl = static_cast<int64_t>(L.point_indices.size());
+    const bool compact = li < S.d_lidx.size() && S.d_lidx[li] != nullptr;
+    if (compact) {
+        // only the level's rows matter to its domains (they read nothing else, and every row of the level is
+        // internal to exactly one domain): residual on those rows, up, solve, coefficients of those rows back
+        const int64_t *idx = L.point_indices.data();
+        parallel_for_chunks(nl, 1 << 15, [&](int64_t b, int64_t e) {
+            for (int64_t j = b; j < e; ++j) {
+                const double v = sl ? rg[idx[j]] - S.tmp[idx[j]] : rg[idx[j]];
+                S.h_comp[j] = v;
+                S.res[idx[j]] = v; // (the coarse domain's polynomial recovery reads its special points here)
+            }
+        });
+        if (hipMemcpyAsync(S.d_comp, S.h_comp, static_cast<size_t>(nl) * sizeof(double), hipMemcpyHostToDevice, S.stream) != hipSuccess)
+            return BBFMM_DEVICE_ERROR;
+        launch_scatter_output(S.d_comp, nl, 1, S.d_lidx[li], S.d_in, S.n, 0, S.stream);
+        rc = ddm_level_solve(S.levels[li], S.d_in, S.d_out, coarse, S.stream);
+        if (rc) return rc;
+        launch_gather_rows(S.d_out, S.n, 1, S.d_lidx[li], nl, S.d_comp + S.comp_cap, nl, S.stream);
+        if (hipMemcpyAsync(S.h_comp + S.comp_cap, S.d_comp + S.comp_cap, static_cast<size_t>(nl) * sizeof(double),
+                           hipMemcpyDeviceToHost, S.stream) != hipSuccess)
+            return BBFMM_DEVICE_ERROR;
+        parallel_for_chunks(nt, 1 << 18, [&](int64_t b, int64_t e) { // (beside the device work)
+            std::memset(S.s1.data() + b, 0, static_cast<size_t>(e - b) * sizeof(double));
+        });
+        if (hipStreamSynchronize(S.stream) != hipSuccess) return BBFMM_DEVICE_ERROR;
+        parallel_for_chunks(nl, 1 << 15, [&](int64_t b, int64_t e) {
+            for (int64_t j = b; j < e; ++j) S.s1[idx[j]] = S.h_comp[S.comp_cap + j];
+        });
+    } else {
+        if (sl) {
+            parallel_for_chunks(nt, 1 << 16, [&](int64_t b, int64_t e) {
+                for (int64_t i = b; i < e; ++i) S.res[i] = rg[i] - S.tmp[i];
+            });
+        } else { // debug entry: solve the level for rg itself
+            std::copy(rg, rg + nt, S.res.begin());
+        }
+        if (hipMemcpyAsync(S.d_in, S.res.data(), static_cast<size_t>(S.n) * sizeof(double), hipMemcpyHostToDevice, S.stream) != hipSuccess ||
+            hipMemsetAsync(S.d_out, 0, static_cast<size_t>(S.n) * sizeof(double), S.stream) != hipSuccess)
+            return BBFMM_DEVICE_ERROR;
+        rc = ddm_level_solve(S.levels[li], S.d_in, S.d_out, coarse, S.stream);
+        if (rc) return rc;
+        if (hipMemcpyAsync(S.s1.data(), S.d_out, static_cast<size_t>(S.n) * sizeof(double), hipMemcpyDeviceToHost, S.stream) != hipSuccess ||
+            hipStreamSynchronize(S.stream) != hipSuccess)
+            return BBFMM_DEVICE_ERROR;
+        for (int64_t i = S.n; i < nt; ++i) S.s1[i] = 0.0;
+    }
     S.t_solve += secs(t0, now());
     if (S.t_level.size() < S.levels.size()) S.t_level.resize(S.levels.size(), 0.0);
     S.t_level[li] += secs(t0, now());
@@ -98,12 +141,19 @@ int level_correction(Schwarz &S, size_t li, const double *rg, const double *sl, 
     if (!coarse) {
         if (S.basis) { // orthogonalise against the global polynomial basis (schwarz.rs:113-126)
             std::vector<double> proj(static_cast<size_t>(S.basis), 0.0);
-            for (int b = 0; b < S.basis; ++b) {
-                double s = 0.0;
-                const double *q = &S.ortho[static_cast<size_t>(b) * S.n];
-                for (int64_t i = 0; i < S.n; ++i) s += q[i] * S.s1[i];
-                proj[b] = s;
-            }
+            constexpr int64_t kChunkP = 1 << 16; // fixed chunks, partial sums combined in order: deterministic
+            const int64_t nch = (S.n + kChunkP - 1) / kChunkP;
+            std::vector<double> part(static_cast<size_t>(nch) * S.basis, 0.0);
+            parallel_for_chunks(S.n, kChunkP, [&](int64_t lo, int64_t hi) {
+                for (int b = 0; b < S.basis; ++b) {
+                    double s = 0.0;
+                    const double *q = &S.ortho[static_cast<size_t>(b) * S.n];
+                    for (int64_t i = lo; i < hi; ++i) s += q[i] * S.s1[i];
+                    part[static_cast<size_t>(lo / kChunkP) * S.basis + b] = s;
+                }
+            });
+            for (int64_t c = 0; c < nch; ++c)
+                for (int b = 0; b < S.basis; ++b) proj[b] += part[static_cast<size_t>(c) * S.basis + b];
             parallel_for_chunks(S.n, 1 << 16, [&](int64_t bb, int64_t e) {
                 for (int64_t i = bb; i < e; ++i) {
                     double s = 0.0;
@@ -281,6 +331,20 @@ int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, in
     S.res.assign(static_cast<size_t>(n + S.basis), 0.0);
     S.tmp.assign(static_cast<size_t>(n + S.basis), 0.0);
     S.s1.assign(static_cast<size_t>(n + S.basis), 0.0);
+    S.d_lidx.assign(S.ddm.levels.size(), nullptr);
+    for (size_t li = 0; li < S.ddm.levels.size(); ++li) {
+        const auto &pi = S.ddm.levels[li].point_indices;
+        if (static_cast<int64_t>(pi.size()) * 2 >= n || pi.empty()) continue; // (the finest level moves whole vectors)
+        std::vector<int32_t> idx32(pi.begin(), pi.end());
+        if (hipMalloc(reinterpret_cast<void **>(&S.d_lidx[li]), idx32.size() * sizeof(int32_t)) != hipSuccess ||
+            hipMemcpy(S.d_lidx[li], idx32.data(), idx32.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
+            return BBFMM_DEVICE_ERROR;
+        S.comp_cap = std::max<int64_t>(S.comp_cap, static_cast<int64_t>(pi.size()));
+    }
+    if (S.comp_cap > 0 &&
+        (hipHostMalloc(reinterpret_cast<void **>(&S.h_comp), static_cast<size_t>(2 * S.comp_cap) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+         hipMalloc(reinterpret_cast<void **>(&S.d_comp), static_cast<size_t>(2 * S.comp_cap) * sizeof(double)) != hipSuccess))
+        return BBFMM_DEVICE_ERROR;
     // the target-subset plans of the levels' partial matvecs belong to the setup, not to the first apply
     for (const DdmLevel &L : S.ddm.levels) {
         rc = bbfmm_prepare_target_subset(tree, L.point_indices.data(), static_cast<int64_t>(L.point_indices.size()));
