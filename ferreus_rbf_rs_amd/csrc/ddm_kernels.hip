@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
 // factorises the 64 x 64 diagonal block and stores its inverse, a launch over the rows below multiplies
 // them by that inverse; the second half is first updated with the first (K = 64); the trailing update
 // uses both (K = 128).  All products run on the MFMA tiles of the per-domain kernel.
-__global__ __launch_bounds__(256) void big_diag_kernel(double *A, int m, int jb, double *Linv, int *fail) {
+__global__ __launch_bounds__(256) void big_diag_kernel(double *A, int m, int jb, double *Linv, double *keep, int *fail) {
     __shared__ double Ld[CB][CB + 1];
     __shared__ double colj[CB];
     const int tid = threadIdx.x, nb = min(CB, m - jb);
@@ -278,7 +278,11 @@ __global__ __launch_bounds__(256) void big_diag_kernel(double *A, int m, int jb,
         }
         __syncthreads();
     }
-    for (int e = tid; e < CB * CB; e += 256) Linv[e] = Ld[e >> 6][e & (CB - 1)]; // row-major [column of X][k]
+    for (int e = tid; e < CB * CB; e += 256) { // row-major [column of X][k]; kept per block for the substitutions
+        const double x = Ld[e >> 6][e & (CB - 1)];
+        Linv[e] = x;
+        keep[static_cast<int64_t>(jb / CB) * (CB * CB) + e] = x;
+    }
 }
 
 // rows r0 + 64 * blockIdx.x ..: X = A[rows, jb..jb+64) inv(L11)^T
@@ -479,25 +483,27 @@ __global__ __launch_bounds__(256) void big_rhs_kernel(View v, int k, int m) { //
 
 // forward step jb: z[jb..jb+nb) = L_bb^{-1} y[jb..), then y[r] -= L[r, jb..] z[jb..] for the rows below.
 // Every workgroup solves the diagonal block itself (cheaper than another launch); workgroup 0 stores it.
-__global__ __launch_bounds__(256) void big_fwd_step_kernel(const double *__restrict__ L, int m, int jb, double *y,
-                                                           double *__restrict__ z) {
-    __shared__ double Ld[SB][SB + 1];
-    __shared__ double yb[SB];
+__global__ __launch_bounds__(256) void big_fwd_step_kernel(const double *__restrict__ L, const double *__restrict__ linv,
+                                                           int m, int jb, double *y, double *__restrict__ z) {
+    // the diagonal block's inverse was stored at factorisation (row-major [row][k]): the block solve is a
+    // 64 x 64 product by all four waves instead of 64 dependent substitution steps
+    __shared__ double Li[SB][SB + 1];
+    __shared__ double yin[SB], yb[SB];
     __shared__ double part[4][SB];
     const int tid = threadIdx.x, nb = min(SB, m - jb);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? L[pk(jb + r, jb + c, m)] : 0.0;
-    }
-    if (tid < nb) yb[tid] = y[jb + tid];
+    const double *lb = linv + static_cast<int64_t>(jb / SB) * (SB * SB);
+    for (int e = tid; e < SB * SB; e += 256) Li[e >> 6][e & (SB - 1)] = lb[e];
+    if (tid < SB) yin[tid] = tid < nb ? y[jb + tid] : 0.0;
     __syncthreads();
-    if (tid < 64) {
-        for (int c = 0; c < nb; ++c) {
-            if (tid == c) yb[c] = yb[c] / Ld[c][c];
-            __builtin_amdgcn_wave_barrier();
-            if (tid > c && tid < nb) yb[tid] -= Ld[tid][c] * yb[c];
-            __builtin_amdgcn_wave_barrier();
-        }
+    {
+        const int r = tid & (SB - 1), q4 = tid >> 6;
+        double s = 0.0;
+        for (int k = q4; k <= r; k += 4) s += Li[r][k] * yin[k];
+        part[q4][r] = s;
+    }
+    __syncthreads();
+    if (tid < SB) {
+        yb[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         if (blockIdx.x == 0 && tid < nb) z[jb + tid] = yb[tid];
     }
     __syncthreads();
@@ -515,24 +521,25 @@ __global__ __launch_bounds__(256) void big_fwd_step_kernel(const double *__restr
 }
 
 // backward step jb: g[jb..jb+nb) = L_bb^{-T} z[jb..), then z[c] -= L[jb.., c]^T g[jb..) for the columns before.
-__global__ __launch_bounds__(256) void big_bwd_step_kernel(const double *__restrict__ L, int m, int jb, double *z,
-                                                           double *__restrict__ g) {
-    __shared__ double Ld[SB][SB + 1];
-    __shared__ double yb[SB];
+__global__ __launch_bounds__(256) void big_bwd_step_kernel(const double *__restrict__ L, const double *__restrict__ linv,
+                                                           int m, int jb, double *z, double *__restrict__ g) {
+    __shared__ double Li[SB][SB + 1];
+    __shared__ double zin[SB], yb[SB];
+    __shared__ double part[4][SB];
     const int tid = threadIdx.x, nb = min(SB, m - jb);
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int r = e % nb, c = e / nb;
-        Ld[r][c] = r >= c ? L[pk(jb + r, jb + c, m)] : 0.0;
-    }
-    if (tid < nb) yb[tid] = z[jb + tid];
+    const double *lb = linv + static_cast<int64_t>(jb / SB) * (SB * SB);
+    for (int e = tid; e < SB * SB; e += 256) Li[e >> 6][e & (SB - 1)] = lb[e];
+    if (tid < SB) zin[tid] = tid < nb ? z[jb + tid] : 0.0;
     __syncthreads();
-    if (tid < 64) {
-        for (int c = nb - 1; c >= 0; --c) {
-            if (tid == c) yb[c] = yb[c] / Ld[c][c];
-            __builtin_amdgcn_wave_barrier();
-            if (tid < c) yb[tid] -= Ld[c][tid] * yb[c];
-            __builtin_amdgcn_wave_barrier();
-        }
+    {
+        const int r = tid & (SB - 1), q4 = tid >> 6; // gamma[r] = sum_{k >= r} inv[k][r] z[k]
+        double s = 0.0;
+        for (int k = r + q4; k < SB; k += 4) s += Li[k][r] * zin[k];
+        part[q4][r] = s;
+    }
+    __syncthreads();
+    if (tid < SB) {
+        yb[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         if (blockIdx.x == 0 && tid < nb) g[jb + tid] = yb[tid];
     }
     __syncthreads();
@@ -613,12 +620,12 @@ void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
         auto tiles = [](int rows) { return static_cast<unsigned>((rows + 63) / 64); };
         for (int jb = 0; jb < m; jb += 2 * CB) {
             const int h1 = jb + CB, end = std::min(m, jb + 2 * CB); // second half [h1, end), trailing part from end
-            hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, jb, Linv, d_fail);
+            hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, jb, Linv, lv.d_linv, d_fail);
             if (h1 >= m) break;
             hipLaunchKernelGGL(big_panel_kernel, dim3(tiles(m - h1)), dim3(256), 0, s, A, m, jb, h1, Linv);
             // second half of the panel brought up to date with the first (K = 64)
             hipLaunchKernelGGL(big_syrk_kernel, dim3(tiles(m - h1), 1), dim3(256), 0, s, A, m, jb, CB, h1, h1, end);
-            hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, h1, Linv, d_fail);
+            hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, h1, Linv, lv.d_linv, d_fail);
             if (end >= m) break;
             hipLaunchKernelGGL(big_panel_kernel, dim3(tiles(m - end)), dim3(256), 0, s, A, m, h1, end, Linv);
             const unsigned t = tiles(m - end);
@@ -640,10 +647,10 @@ void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *
         if (k) hipLaunchKernelGGL(big_rhs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, v, k, m);
         for (int jb = 0; jb < m; jb += SB) {
             const int rest = m - jb - std::min(SB, m - jb);
-            hipLaunchKernelGGL(big_fwd_step_kernel, dim3(std::max(1, (rest + 63) / 64)), dim3(256), 0, s, L, m, jb, y, z);
+            hipLaunchKernelGGL(big_fwd_step_kernel, dim3(std::max(1, (rest + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, y, z);
         }
         for (int jb = ((m - 1) / SB) * SB; jb >= 0; jb -= SB)
-            hipLaunchKernelGGL(big_bwd_step_kernel, dim3(std::max(1, (jb + 63) / 64)), dim3(256), 0, s, L, m, jb, z, g);
+            hipLaunchKernelGGL(big_bwd_step_kernel, dim3(std::max(1, (jb + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, z, g);
         if (k) hipLaunchKernelGGL(big_special_kernel, dim3(k), dim3(256), 0, s, v, m, g);
         hipLaunchKernelGGL(big_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, n, k, g, d_out, all_points ? 1 : 0);
         return;

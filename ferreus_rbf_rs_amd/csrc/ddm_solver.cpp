@@ -326,6 +326,8 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     }
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_fac), static_cast<size_t>(std::max<int64_t>(lv->fac_off[nd], 1)) * sizeof(double)));
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_work), static_cast<size_t>(std::max<int64_t>(lv->n_entries, 1)) * (ddm_level_is_big(*lv) ? 3 : 1) * sizeof(double)));
+    if (ddm_level_is_big(*lv))
+        DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_linv), static_cast<size_t>((lv->max_m + 63) / 64) * 4096 * sizeof(double)));
     int *d_fail = nullptr; // one flag per domain
     DHIP(hipMalloc(reinterpret_cast<void **>(&d_fail), static_cast<size_t>(std::max<int64_t>(nd, 1)) * sizeof(int)));
     DHIP(hipMemsetAsync(d_fail, 0, static_cast<size_t>(std::max<int64_t>(nd, 1)) * sizeof(int), s));
@@ -383,6 +385,7 @@ void ddm_level_free(DdmLevelSolver *lv) {
     (void)hipFree(lv->d_fac);
     (void)hipFree(lv->d_work);
     (void)hipFree(lv->d_mode);
+    (void)hipFree(lv->d_linv);
     (void)hipFree(lv->d_tmp);
     *lv = DdmLevelSolver();
 }

@@ -45,6 +45,7 @@ struct DdmLevelSolver {
     int32_t *d_k = nullptr;
     uint8_t *d_internal = nullptr;
     double *d_q = nullptr, *d_t = nullptr, *d_g = nullptr, *d_fac = nullptr;
+    double *d_linv = nullptr;  // one large domain: inverses of the 64 x 64 diagonal blocks of the factor
     uint8_t *d_mode = nullptr; // per domain: 1 = fac holds the packed symmetric inverse (host fallback)
     double *d_tmp = nullptr;   // n_entries scratch for those domains
     int n_fallback = 0;
