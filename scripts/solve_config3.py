@@ -21,11 +21,16 @@ ap.add_argument("--leaf-threshold", type=int, default=1024)
 ap.add_argument("--precon-order", type=int, default=0,
                 help="interpolation order of a second tree that serves only the preconditioner's partial matvecs "
                      "(0: the reference's arrangement, one tree for both)")
+ap.add_argument("--clustered", action="store_true", help="points from a mixture of 12 Gaussian clusters instead of uniform")
 a = ap.parse_args()
 kid = {"LinearRbf": 0, "ThinPlateSplineRbf": 1, "CubicRbf": 2, "Spheroidal3Rbf": 3}[a.kernel]
 n = a.points
 rng = np.random.default_rng(42)
 pts = rng.random((n, 3))
+if a.clustered:
+    c = rng.random((12, 3)); sg = 0.01 + 0.08 * rng.random(12); which = rng.integers(0, 12, n)
+    pts = np.clip(c[which] + rng.normal(size=(n, 3)) * sg[which, None], 0.0, 0.999)
+    pts = np.unique(pts, axis=0); n = pts.shape[0]          # (clipping can duplicate points on the box faces)
 vals = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.5 * pts[:, 2] ** 2          # smooth test function
 t0 = time.time()
 tree = F.FmmTree(pts, a.order, F.KernelParams(F.KernelType(kid)), True, True)
