@@ -194,12 +194,24 @@ def main():
                 traffic = tj["per_launch_bytes"].get(dominant)
         except (OSError, ValueError, KeyError):
             pass
+        # MFMA-pipe utilisation of the same kernel from the committed counter passes (scripts/gpu_mfma_util.sh ->
+        # profiles/r01_mfma.json: derived metrics MfmaUtil, MfmaFlopsF64); null when no profile matches
+        mfma_util = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_mfma.json")) as f:
+                mj = json.load(f)
+            if (mj.get("points"), mj.get("kernel"), mj.get("order"), mj.get("nrhs")) == (N, args.kernel, args.order, K) \
+                    and world == 1:
+                mfma_util = mj["per_kernel"].get(dominant, {}).get("mfma_util_pct")
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {
             "kernel": dominant, "bound": kd["bound"], "achieved": achieved, "peak": kd["peak"],
             "unit": kd["unit"], "frac": (achieved / kd["peak"]) if achieved else None,
             "traffic": traffic,
             "avg_launch_ms": per_launch[dominant],
             "algorithmic_work_per_launch": kd["work"],
+            "mfma_util_pct": mfma_util,
         }
         compulsory_bytes = N * (16 * 3 + 16 * K) + 4 * C * n * 8 * K
         line = {
