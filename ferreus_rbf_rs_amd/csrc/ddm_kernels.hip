@@ -71,12 +71,31 @@ template <int KID> __global__ __launch_bounds__(256) void ddm_assemble_kernel(Ke
     const int k = v.k[dom], m = static_cast<int>(v.dom_off[dom + 1] - o) - k;
     const double *Q = v.q + v.q_off[dom], *T = v.t + v.q_off[dom], *G = v.g + v.q_off[dom];
     double *A = v.fac + v.fac_off[dom];
-    // blockIdx.y takes every gridDim.y-th column
-    for (int j = blockIdx.y; j < m; j += gridDim.y)
-        for (int i = j + threadIdx.x; i < m; i += 256) {
-            double s = phi<KID>(ks, v, o + k + i, o + k + j) + (i == j ? nugget : 0.0);
-            for (int a = 0; a < k; ++a) s += Q[a * m + i] * G[a * m + j] + T[a * m + i] * Q[a * m + j];
-            A[pk(i, j, m)] = s;
+    // blockIdx.y takes every gridDim.y-th group of four columns; a thread keeps its row's coordinates and its
+    // Q / T entries in registers across the four columns of a group
+    constexpr int KMAX = 10; // monomials up to degree 2 in 3-D
+    for (int jg = 4 * blockIdx.y; jg < m; jg += 4 * gridDim.y)
+        for (int i = jg + threadIdx.x; i < m; i += 256) {
+            const int64_t gi = o + k + i;
+            const double xi = v.x[gi], yi = v.y[gi], zi = v.z[gi];
+            double qi[KMAX], ti[KMAX];
+#pragma unroll
+            for (int a = 0; a < KMAX; ++a) {
+                qi[a] = a < k ? Q[a * m + i] : 0.0;
+                ti[a] = a < k ? T[a * m + i] : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int j = jg + c;
+                if (j >= m || i < j) continue;
+                const int64_t gj = o + k + j;
+                const double dx = xi - v.x[gj], dy = yi - v.y[gj], dz = zi - v.z[gj];
+                double s = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz) + (i == j ? nugget : 0.0);
+#pragma unroll
+                for (int a = 0; a < KMAX; ++a)
+                    if (a < k) s += qi[a] * G[a * m + j] + ti[a] * Q[a * m + j];
+                A[pk(i, j, m)] = s;
+            }
         }
 }
 
