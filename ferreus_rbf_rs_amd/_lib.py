@@ -59,6 +59,8 @@ SIGNATURES = {
     "bbfmm_fast_matrix_vector_product": (ctypes.c_int, [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p,
                                                         c_i64, c_f64, c_p]),
     "bbfmm_matvec_device": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_i64, c_i32]),
+    "bbfmm_target_subset_create": (ctypes.c_int, [c_p, c_p, c_i64, c_p]),
+    "bbfmm_matvec_subset_device": (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32]),
     "bbfmm_stream": (c_p, [c_p]),
     "bbfmm_set_partition": (ctypes.c_int, [c_p, c_i32, c_i32]),
     "bbfmm_partition_row_count": (c_i64, [c_p]),
@@ -79,6 +81,11 @@ SIGNATURES = {
     "bbfmm_debug_dense_m2m": (ctypes.c_int, [c_p, c_i32, c_p]),
     "bbfmm_debug_apply_m2l_tables_host": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_debug_get_coefficients": (ctypes.c_int, [c_p, ctypes.c_char, c_i32, c_p]),
+    "bbfmm_debug_morton_encode": (ctypes.c_uint64, [c_i32, c_p, ctypes.c_uint64]),
+    "bbfmm_debug_morton_decode": (None, [c_i32, ctypes.c_uint64, c_p, c_p]),
+    "bbfmm_debug_morton_neighbours": (c_i32, [c_i32, ctypes.c_uint64, c_p]),
+    "bbfmm_debug_direction_vectors": (c_i32, [c_i32, c_p]),
+    "bbfmm_debug_reference_vectors": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_givens_rotation": (None, [c_f64, c_f64, c_p, c_p, c_p]),
     "bbfmm_fgmres": (ctypes.c_int, [c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_i32, c_i32, c_i32, c_f64,
                                     c_p, c_p, c_p, c_p, c_p]),
@@ -103,7 +110,7 @@ SIGNATURES = {
     "bbfmm_schwarz_apply": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
     "bbfmm_schwarz_level_size": (c_i64, [c_p, c_i32]),
     "bbfmm_schwarz_level_points": (ctypes.c_int, [c_p, c_i32, c_p]),
-    "bbfmm_schwarz_debug_level_solve": (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i32]),
+    "bbfmm_schwarz_debug_level_solve": (ctypes.c_int, [c_p, c_i32, c_p, c_p, c_i64, c_i32]),
 }
 
 

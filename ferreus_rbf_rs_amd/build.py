@@ -5,6 +5,7 @@ with the repository snapshot.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -16,16 +17,25 @@ OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libferreus_bbfmm_hip.so")
 
 HOST_SOURCES = ["tree.cpp", "operators.cpp", "fmm_tree.cpp", "capi.cpp", "solver.cpp", "ddm.cpp", "ddm_solver.cpp", "schwarz.cpp"]
-HIP_SOURCES = ["device.hip", "ddm_kernels.hip", "targets.hip"]
+HIP_SOURCES = ["device.hip", "ddm_kernels.hip", "targets.hip", "schwarz_kernels.hip"]
 HEADERS = ["morton.hpp", "tree.hpp", "parallel.hpp", "kernels.hpp", "operators.hpp", "device.hpp",
-           "fmm_tree.hpp", "targets.hpp", "ddm.hpp", "ddm_solver.hpp", os.path.join(ROOT, "include", "ferreus_bbfmm_hip.h")]
+           "fmm_tree.hpp", "targets.hpp", "ddm.hpp", "ddm_solver.hpp", "schwarz_kernels.hpp", os.path.join(ROOT, "include", "ferreus_bbfmm_hip.h")]
 
 
-def _newer(target: str, deps: list[str]) -> bool:
-    if not os.path.exists(target):
+def _digest(paths: list[str], extra: str = "") -> str:
+    h = hashlib.sha256(extra.encode())
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode() + b"\0" + f.read())
+    return h.hexdigest()
+
+
+def _stale(target: str, stamp: str, digest: str) -> bool:
+    """Content-based (not mtime-based): a snapshot copied to another machine keeps its objects."""
+    if not os.path.exists(target) or not os.path.exists(stamp):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != digest
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -34,26 +44,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     common = ["-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
               "-Wall", "-Wno-unused-result"]
-    objs = []
+    objs, digests = [], []
     for src in HOST_SOURCES + HIP_SOURCES:
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ, src + ".o")
+        stamp = obj + ".sha256"
+        cmd = [hipcc] + common + ["--offload-arch=gfx950", "-c", path, "-o", obj]
+        digest = _digest([path] + hdrs, " ".join(cmd[1:-3]))
         objs.append(obj)
-        if force or _newer(obj, [path] + hdrs):
-            cmd = [hipcc] + common + ["--offload-arch=gfx950", "-c", path, "-o", obj]
-            if src.endswith(".cpp"):
-                # host translation units still see the HIP runtime API (hip_runtime.h)
-                cmd += ["-x", "hip"] if False else []
+        digests.append(digest)
+        if force or _stale(obj, stamp, digest):
             if verbose:
                 print(" ".join(cmd), flush=True)
-            if os.path.exists(obj):
-                os.remove(obj)  # never link a stale object after a failed compile
+            for f in (obj, stamp):
+                if os.path.exists(f):
+                    os.remove(f)  # never link a stale object after a failed compile
             subprocess.check_call(cmd)
-    if force or _newer(LIB, objs):
+            with open(stamp, "w") as f:
+                f.write(digest)
+    lib_digest = hashlib.sha256("".join(digests).encode()).hexdigest()
+    lib_stamp = os.path.join(OBJ, "lib.sha256")
+    if force or _stale(LIB, lib_stamp, lib_digest):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(lib_stamp, "w") as f:
+            f.write(lib_digest)
     return LIB
 
 

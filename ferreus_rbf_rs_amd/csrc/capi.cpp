@@ -6,6 +6,7 @@
 
 #include "ferreus_bbfmm_hip.h"
 #include "fmm_tree.hpp"
+#include "morton.hpp"
 
 struct bbfmm_handle {
     bbfmm::FmmTree tree;
@@ -145,6 +146,21 @@ int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t
 }
 
 void *bbfmm_stream(bbfmm_handle *h) { return h ? static_cast<void *>(h->tree.stream()) : nullptr; }
+
+int bbfmm_target_subset_create(bbfmm_handle *h, const int64_t *target_indices, int64_t n_target_indices,
+                               int32_t *subset_id) {
+    GUARD(h)
+    int id = 0;
+    const int rc = h->tree.register_subset(target_indices, n_target_indices, &id);
+    if (rc == BBFMM_OK && subset_id) *subset_id = id;
+    return rc;
+    END_GUARD(h)
+}
+
+int bbfmm_matvec_subset_device(bbfmm_handle *h, int32_t subset_id, const double *d_w, double *d_y, int32_t sync) {
+    GUARD(h) return h->tree.matvec_subset_device(subset_id, d_w, d_y, sync != 0);
+    END_GUARD(h)
+}
 
 int bbfmm_set_partition(bbfmm_handle *h, int32_t rank, int32_t world) {
     GUARD(h) return h->tree.set_partition(rank, world);
@@ -318,6 +334,34 @@ int bbfmm_debug_dense_m2m(const bbfmm_handle *h, int32_t child_index, double *ou
 int bbfmm_debug_apply_m2l_tables_host(const bbfmm_handle *h, const double *M, double *L) {
     if (!h || !M || !L) return BBFMM_BAD_ARGUMENT;
     return h->tree.debug_apply_m2l_tables_host(M, L);
+}
+
+uint64_t bbfmm_debug_morton_encode(int32_t d, const uint64_t *anchor, uint64_t level) {
+    if (d < 1 || d > 3 || !anchor) return 0;
+    return bbfmm::encode_morton_point(anchor, level, d);
+}
+void bbfmm_debug_morton_decode(int32_t d, uint64_t key, uint64_t *anchor_out, uint64_t *level_out) {
+    if (d < 1 || d > 3 || !anchor_out || !level_out) return;
+    bbfmm::decode_key(key, d, anchor_out, level_out);
+}
+int32_t bbfmm_debug_morton_neighbours(int32_t d, uint64_t key, uint64_t *keys_out) {
+    if (d < 1 || d > 3 || !keys_out) return -1;
+    return bbfmm::get_neighbours(key, d, keys_out);
+}
+int32_t bbfmm_debug_direction_vectors(int32_t d, int32_t *out) {
+    if (d < 1 || d > 3 || !out) return -1;
+    const int(*dirs)[3];
+    const int n = bbfmm::direction_vectors(d, &dirs);
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < d; ++a) out[i * d + a] = dirs[i][a];
+    return n;
+}
+int bbfmm_debug_reference_vectors(const bbfmm_handle *h, int32_t *out, int32_t *n_ref_out) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    const bbfmm::Operators &ops = h->tree.ops();
+    if (n_ref_out) *n_ref_out = ops.n_ref;
+    if (out) std::copy(ops.ref_vecs.begin(), ops.ref_vecs.end(), out);
+    return BBFMM_OK;
 }
 
 int bbfmm_debug_get_coefficients(bbfmm_handle *h, char which, int32_t k, double *out) {

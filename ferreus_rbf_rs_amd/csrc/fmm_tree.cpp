@@ -1642,11 +1642,25 @@ void FmmTree::free_downward_plan(DownwardPlan *dp) {
 // (8 sets, least recently used evicted).
 int FmmTree::subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out) {
     const int64_t N = tree_.n_points;
+    // hash of the index set: chunk hashes computed in parallel, combined in order
     uint64_t h = 1469598103934665603ull ^ static_cast<uint64_t>(n_idx);
-    for (int64_t j = 0; j < n_idx; ++j) h = (h ^ static_cast<uint64_t>(idx[j])) * 1099511628211ull;
+    {
+        constexpr int64_t kChunk = int64_t(1) << 16;
+        const int64_t nch = (n_idx + kChunk - 1) / kChunk;
+        std::vector<uint64_t> part(static_cast<size_t>(std::max<int64_t>(nch, 1)), 0);
+        parallel_for_chunks(n_idx, kChunk, [&](int64_t b, int64_t e) {
+            for (int64_t c = b; c < e; c += kChunk) { // (a single-threaded host gets one call for everything)
+                uint64_t hc = 1469598103934665603ull;
+                for (int64_t j = c; j < std::min(e, c + kChunk); ++j) hc = (hc ^ static_cast<uint64_t>(idx[j])) * 1099511628211ull;
+                part[static_cast<size_t>(c / kChunk)] = hc;
+            }
+        });
+        for (uint64_t hc : part) h = (h ^ hc) * 1099511628211ull;
+    }
     ++subset_clock_;
     for (auto &sp : subset_plans_)
-        if (sp->key == h && sp->n_idx == n_idx) {
+        if (sp->key == h && sp->n_idx == n_idx &&
+            (n_idx == 0 || std::memcmp(sp->idx.data(), idx, static_cast<size_t>(n_idx) * sizeof(int64_t)) == 0)) {
             sp->last_use = subset_clock_;
             *out = sp.get();
             return BBFMM_OK;
@@ -1663,8 +1677,18 @@ int FmmTree::subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out) {
     }
     std::unique_ptr<SubsetPlan> sp(new SubsetPlan());
     sp->key = h;
-    sp->n_idx = n_idx;
     sp->last_use = subset_clock_;
+    CHK(fill_subset_plan(idx, n_idx, sp.get()));
+    *out = sp.get();
+    subset_plans_.push_back(std::move(sp));
+    return BBFMM_OK;
+}
+
+// Sorted targets + restricted downward pass of one index set (rows validated by the caller).
+int FmmTree::fill_subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan *sp) {
+    const int64_t N = tree_.n_points;
+    sp->n_idx = n_idx;
+    sp->idx.assign(idx, idx + n_idx);
     const int64_t m = n_idx;
     std::vector<double> x(static_cast<size_t>(std::max<int64_t>(m, 1)) * d_); // select_mat_rows, rbf.rs:1359-1360
     for (int a = 0; a < d_; ++a)
@@ -1686,10 +1710,55 @@ int FmmTree::subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out) {
     if (rc != BBFMM_OK) {
         free_target_set(&sp->ts);
         free_downward_plan(&sp->dp);
-        return rc;
     }
-    *out = sp.get();
-    subset_plans_.push_back(std::move(sp));
+    return rc;
+}
+
+// A registered index set (bbfmm_target_subset_create): like a cached plan, but named by an id and kept for the
+// life of the handle -- the Schwarz sweep names its levels once and then calls by id, without passing (and
+// comparing) millions of indices per product.  id -1 = all rows in order.
+int FmmTree::register_subset(const int64_t *idx, int64_t n_idx, int *id_out) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (!idx || n_idx < 0 || !id_out) return fail(BBFMM_BAD_ARGUMENT, "bad target index array");
+    CHK(ensure_rhs_capacity(1));
+    if (is_identity_subset(idx, n_idx)) {
+        *id_out = -1;
+        return BBFMM_OK;
+    }
+    const int64_t N = tree_.n_points;
+    for (int64_t j = 0; j < n_idx; ++j)
+        if (idx[j] < 0 || idx[j] >= N) return fail(BBFMM_BAD_ARGUMENT, "target index out of range");
+    std::unique_ptr<SubsetPlan> sp(new SubsetPlan());
+    CHK(fill_subset_plan(idx, n_idx, sp.get()));
+    *id_out = static_cast<int>(registered_plans_.size());
+    registered_plans_.push_back(std::move(sp));
+    return BBFMM_OK;
+}
+
+// d_y[j] = sum_i phi(x_idx[j], x_i) d_w[i]: set_weights + evaluate at the registered rows
+// (IterativeSolver::matvec_partial, rbf.rs:119-133, without the nugget / polynomial terms), all on the device.
+int FmmTree::matvec_subset_device(int id, const double *d_w, double *d_y, bool sync) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    const int64_t N = tree_.n_points;
+    if (!d_w || !d_y) return fail(BBFMM_BAD_ARGUMENT, "bad device matvec arguments");
+    if (id == -1) return matvec_device(d_w, N, 1, d_y, N, sync);
+    if (id < 0 || id >= static_cast<int>(registered_plans_.size())) return fail(BBFMM_BAD_ARGUMENT, "unknown subset id");
+    SubsetPlan *sp = registered_plans_[static_cast<size_t>(id)].get();
+    CHK(ensure_rhs_capacity(1));
+    nrhs_ = 1;
+    phase_begin();
+    launch_gather_weights(d_w, N, 1, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_end(kPhGather);
+    CHK(upward(1));
+    CHK(downward(1, &sp->dp));
+    if (sp->n_idx > 0) {
+        CHK(leaf_pass(sp->ts, 1, false));
+        phase_begin();
+        launch_scatter_output(sp->ts.out.p, sp->n_idx, 1, sp->ts.perm.p, d_y, sp->n_idx, 0, stream_);
+        phase_end(kPhScatter);
+    }
+    HIPCHK(hipGetLastError());
+    if (sync) HIPCHK(hipStreamSynchronize(stream_));
     return BBFMM_OK;
 }
 

@@ -75,6 +75,7 @@ struct DownwardPlan {
 struct SubsetPlan { // cached target subset of bbfmm_fast_matrix_vector_product (rbf.rs:119-133)
     uint64_t key = 0;
     int64_t n_idx = 0;
+    std::vector<int64_t> idx; // the index set itself: a hash hit is confirmed by comparing it
     uint64_t last_use = 0;
     TargetSet ts;
     DownwardPlan dp;
@@ -102,6 +103,8 @@ class FmmTree {
                                    int64_t n_target_indices, const double *poly, int64_t ldp, double nugget,
                                    double *result);                                     // rbf.rs:1338-1379
     int matvec_device(const double *d_w, int64_t ldw, int k, double *d_out, int64_t ldo, bool sync);
+    int register_subset(const int64_t *idx, int64_t n_idx, int *id_out);
+    int matvec_subset_device(int id, const double *d_w, double *d_y, bool sync);
     int set_partition(int rank, int world);
 
     const HostTree &tree() const { return tree_; }
@@ -197,6 +200,8 @@ class FmmTree {
     int build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp);
     void free_downward_plan(DownwardPlan *dp);
     int subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out);
+    int fill_subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan *sp);
+    std::vector<std::unique_ptr<SubsetPlan>> registered_plans_; // bbfmm_target_subset_create: kept for the handle's life
 
     // ---- device state
     hipStream_t stream_ = nullptr, stream2_ = nullptr;

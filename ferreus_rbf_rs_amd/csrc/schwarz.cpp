@@ -2,8 +2,12 @@
 // C ABI: restricted additive Schwarz inside a level (local solves on the device, ddm_solver.hpp),
 // multiplicative between the levels with the coarse domain as smoother, two partial matvecs per fine
 // level through the BBFMM tree (IterativeSolver::precon, rbf.rs:140-155).  SURVEY.md 8(f)-1.
-// Vectors are host arrays (the FGMRES driver is a host driver); the residual of a level goes to the
-// device for the batched local solves and the correction comes back.
+// The FGMRES driver is a host driver, so an apply takes and returns host vectors -- but inside an apply
+// every vector stays in HBM: the residual goes up once, the running correction `sl`, the level
+// residuals, the partial products (bbfmm_matvec_subset_device), the local solves, the write-back and the
+// orthogonalisation against the polynomial basis all run on the tree's stream, and the correction comes
+// down once.  The first correction of a sweep skips its partial product: `sl` is still zero there and
+// K * 0 = 0 exactly (schwarz.rs:53-59 with sl = 0).
 #include "../../include/ferreus_bbfmm_hip.h"
 
 #include <algorithm>
@@ -20,6 +24,7 @@
 #include "ddm_solver.hpp"
 #include "device.hpp"
 #include "parallel.hpp"
+#include "schwarz_kernels.hpp"
 
 namespace {
 using namespace bbfmm;
@@ -35,146 +40,97 @@ struct Schwarz {
     std::vector<double> mono;  // N x basis column-major, the solver's global monomial matrix (rbf.rs:485-491)
     std::vector<double> ortho; // N x basis column-major, thin Q of mono (rbf.rs:493-495)
     std::vector<double> a_special; // coarse domain: k x n_coarse rows of A (domain.rs:352-355), row-major
-    std::vector<double> coarse_xyz; // coarse domain points (domain order), 3 x n_c
-    hipStream_t stream = nullptr;
-    double *d_in = nullptr, *d_out = nullptr;
-    // levels well under N points exchange only their own rows with the device: per level the point indices on
-    // the device, one pinned buffer [values in | coefficients out] and its device twin
-    std::vector<int32_t *> d_lidx;
-    double *h_comp = nullptr, *d_comp = nullptr;
-    int64_t comp_cap = 0;
-    std::vector<double> res, tmp, s1;
-    double t_matvec = 0, t_solve = 0, t_host = 0; // BBFMM_VERBOSE: seconds per apply
+    hipStream_t stream = nullptr;  // the tree's stream (not owned): products and level work stay in order
+    // device vectors of a sweep (N doubles each): incoming residual, running correction, level residual,
+    // local-solve output, partial product; the orthonormal polynomial basis; projection scratch
+    double *d_rg = nullptr, *d_sl = nullptr, *d_res = nullptr, *d_out = nullptr, *d_y = nullptr;
+    double *d_ortho = nullptr, *d_part = nullptr, *d_proj = nullptr;
+    double *d_small = nullptr;          // coarse tail: coefficients of the coarse entries + k residuals
+    double *h_pin = nullptr;            // pinned staging: N doubles (+ the coarse tail download)
+    int64_t small_cap = 0;
+    std::vector<int32_t *> d_lidx;      // per level: its rows on the device (nullptr: all rows in order)
+    std::vector<int32_t> subset_id;     // per level: registered target subset of the tree (-1: all rows)
+    double t_matvec = 0, t_solve = 0, t_host = 0; // BBFMM_VERBOSE: seconds per apply (stream synchronised per stage)
     std::vector<double> t_level, t_level_mv;      // per level: local solves, partial matvecs
+    bool verbose = false;
     ~Schwarz() {
         for (auto &lv : levels) ddm_level_free(&lv);
-        if (d_in) (void)hipFree(d_in);
-        if (d_out) (void)hipFree(d_out);
+        for (double *p : {d_rg, d_sl, d_res, d_out, d_y, d_ortho, d_part, d_proj, d_small})
+            if (p) (void)hipFree(p);
         for (int32_t *p : d_lidx)
             if (p) (void)hipFree(p);
-        if (d_comp) (void)hipFree(d_comp);
-        if (h_comp) (void)hipHostFree(h_comp);
-        if (stream) (void)hipStreamDestroy(stream);
+        if (h_pin) (void)hipHostFree(h_pin);
     }
 };
 
-int partial_matvec(Schwarz &S, const double *w, const std::vector<int64_t> &idx, double *y) {
-    return bbfmm_fast_matrix_vector_product(S.tree, w, S.n + S.basis, S.basis, idx.data(),
-                                            static_cast<int64_t>(idx.size()), S.basis ? S.mono.data() : nullptr,
-                                            S.n, S.nugget, y);
-}
+#define HIPOK(expr)                                      \
+    do {                                                 \
+        if ((expr) != hipSuccess) return BBFMM_DEVICE_ERROR; \
+    } while (0)
 
-// res = rg - matvec(sl, rows idx); then the level's local solves into s1 (zero elsewhere)
-int level_correction(Schwarz &S, size_t li, const double *rg, const double *sl, bool coarse, bool add_poly) {
-    const int64_t nt = S.n + S.basis;
+// One level of the sweep on the device vectors: d_sl += solve(d_rg - K d_sl | level rows).  have_sl = false:
+// d_sl is known to be zero, the product is skipped.  The coarse domain's polynomial tail (k values) is
+// returned through tail when asked for.
+int level_step(Schwarz &S, size_t li, bool have_sl, bool coarse, bool add_poly, std::vector<double> *tail) {
     const DdmLevel &L = S.ddm.levels[li];
-    int rc = BBFMM_OK;
-    auto now = [] { return std::chrono::steady_clock::now(); };
+    const DdmLevelSolver &lv = S.levels[li];
+    const int64_t nl = static_cast<int64_t>(L.point_indices.size());
+    const int32_t *rows = S.d_lidx[li];
+    auto now = [&] {
+        if (S.verbose) (void)hipStreamSynchronize(S.stream);
+        return std::chrono::steady_clock::now();
+    };
     auto secs = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
         return std::chrono::duration<double>(b - a).count();
     };
     auto t0 = now();
-    if (sl) {
-        rc = partial_matvec(S, sl, L.point_indices, S.tmp.data());
+    const double *src = S.d_rg;
+    if (have_sl) { // rg - matvec_partial(sl, level rows)  (schwarz.rs:53-59, 63-67)
+        const int rc = bbfmm_matvec_subset_device(S.tree, S.subset_id[li], S.d_sl, S.d_y, 0);
         if (rc) return rc;
-        S.t_matvec += secs(t0, now());
-        if (S.t_level_mv.size() < S.levels.size()) S.t_level_mv.resize(S.levels.size(), 0.0);
-        S.t_level_mv[li] += secs(t0, now());
+        launch_schwarz_residual(S.d_rg, S.d_y, S.d_sl, S.nugget, rows, nl, S.d_res, S.stream);
+        src = S.d_res;
+        if (S.verbose) {
+            const double dt = secs(t0, now());
+            S.t_matvec += dt;
+            S.t_level_mv[li] += dt;
+            t0 = now();
+        }
+    }
+    int rc = ddm_level_solve(lv, src, S.d_out, coarse, S.stream);
+    if (rc) return rc;
+    if (!coarse) { // solve_fine_level, schwarz.rs:84-126: internal points written back, then orthogonalised
+        if (S.basis)
+            launch_schwarz_project(S.d_ortho, S.n, S.basis, S.d_out, rows, nl, S.d_part, kSchwarzProjectBlocks, S.d_proj,
+                                   S.stream);
+        launch_schwarz_add_rows(S.d_out, rows, nl, S.d_sl, S.stream);
+        if (S.basis) launch_schwarz_subtract_projection(S.d_ortho, S.n, S.basis, S.d_proj, S.d_sl, S.stream);
+    } else { // solve_coarse_level, schwarz.rs:134-155
+        launch_schwarz_add_rows(S.d_out, rows, nl, S.d_sl, S.stream);
+    }
+    HIPOK(hipGetLastError());
+    if (S.verbose) {
+        const double dt = secs(t0, now());
+        S.t_solve += dt;
+        S.t_level[li] += dt;
         t0 = now();
     }
-    const int64_t nl = static_cast<int64_t>(L.point_indices.size());
-    const bool compact = li < S.d_lidx.size() && S.d_lidx[li] != nullptr;
-    if (compact) {
-        // only the level's rows matter to its domains (they read nothing else, and every row of the level is
-        // internal to exactly one domain): residual on those rows, up, solve, coefficients of those rows back
-        const int64_t *idx = L.point_indices.data();
-        parallel_for_chunks(nl, 1 << 15, [&](int64_t b, int64_t e) {
-            for (int64_t j = b; j < e; ++j) {
-                const double v = sl ? rg[idx[j]] - S.tmp[idx[j]] : rg[idx[j]];
-                S.h_comp[j] = v;
-                S.res[idx[j]] = v; // (the coarse domain's polynomial recovery reads its special points here)
-            }
-        });
-        if (hipMemcpyAsync(S.d_comp, S.h_comp, static_cast<size_t>(nl) * sizeof(double), hipMemcpyHostToDevice, S.stream) != hipSuccess)
-            return BBFMM_DEVICE_ERROR;
-        launch_scatter_output(S.d_comp, nl, 1, S.d_lidx[li], S.d_in, S.n, 0, S.stream);
-        rc = ddm_level_solve(S.levels[li], S.d_in, S.d_out, coarse, S.stream);
-        if (rc) return rc;
-        launch_gather_rows(S.d_out, S.n, 1, S.d_lidx[li], nl, S.d_comp + S.comp_cap, nl, S.stream);
-        if (hipMemcpyAsync(S.h_comp + S.comp_cap, S.d_comp + S.comp_cap, static_cast<size_t>(nl) * sizeof(double),
-                           hipMemcpyDeviceToHost, S.stream) != hipSuccess)
-            return BBFMM_DEVICE_ERROR;
-        parallel_for_chunks(nt, 1 << 18, [&](int64_t b, int64_t e) { // (beside the device work)
-            std::memset(S.s1.data() + b, 0, static_cast<size_t>(e - b) * sizeof(double));
-        });
-        if (hipStreamSynchronize(S.stream) != hipSuccess) return BBFMM_DEVICE_ERROR;
-        parallel_for_chunks(nl, 1 << 15, [&](int64_t b, int64_t e) {
-            for (int64_t j = b; j < e; ++j) S.s1[idx[j]] = S.h_comp[S.comp_cap + j];
-        });
-    } else {
-        if (sl) {
-            parallel_for_chunks(nt, 1 << 16, [&](int64_t b, int64_t e) {
-                for (int64_t i = b; i < e; ++i) S.res[i] = rg[i] - S.tmp[i];
-            });
-        } else { // debug entry: solve the level for rg itself
-            std::copy(rg, rg + nt, S.res.begin());
-        }
-        if (hipMemcpyAsync(S.d_in, S.res.data(), static_cast<size_t>(S.n) * sizeof(double), hipMemcpyHostToDevice, S.stream) != hipSuccess ||
-            hipMemsetAsync(S.d_out, 0, static_cast<size_t>(S.n) * sizeof(double), S.stream) != hipSuccess)
-            return BBFMM_DEVICE_ERROR;
-        rc = ddm_level_solve(S.levels[li], S.d_in, S.d_out, coarse, S.stream);
-        if (rc) return rc;
-        if (hipMemcpyAsync(S.s1.data(), S.d_out, static_cast<size_t>(S.n) * sizeof(double), hipMemcpyDeviceToHost, S.stream) != hipSuccess ||
-            hipStreamSynchronize(S.stream) != hipSuccess)
-            return BBFMM_DEVICE_ERROR;
-        for (int64_t i = S.n; i < nt; ++i) S.s1[i] = 0.0;
-    }
-    S.t_solve += secs(t0, now());
-    if (S.t_level.size() < S.levels.size()) S.t_level.resize(S.levels.size(), 0.0);
-    S.t_level[li] += secs(t0, now());
-    t0 = now();
-    struct HostTime { // the rest of this function is host work
-        Schwarz &s;
-        std::chrono::steady_clock::time_point t;
-        ~HostTime() { s.t_host += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); }
-    } host_time{S, t0};
-    if (!coarse) {
-        if (S.basis) { // orthogonalise against the global polynomial basis (schwarz.rs:113-126)
-            std::vector<double> proj(static_cast<size_t>(S.basis), 0.0);
-            constexpr int64_t kChunkP = 1 << 16; // fixed chunks, partial sums combined in order: deterministic
-            const int64_t nch = (S.n + kChunkP - 1) / kChunkP;
-            std::vector<double> part(static_cast<size_t>(nch) * S.basis, 0.0);
-            parallel_for_chunks(S.n, kChunkP, [&](int64_t lo, int64_t hi) {
-                for (int b = 0; b < S.basis; ++b) {
-                    double s = 0.0;
-                    const double *q = &S.ortho[static_cast<size_t>(b) * S.n];
-                    for (int64_t i = lo; i < hi; ++i) s += q[i] * S.s1[i];
-                    part[static_cast<size_t>(lo / kChunkP) * S.basis + b] = s;
-                }
-            });
-            for (int64_t c = 0; c < nch; ++c)
-                for (int b = 0; b < S.basis; ++b) proj[b] += part[static_cast<size_t>(c) * S.basis + b];
-            parallel_for_chunks(S.n, 1 << 16, [&](int64_t bb, int64_t e) {
-                for (int64_t i = bb; i < e; ++i) {
-                    double s = 0.0;
-                    for (int b = 0; b < S.basis; ++b) s += S.ortho[static_cast<size_t>(b) * S.n + i] * proj[b];
-                    S.s1[i] -= s;
-                }
-            });
-        }
-        return BBFMM_OK;
-    }
-    // coarse domain: polynomial 'tail' (schwarz.rs:145-151, domain.rs:452-472)
-    const DdmLevelSolver &lv = S.levels[li];
-    if (lv.solve_for_poly && add_poly && S.basis) {
+    if (coarse && lv.solve_for_poly && add_poly && S.basis && tail) {
+        // polynomial 'tail' (schwarz.rs:145-151, domain.rs:452-472): k x k system on the special points
         const DomainPrep &pp = lv.prep[0];
         const int k = pp.k;
         const int64_t nc = static_cast<int64_t>(lv.gidx_h.size());
+        launch_gather_rows64(S.d_out, lv.d_gidx, nc, S.d_small, S.stream);
+        launch_gather_rows64(src, lv.d_gidx, k, S.d_small + nc, S.stream);
+        double *h = S.h_pin + S.n;
+        HIPOK(hipMemcpyAsync(h, S.d_small, static_cast<size_t>(nc + k) * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+        HIPOK(hipStreamSynchronize(S.stream));
+        const auto th = std::chrono::steady_clock::now();
         std::vector<double> r(static_cast<size_t>(k));
         for (int a = 0; a < k; ++a) {
-            double s = S.res[lv.gidx_h[a]];
+            double s = h[nc + a];
             const double *row = &S.a_special[static_cast<size_t>(a) * nc];
-            for (int64_t j = 0; j < nc; ++j) s -= row[j] * S.s1[lv.gidx_h[j]];
+            for (int64_t j = 0; j < nc; ++j) s -= row[j] * h[j];
             r[a] = s;
         }
         // solve sp_mono * poly = r (k x k, partial pivoting)
@@ -194,13 +150,36 @@ int level_correction(Schwarz &S, size_t li, const double *rg, const double *sl, 
             }
         }
         for (int c = k - 1; c >= 0; --c) {
-            double s = x[c];
-            for (int q = c + 1; q < k; ++q) s -= a[static_cast<size_t>(c) * k + q] * x[q];
-            x[c] = s / a[static_cast<size_t>(c) * k + c];
+            double sacc = x[c];
+            for (int q = c + 1; q < k; ++q) sacc -= a[static_cast<size_t>(c) * k + q] * x[q];
+            x[c] = sacc / a[static_cast<size_t>(c) * k + c];
         }
-        // sc.subrows_mut(idx_offset, num_poly) <- poly coefficients (schwarz.rs:146-151)
-        for (int a2 = 0; a2 < k; ++a2) S.s1[nt - k + a2] = x[a2];
+        tail->assign(x.begin(), x.end()); // sc.subrows_mut(idx_offset, num_poly) <- poly coefficients (schwarz.rs:146-151)
+        S.t_host += std::chrono::duration<double>(std::chrono::steady_clock::now() - th).count();
     }
+    return BBFMM_OK;
+}
+
+int upload_residual(Schwarz &S, const double *rg) {
+    parallel_for_chunks(S.n, int64_t(1) << 18, [&](int64_t b, int64_t e) {
+        std::memcpy(S.h_pin + b, rg + b, static_cast<size_t>(e - b) * sizeof(double));
+    });
+    HIPOK(hipMemcpyAsync(S.d_rg, S.h_pin, static_cast<size_t>(S.n) * sizeof(double), hipMemcpyHostToDevice, S.stream));
+    HIPOK(hipMemsetAsync(S.d_sl, 0, static_cast<size_t>(S.n) * sizeof(double), S.stream));
+    return BBFMM_OK;
+}
+
+// d_sl -> out[0 .. N), tail -> the last `basis` rows (zero when no tail was produced)
+int download_correction(Schwarz &S, const std::vector<double> &tail, double *out) {
+    // (the staging buffer is free again: the upload was consumed before the first kernel of the sweep ran)
+    HIPOK(hipMemcpyAsync(S.h_pin, S.d_sl, static_cast<size_t>(S.n) * sizeof(double), hipMemcpyDeviceToHost, S.stream));
+    HIPOK(hipStreamSynchronize(S.stream));
+    parallel_for_chunks(S.n, int64_t(1) << 18, [&](int64_t b, int64_t e) {
+        std::memcpy(out + b, S.h_pin + b, static_cast<size_t>(e - b) * sizeof(double));
+    });
+    for (int b = 0; b < S.basis; ++b) out[S.n + b] = 0.0;
+    const int64_t nt = S.n + S.basis;
+    for (size_t a = 0; a < tail.size(); ++a) out[nt - static_cast<int64_t>(tail.size()) + static_cast<int64_t>(a)] = tail[a];
     return BBFMM_OK;
 }
 
@@ -210,19 +189,9 @@ struct bbfmm_schwarz {
     Schwarz s;
 };
 
-extern "C" {
-
-int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
-                         const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, bbfmm_schwarz **out) {
-    if (!out) return BBFMM_BAD_ARGUMENT;
-    *out = nullptr;
-    if (!tree || !points || !settings || n < 1 || d < 1 || d > 3 || ld < n) return BBFMM_BAD_ARGUMENT;
-    if (settings->kernel_type < 0 || settings->kernel_type > 6 || settings->polynomial_degree < -1 ||
-        settings->polynomial_degree > 2)
-        return BBFMM_BAD_ARGUMENT;
-    std::unique_ptr<bbfmm_schwarz> h(new (std::nothrow) bbfmm_schwarz());
-    if (!h) return BBFMM_DEVICE_ERROR;
-    Schwarz &S = h->s;
+namespace {
+int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
+                        const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, Schwarz &S) {
     S.tree = tree;
     S.n = n;
     S.d = d;
@@ -249,7 +218,8 @@ int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, in
     int rc = build_ddm_tree(points, n, d, ld, p, &S.ddm);
     if (rc) return rc;
     lap("domain decomposition", -1);
-    if (hipStreamCreate(&S.stream) != hipSuccess) return BBFMM_DEVICE_ERROR;
+    S.stream = static_cast<hipStream_t>(bbfmm_stream(tree));
+    if (!S.stream) return BBFMM_DEVICE_ERROR;
     // global monomial matrix on the cube-scaled points and its thin Q (rbf.rs:418-421, 476-495)
     double gscale[6] = {0, 0, 0, 1, 1, 1}; // translation, scale of the global monomial basis
     if (S.basis) {
@@ -325,34 +295,66 @@ int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, in
                 S.a_special[static_cast<size_t>(a) * nc + j] = kernel_value_r2_rt(S.ks, r2) + (a == j ? S.nugget : 0.0);
             }
     }
-    if (hipMalloc(reinterpret_cast<void **>(&S.d_in), static_cast<size_t>(n) * sizeof(double)) != hipSuccess ||
-        hipMalloc(reinterpret_cast<void **>(&S.d_out), static_cast<size_t>(n) * sizeof(double)) != hipSuccess)
-        return BBFMM_DEVICE_ERROR;
-    S.res.assign(static_cast<size_t>(n + S.basis), 0.0);
-    S.tmp.assign(static_cast<size_t>(n + S.basis), 0.0);
-    S.s1.assign(static_cast<size_t>(n + S.basis), 0.0);
+    // device vectors of the sweep, the polynomial basis, staging
+    const size_t nb = static_cast<size_t>(n) * sizeof(double);
+    for (double **pp : {&S.d_rg, &S.d_sl, &S.d_res, &S.d_out, &S.d_y}) HIPOK(hipMalloc(reinterpret_cast<void **>(pp), nb));
+    HIPOK(hipMemsetAsync(S.d_out, 0, nb, S.stream));
+    S.small_cap = static_cast<int64_t>(S.levels.back().gidx_h.size()) + 16;
+    HIPOK(hipMalloc(reinterpret_cast<void **>(&S.d_small), static_cast<size_t>(S.small_cap) * sizeof(double)));
+    HIPOK(hipHostMalloc(reinterpret_cast<void **>(&S.h_pin), static_cast<size_t>(n + S.small_cap) * sizeof(double), hipHostMallocDefault));
+    if (S.basis) {
+        HIPOK(hipMalloc(reinterpret_cast<void **>(&S.d_ortho), nb * static_cast<size_t>(S.basis)));
+        HIPOK(hipMemcpy(S.d_ortho, S.ortho.data(), nb * static_cast<size_t>(S.basis), hipMemcpyHostToDevice));
+        HIPOK(hipMalloc(reinterpret_cast<void **>(&S.d_part), static_cast<size_t>(kSchwarzProjectBlocks) * S.basis * sizeof(double)));
+        HIPOK(hipMalloc(reinterpret_cast<void **>(&S.d_proj), 16 * sizeof(double)));
+    }
+    // the levels' rows: registered with the tree once (sorted targets + restricted downward pass belong to the
+    // setup, not to the first apply) and resident on the device for the vector kernels
     S.d_lidx.assign(S.ddm.levels.size(), nullptr);
+    S.subset_id.assign(S.ddm.levels.size(), -1);
     for (size_t li = 0; li < S.ddm.levels.size(); ++li) {
         const auto &pi = S.ddm.levels[li].point_indices;
-        if (static_cast<int64_t>(pi.size()) * 2 >= n || pi.empty()) continue; // (the finest level moves whole vectors)
-        std::vector<int32_t> idx32(pi.begin(), pi.end());
-        if (hipMalloc(reinterpret_cast<void **>(&S.d_lidx[li]), idx32.size() * sizeof(int32_t)) != hipSuccess ||
-            hipMemcpy(S.d_lidx[li], idx32.data(), idx32.size() * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess)
-            return BBFMM_DEVICE_ERROR;
-        S.comp_cap = std::max<int64_t>(S.comp_cap, static_cast<int64_t>(pi.size()));
-    }
-    if (S.comp_cap > 0 &&
-        (hipHostMalloc(reinterpret_cast<void **>(&S.h_comp), static_cast<size_t>(2 * S.comp_cap) * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-         hipMalloc(reinterpret_cast<void **>(&S.d_comp), static_cast<size_t>(2 * S.comp_cap) * sizeof(double)) != hipSuccess))
-        return BBFMM_DEVICE_ERROR;
-    // the target-subset plans of the levels' partial matvecs belong to the setup, not to the first apply
-    for (const DdmLevel &L : S.ddm.levels) {
-        rc = bbfmm_prepare_target_subset(tree, L.point_indices.data(), static_cast<int64_t>(L.point_indices.size()));
+        int32_t id = -1;
+        rc = bbfmm_target_subset_create(tree, pi.data(), static_cast<int64_t>(pi.size()), &id);
         if (rc) return rc;
+        S.subset_id[li] = id;
+        if (id == -1) continue; // all rows in order
+        std::vector<int32_t> idx32(pi.begin(), pi.end());
+        HIPOK(hipMalloc(reinterpret_cast<void **>(&S.d_lidx[li]), std::max<size_t>(idx32.size(), 1) * sizeof(int32_t)));
+        HIPOK(hipMemcpy(S.d_lidx[li], idx32.data(), idx32.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    S.t_level.assign(S.levels.size(), 0.0);
+    S.t_level_mv.assign(S.levels.size(), 0.0);
+    S.verbose = verbose;
     lap("target-subset plans", -1);
+    return BBFMM_OK;
+}
+} // namespace
+
+// Nothing may unwind through the C ABI (the N-sized host vectors can throw std::bad_alloc / length_error).
+#define SCHWARZ_GUARD try {
+#define SCHWARZ_END_GUARD                                   \
+    }                                                       \
+    catch (const std::bad_alloc &) { return BBFMM_DEVICE_ERROR; } \
+    catch (...) { return BBFMM_BAD_ARGUMENT; }
+
+extern "C" {
+
+int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
+                         const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, bbfmm_schwarz **out) {
+    if (!out) return BBFMM_BAD_ARGUMENT;
+    *out = nullptr;
+    if (!tree || !points || !settings || n < 1 || d < 1 || d > 3 || ld < n) return BBFMM_BAD_ARGUMENT;
+    if (settings->kernel_type < 0 || settings->kernel_type > 6 || settings->polynomial_degree < -1 ||
+        settings->polynomial_degree > 2)
+        return BBFMM_BAD_ARGUMENT;
+    SCHWARZ_GUARD
+    std::unique_ptr<bbfmm_schwarz> h(new bbfmm_schwarz());
+    const int rc = schwarz_create_impl(tree, points, n, d, ld, settings, params, h->s);
+    if (rc) return rc;
     *out = h.release();
     return BBFMM_OK;
+    SCHWARZ_END_GUARD
 }
 
 void bbfmm_schwarz_destroy(bbfmm_schwarz *h) { delete h; }
@@ -372,55 +374,58 @@ int bbfmm_schwarz_level_points(const bbfmm_schwarz *h, int32_t level, int64_t *o
     return BBFMM_OK;
 }
 // solve_fine_level / solve_coarse_level (schwarz.rs:84-155) of one level for a given residual
-int bbfmm_schwarz_debug_level_solve(bbfmm_schwarz *h, int32_t level, const double *residual, double *out,
+int bbfmm_schwarz_debug_level_solve(bbfmm_schwarz *h, int32_t level, const double *residual, double *out, int64_t n,
                                     int32_t add_poly) {
-    if (!h || !residual || !out || level < 0 || level >= static_cast<int32_t>(h->s.ddm.levels.size()))
+    if (!h || !residual || !out || level < 0 || level >= static_cast<int32_t>(h->s.ddm.levels.size()) ||
+        n != h->s.n + h->s.basis)
         return BBFMM_BAD_ARGUMENT;
+    SCHWARZ_GUARD
     Schwarz &S = h->s;
     const bool coarse = static_cast<size_t>(level) + 1 == S.ddm.levels.size();
-    const int rc = level_correction(S, static_cast<size_t>(level), residual, nullptr, coarse, add_poly != 0);
+    int rc = upload_residual(S, residual);
     if (rc) return rc;
-    std::copy(S.s1.begin(), S.s1.end(), out);
-    return BBFMM_OK;
+    std::vector<double> tail;
+    if ((rc = level_step(S, static_cast<size_t>(level), false, coarse, add_poly != 0, &tail))) return rc;
+    return download_correction(S, tail, out);
+    SCHWARZ_END_GUARD
 }
 
 // schwarz_preconditioner (schwarz.rs:32-82) as a bbfmm_apply_fn: user = bbfmm_schwarz*, n = N + basis
 int bbfmm_schwarz_apply(void *user, const double *rg, double *sl, int64_t n) {
     bbfmm_schwarz *h = static_cast<bbfmm_schwarz *>(user);
     if (!h || !rg || !sl || n != h->s.n + h->s.basis) return BBFMM_BAD_ARGUMENT;
+    SCHWARZ_GUARD
     Schwarz &S = h->s;
-    std::memset(sl, 0, static_cast<size_t>(n) * sizeof(double));
+    const auto t_begin = std::chrono::steady_clock::now();
+    int rc = upload_residual(S, rg);
+    if (rc) return rc;
     const size_t coarse = S.ddm.levels.size() - 1;
-    auto add = [&]() {
-        parallel_for_chunks(n, 1 << 16, [&](int64_t b, int64_t e) {
-            for (int64_t i = b; i < e; ++i) sl[i] += S.s1[i];
-        });
-    };
-    int rc;
+    std::vector<double> tail;
+    bool have_sl = false; // sl = 0 until the first correction has been added
     if (coarse > 0) {
         for (size_t i = 0; i < coarse; ++i) {
-            if ((rc = level_correction(S, i, rg, sl, false, false))) return rc;
-            add();
-            if ((rc = level_correction(S, coarse, rg, sl, true, i == coarse - 1))) return rc;
-            add();
+            if ((rc = level_step(S, i, have_sl, false, false, nullptr))) return rc;
+            have_sl = true;
+            if ((rc = level_step(S, coarse, true, true, i == coarse - 1, &tail))) return rc;
         }
     } else {
-        if ((rc = level_correction(S, coarse, rg, sl, true, true))) return rc;
-        add();
+        if ((rc = level_step(S, coarse, false, true, true, &tail))) return rc;
     }
-    if (std::getenv("BBFMM_VERBOSE")) {
-        std::fprintf(stderr, "[bbfmm] schwarz apply: partial matvecs %.3f s, level solves (incl. PCIe) %.3f s, host %.3f s\n",
-                     S.t_matvec, S.t_solve, S.t_host);
+    if ((rc = download_correction(S, tail, sl))) return rc;
+    if (S.verbose) {
+        std::fprintf(stderr, "[bbfmm] schwarz apply %.3f s: partial matvecs %.3f s, level solves %.3f s, host %.3f s\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), S.t_matvec, S.t_solve,
+                     S.t_host);
         for (size_t l = 0; l < S.t_level.size(); ++l) {
             std::fprintf(stderr, "[bbfmm]   level %zu: %lld domains, %lld entries, max m %d: solves %.3f s, matvecs %.3f s\n", l,
                          (long long)S.levels[l].n_dom, (long long)S.levels[l].n_entries, S.levels[l].max_m, S.t_level[l],
-                         l < S.t_level_mv.size() ? S.t_level_mv[l] : 0.0);
-            S.t_level[l] = 0;
-            if (l < S.t_level_mv.size()) S.t_level_mv[l] = 0;
+                         S.t_level_mv[l]);
+            S.t_level[l] = S.t_level_mv[l] = 0;
         }
         S.t_matvec = S.t_solve = S.t_host = 0;
     }
     return BBFMM_OK;
+    SCHWARZ_END_GUARD
 }
 
 } // extern "C"

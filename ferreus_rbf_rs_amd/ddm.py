@@ -156,7 +156,7 @@ class SchwarzPreconditioner:
         """solve_fine_level / solve_coarse_level (schwarz.rs:84-155) of one level"""
         r = np.ascontiguousarray(residual, dtype=np.float64).reshape(-1)
         z = np.zeros_like(r)
-        rc = self._lib.bbfmm_schwarz_debug_level_solve(self._h, level, r.ctypes.data, z.ctypes.data, int(add_poly))
+        rc = self._lib.bbfmm_schwarz_debug_level_solve(self._h, level, r.ctypes.data, z.ctypes.data, r.size, int(add_poly))
         if rc != L.OK:
             raise RuntimeError(f"bbfmm_schwarz_debug_level_solve failed with status {rc}")
         return z

@@ -3,8 +3,11 @@
 Every rank holds the whole tree and evaluates the potentials of the targets it owns (a
 contiguous Morton range of leaves, `FmmTree.set_partition`).  Owned rows are disjoint by
 construction, so one all-gather of the owned values (padded to the largest share) completes the
-matvec on every rank; with backend "nccl" this is RCCL over xGMI, with "gloo" the same code runs
-on CPU tensors (tests).
+matvec on every rank; with backend "nccl" this is RCCL over xGMI (`all_gather_into_tensor` on
+preallocated device buffers: one collective, one gather pass before it and one scatter pass after
+it per step).  With a "gloo" group the same bookkeeping runs on CPU tensors (tests), or -- for
+device tensors -- stages the owned values through pinned host buffers, which lets two ranks share
+one GPU (a functional check of the N > 1 path on a one-GPU box, never a scaling number).
 """
 from __future__ import annotations
 
@@ -20,24 +23,36 @@ class OwnedRowsExchange:
         self.world = dist.get_world_size(group)
         self.k = k
         self.n_total = n_total
-        rows_t = torch.as_tensor(rows, dtype=torch.int64, device=device)
-        self.rows = rows_t
-        counts = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(self.world)]
-        dist.all_gather(counts, torch.tensor([rows_t.numel()], dtype=torch.int64, device=device),
-                        group=group)
-        self.counts = [int(c.item()) for c in counts]
+        device = torch.device(device)
+        # collectives run where the backend can: gloo moves host memory
+        self.staged = device.type == "cuda" and dist.get_backend(group) == "gloo"
+        cdev = torch.device("cpu") if self.staged else device
+        rows_t = torch.as_tensor(rows, dtype=torch.int64, device=cdev)
+        counts = torch.zeros(self.world, dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(counts, torch.tensor([rows_t.numel()], dtype=torch.int64, device=cdev), group=group)
+        self.counts = [int(c) for c in counts.tolist()]
         self.m_max = max(max(self.counts), 1)
-        pad = torch.full((self.m_max,), -1, dtype=torch.int64, device=device)
+        pad = torch.full((self.m_max,), -1, dtype=torch.int64, device=cdev)
         pad[: rows_t.numel()] = rows_t
-        gathered = [torch.empty_like(pad) for _ in range(self.world)]
-        dist.all_gather(gathered, pad, group=group)
-        all_rows = torch.stack(gathered)                       # world x m_max
-        self.valid = all_rows.reshape(-1) >= 0
-        self.valid_idx = torch.nonzero(self.valid).reshape(-1)     # once: no mask (= no sync) per step
-        self.flat_rows = all_rows.reshape(-1)[self.valid_idx]
+        all_rows = torch.empty((self.world, self.m_max), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(all_rows.view(-1), pad, group=group)   # flat in, flat out: every backend takes it
+        valid = all_rows >= 0                                           # world x m_max
+        # flat element indices, once: recv is (world, k, m_max), out is (k, n_total)
+        rk = torch.arange(self.world, device=cdev)[:, None, None]
+        kk = torch.arange(k, device=cdev)[None, :, None]
+        mm = torch.arange(self.m_max, device=cdev)[None, None, :]
+        vmask = valid[:, None, :].expand(self.world, k, self.m_max)
+        src = ((rk * k + kk) * self.m_max + mm)[vmask]
+        dst = (kk * n_total + all_rows[:, None, :])[vmask]
+        self.flat_rows = all_rows[valid]
+        self.rows = rows_t.to(device)
+        self.src_idx = src.to(device)
+        self.dst_idx = dst.to(device)
         self.send = torch.zeros((k, self.m_max), dtype=torch.float64, device=device)
-        self.recv = [torch.empty((k, self.m_max), dtype=torch.float64, device=device)
-                     for _ in range(self.world)]
+        self.recv = torch.empty((self.world, k, self.m_max), dtype=torch.float64, device=device)
+        if self.staged:
+            self.h_send = torch.zeros((k, self.m_max), dtype=torch.float64).pin_memory()
+            self.h_recv = torch.empty((self.world, k, self.m_max), dtype=torch.float64).pin_memory()
 
     def check_partition(self) -> bool:
         """True when the owned rows of all ranks are a disjoint cover of 0..n_total-1."""
@@ -46,9 +61,15 @@ class OwnedRowsExchange:
             torch.equal(r, torch.arange(self.n_total, dtype=torch.int64, device=r.device)))
 
     def exchange(self, out: torch.Tensor) -> torch.Tensor:
-        """out: K x N with this rank's owned columns filled in; on return every column is."""
-        self.send[:, : self.rows.numel()] = out.index_select(1, self.rows)
-        dist.all_gather(self.recv, self.send, group=self.group)
-        stacked = torch.stack(self.recv, dim=1).reshape(self.k, -1)   # K x (world*m_max)
-        out.index_copy_(1, self.flat_rows, stacked.index_select(1, self.valid_idx))
+        """out: K x N (contiguous) with this rank's owned columns filled in; on return every column is."""
+        m = self.rows.numel()
+        if m:
+            self.send[:, :m].copy_(out.index_select(1, self.rows))
+        if self.staged:
+            self.h_send.copy_(self.send)                                 # device -> pinned host (synchronises)
+            dist.all_gather_into_tensor(self.h_recv.view(-1), self.h_send.view(-1), group=self.group)
+            self.recv.copy_(self.h_recv)
+        else:
+            dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
+        out.view(-1).index_copy_(0, self.dst_idx, self.recv.view(-1).index_select(0, self.src_idx))
         return out

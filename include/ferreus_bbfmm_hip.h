@@ -172,6 +172,18 @@ int bbfmm_prepare_target_subset(bbfmm_handle *h, const int64_t *target_indices, 
 int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_out,
                         int64_t ldo, int32_t sync);
 
+/* IterativeSolver::matvec_partial (rbf.rs:119-133) on device-resident vectors, for callers that keep
+ * their vectors in HBM between products (the Schwarz sweep, bbfmm_schwarz_apply).  An index set is
+ * registered once -- sorted targets and restricted downward pass are built then and kept for the life
+ * of the handle -- and named by the returned id afterwards (-1 is returned for "all rows in order").
+ *   d_y[j] = sum_i phi(x_target_indices[j], x_i) * d_w[i],   j < n_target_indices
+ * d_w: N values in the caller's point numbering, d_y: n_target_indices values (N for id -1), both DEVICE
+ * pointers.  The nugget and polynomial terms of rbf.rs:1366-1376 are the caller's (they are O(n)).
+ * Asynchronous on the handle's stream unless sync != 0. */
+int bbfmm_target_subset_create(bbfmm_handle *h, const int64_t *target_indices, int64_t n_target_indices,
+                               int32_t *subset_id);
+int bbfmm_matvec_subset_device(bbfmm_handle *h, int32_t subset_id, const double *d_w, double *d_y, int32_t sync);
+
 /* HIP stream the handle launches on (hipStream_t as void*), for event timing. */
 void *bbfmm_stream(bbfmm_handle *h);
 
@@ -250,6 +262,20 @@ int bbfmm_debug_dense_m2m(const bbfmm_handle *h, int32_t child_index, double *ou
  * BBFMM_FLAG_HOST_ONLY handles (the tables are released after upload otherwise). */
 int bbfmm_debug_apply_m2l_tables_host(const bbfmm_handle *h, const double *M, double *L);
 
+/* The Morton primitives of csrc/morton.hpp as the host tree build uses them (morton.rs:58-263; the
+ * reference's byte lookup tables, morton_constants.rs:77-346, are replaced by bit arithmetic): checked
+ * bit-exactly against the reference's own tables in tests/test_reference_tables.py.
+ *   encode: anchor[d] (16 bits per axis are read) + level -> key;   decode: key -> anchor[d], level
+ *   neighbours: same-level neighbour keys inside the root box, in the reference's direction order
+ *               (morton_constants.rs:32-74); keys_out holds up to 26, the count is returned
+ *   direction_vectors: out is n x d (row-major), n = 2 / 8 / 26 returned
+ *   reference_vectors: the handle's M2L reference vectors (chebyshev.rs:272-294), n_ref x d row-major */
+uint64_t bbfmm_debug_morton_encode(int32_t d, const uint64_t *anchor, uint64_t level);
+void bbfmm_debug_morton_decode(int32_t d, uint64_t key, uint64_t *anchor_out, uint64_t *level_out);
+int32_t bbfmm_debug_morton_neighbours(int32_t d, uint64_t key, uint64_t *keys_out);
+int32_t bbfmm_debug_direction_vectors(int32_t d, int32_t *out);
+int bbfmm_debug_reference_vectors(const bbfmm_handle *h, int32_t *out, int32_t *n_ref_out);
+
 /* Copies the device-resident multipole ('M') or local ('L') coefficients of the last pass to
  * the host as k x n_cells x n (rhs-major, cell-major), i.e. column c + j*n_cells of the
  * reference's n x (C*K) matrices (bbfmm.rs:234-242).  Per-phase parity checks. */
@@ -309,8 +335,8 @@ int bbfmm_rbf_system_apply(void *user, const double *x, double *y, int64_t n);
 /* ------------------------------------------------------------------ domain decomposition (host part)
  * DDMTree::new (ferreus_rbf/src/preconditioning/domain_decomposition.rs:67-347), SURVEY.md 8(f)-1:
  * the multi-level overlapping decomposition of the Schwarz preconditioner -- which points form which
- * leaf domain on which level.  The local factorisations (domain.rs) and the apply (schwarz.rs) are
- * not behind this ABI yet; the index sets are what they will run on. */
+ * leaf domain on which level.  The local factorisations (domain.rs) and the apply (schwarz.rs) on these
+ * index sets are the bbfmm_schwarz_* entry points further down. */
 typedef struct bbfmm_ddm bbfmm_ddm;
 typedef struct bbfmm_ddm_params { /* DDMParams, config.rs:42-69 */
     int64_t leaf_threshold;   /* 1024 */
@@ -369,9 +395,9 @@ const double *bbfmm_schwarz_monomial_matrix(const bbfmm_schwarz *h); /* N x basi
 int64_t bbfmm_schwarz_level_size(const bbfmm_schwarz *h, int32_t level);      /* Level::point_indices */
 int bbfmm_schwarz_level_points(const bbfmm_schwarz *h, int32_t level, int64_t *out);
 /* solve_fine_level / solve_coarse_level (schwarz.rs:84-155) of one level for a given residual
- * (N + basis_size values in, N + basis_size out); parity checks. */
+ * (n = N + basis_size values in, n out); parity checks. */
 int bbfmm_schwarz_debug_level_solve(bbfmm_schwarz *h, int32_t level, const double *residual, double *out,
-                                    int32_t add_poly);
+                                    int64_t n, int32_t add_poly);
 /* a bbfmm_apply_fn: user = bbfmm_schwarz*, vectors of N + basis_size doubles */
 int bbfmm_schwarz_apply(void *user, const double *residual, double *correction, int64_t n);
 

@@ -17,9 +17,7 @@ def pytest_configure(config):
 def _built():
     """Build the HIP library (cross-compiles without a GPU) and the oracle's C passes once."""
     from ferreus_rbf_rs_amd import build as b
-    lib = os.path.join(ROOT, "ferreus_rbf_rs_amd", "libferreus_bbfmm_hip.so")
-    if not os.path.exists(lib):      # the driver's build() normally did this already
-        b.build()
+    b.build()                        # mtime-aware: a no-op when the library is newer than every source
     from oracle import bbfmm_oracle as O
     O.build_passes()
     return True

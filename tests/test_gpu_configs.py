@@ -1,0 +1,237 @@
+"""BASELINE.json configs 2, 3 and 4 on a real MI355X ("configs not exercised by the driver-run
+-m gpu suite").
+
+  * config 4's code paths: more right-hand sides than one chunk of the direct kernels holds (nrhs = 5: one
+    full chunk + a partial one, nrhs = 8: the config itself) on a mixed-level tree, values, gradients,
+    leaves-only evaluation and the device-resident matvec, against the oracle at 1e-11 (reference loops over
+    the right-hand sides: bbfmm.rs:720,745,906,1031,1060,1184,1279,1402); the 10M x 8 size through
+    size-independent properties;
+  * config 3: 3-D thin-plate spline, order 9 (the solver's default for it), linear drift, FGMRES 20 x 5
+    with the Schwarz preconditioner (rbf.rs:536-554) against the dense restatement (oracle/ddm.py +
+    oracle/solvers.py) and a direct dense solve;
+  * config 2: 1M points, Spheroidal3 (reference-native) and the multiquadric extension, mixed-level tree:
+    linearity, symmetry and sampled dense rows.
+"""
+import numpy as np
+import pytest
+
+import ferreus_rbf_rs_amd as F
+from conftest import clustered_points, inject_product_operators, relerr
+from oracle import bbfmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+def _pair(pts, kid, order=7, br=1.0, sill=1.0, params=None, inject=True):
+    fp = None if params is None else F.FmmParams(*params)
+    op = None if params is None else O.FmmParams(*params)
+    t = F.FmmTree(pts, order, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill), True, True, params=fp)
+    r = O.FmmTree(pts, order, kid, True, True, None, op, base_range=br, total_sill=sill)
+    if inject:
+        inject_product_operators(t, r)
+    return t, r
+
+
+@pytest.mark.parametrize("nrhs,kid", [(5, 0), (8, 2)])
+def test_many_right_hand_sides_on_a_mixed_level_tree(nrhs, kid):
+    """DIRECT_KB / P2M_KB chunk loops with k0 > 0, the zero-filled partial chunk (nrhs = 5), M2L with more
+    than two rhs: every pass's output against the oracle."""
+    import torch
+    rng = np.random.default_rng(300 + nrhs)
+    n = 130000
+    pts = rng.random((n, 3))
+    t, r = _pair(pts, kid)
+    s = t.stats()
+    assert s.n_w > 0 and s.n_x == s.n_w                                        # W / X lists are live
+    w = rng.standard_normal((n, nrhs))
+    t.set_weights(w)
+    r.set_weights(w)
+    assert relerr(t.debug_get_coefficients("M", nrhs), r.M) < TOL              # P2M + M2M, all rhs
+    y, yr = t.evaluate(w, pts), r.evaluate(w, pts)
+    assert relerr(t.debug_get_coefficients("L", nrhs), r.L) < TOL              # M2L + P2L + L2L
+    assert relerr(y, yr) < TOL
+    for j in range(nrhs):                                                       # no rhs hides behind a bigger one
+        assert relerr(y[:, j], yr[:, j]) < TOL
+    # gradients (P2P / M2P / L2P gradient accumulators per rhs chunk)
+    tg = pts[rng.choice(n, 20000, replace=False)] + 1e-4 * rng.standard_normal((20000, 3))
+    tg = np.clip(tg, pts.min(0), pts.max(0))
+    yg, g = t.evaluate_with_gradients(w, tg)
+    ygr, gr = r.evaluate_with_gradients(w, tg)
+    assert g.shape == (20000, 3 * nrhs)
+    assert relerr(yg, ygr) < TOL and relerr(g, gr) < 1e-9
+    # leaves-only evaluation after set_local_coefficients
+    t.set_local_coefficients(w)
+    r.set_local_coefficients(w)
+    assert relerr(t.evaluate_leaves(w, tg), r.evaluate_leaves(w, tg)) < TOL
+    yl, gl = t.evaluate_leaves_with_gradients(w, tg[:5000])
+    ylr, glr = r.evaluate_leaves_with_gradients(w, tg[:5000])
+    assert relerr(yl, ylr) < TOL and relerr(gl, glr) < 1e-9
+    # device-resident matvec (what bench.py times), same weights
+    dw = torch.from_numpy(np.ascontiguousarray(w.T)).cuda()
+    out = torch.zeros((nrhs, n), dtype=torch.float64, device="cuda")
+    t.matvec_device(dw.data_ptr(), n, nrhs, out.data_ptr(), n, True)
+    assert relerr(out.cpu().numpy().T, yr) < TOL
+    # dense rows
+    idx = rng.choice(n, 200, replace=False)
+    yd = O.dense_sum(kid, 1.0, 1.0, pts[idx], pts, w)
+    assert relerr(y[idx], yd) < 1e-6
+
+
+def test_config3_tps_order9_linear_drift_fgmres_schwarz_end_to_end():
+    """3-D thin-plate spline, p = 9, linear drift: FGMRES(20 x 5) + Schwarz on the device against (1) the dense
+    restatement of the same solver + preconditioner and (2) a direct solve of the dense saddle system."""
+    from ferreus_rbf_rs_amd import solvers as S
+    from ferreus_rbf_rs_amd.ddm import DDMParams, InterpolantSettings, SchwarzPreconditioner
+    from oracle import ddm as D
+    from oracle import solvers as OS
+    rng = np.random.default_rng(333)
+    n, dim, kid, drift = 8000, 3, 1, 1
+    pts = rng.random((n, dim))
+    prm = (160, 0.5, 0.125, 600)
+    st = InterpolantSettings(kid, dim, drift=drift)
+    ost = D.InterpolantSettings(kid, dim, drift=drift)
+    assert st.basis_size == ost.basis_size == 4
+    tree = F.FmmTree(pts, 9, F.KernelParams(F.KernelType(kid)), True, True)
+    pre = SchwarzPreconditioner(tree, pts, st, DDMParams(*prm))
+    levels = D.build_ddm_tree(pts, ost, D.DDMParams(*prm))
+    assert pre.num_levels == len(levels) >= 3
+    for lv in range(len(levels)):
+        assert np.array_equal(pre.level_points(lv), np.asarray(levels[lv].point_indices))
+    # dense system of the restatement
+    A = D.a_matrix(pts, ost)
+    tr, sc = D.cheb_cube_scaling_factors(pts)
+    mono, ortho = D.orthonormal_poly(pts, ost, tr, sc)
+    np.testing.assert_allclose(pre.monomial_matrix, mono, rtol=0, atol=1e-14)
+    m = ost.basis_size
+
+    def dense_matvec(w):                                    # rbf.rs:1338-1379
+        y = np.zeros(n + m)
+        y[:n] = A @ w[:n] + mono @ w[n:]
+        return y
+
+    def dense_partial(w, idx):
+        y = np.zeros(n + m)
+        idx = np.asarray(idx)
+        y[idx] = A[idx] @ w[:n] + mono[idx] @ w[n:]
+        return y
+
+    op = S.RbfSystemOperator(tree, m, pre.monomial_matrix, 0.0)
+    wt = rng.standard_normal(n + m)
+    yd = dense_matvec(wt)
+    assert np.abs(op(wt) - yd).max() < 1e-7 * np.abs(yd).max()             # the operator (p = 9: ~1e-9)
+    # one application of the preconditioner against the restatement on the dense partial products
+    r0 = rng.standard_normal(n + m)
+    r0[n:] = 0.0
+    z, zo = pre(r0), D.schwarz_preconditioner(r0, levels, dense_partial, ost, ortho)
+    assert np.abs(z - zo).max() < 2e-5 * np.abs(zo).max()
+    # the solve, as the solver calls it (rbf.rs:545-554)
+    vals = np.sin(4 * pts[:, 0]) * np.cos(3 * pts[:, 1]) + pts[:, 2] ** 2 + 0.5 * pts[:, 0]
+    rhs = np.concatenate([vals, np.zeros(m)])
+    x, hist = S.fgmres(op, rhs, pre, None, 20, 5, S.FittingAccuracy(1e-6))
+    assert hist[-1][1] < 1e-6 and len(hist) <= 30
+    pre_o = lambda v: D.schwarz_preconditioner(v, levels, dense_partial, ost, ortho)
+    xo, histo = OS.fgmres(dense_matvec, rhs, pre_o, None, 20, 5, OS.RELATIVE, 1e-6)
+    assert histo[-1][1] < 1e-6
+    assert abs(len(hist) - len(histo)) <= 1                                   # same convergence
+    k = min(len(hist), len(histo)) - 1
+    np.testing.assert_allclose([h[1] for h in hist[:k]], [h[1] for h in histo[:k]], rtol=0.05)
+    # both reach the same residual of the dense system, and the interpolant reproduces the data
+    res = np.linalg.norm(dense_matvec(x) - rhs) / np.linalg.norm(rhs)
+    reso = np.linalg.norm(dense_matvec(xo) - rhs) / np.linalg.norm(rhs)
+    assert res < 2e-6 and reso < 2e-6
+    assert np.abs(dense_matvec(x)[:n] - vals).max() < 1e-4 * np.abs(vals).max()
+    # direct solve of [A P; P^T 0][lambda; c] = [f; 0] (the system FGMRES approximates, in the orthogonal
+    # complement of the polynomials): same fitted surface away from the data
+    Ks = np.block([[A, mono], [mono.T, np.zeros((m, m))]])
+    xs = np.linalg.solve(Ks, rhs)
+    q = rng.random((500, 3))
+    Pq = D.evaluate_monomials(q, ost.polynomial_degree, m, tr, sc)
+    Phi = np.array(O.kernel_matrix(kid, 1.0, 1.0, q, pts))
+    fs = Phi @ xs[:n] + Pq @ xs[n:]
+    # FGMRES keeps lambda orthogonal to the polynomials only approximately and returns the tail from the
+    # coarse solves; evaluate with its own coefficients
+    ff = Phi @ x[:n] + Pq @ x[n:]
+    assert np.abs(ff - fs).max() < 1e-3 * np.abs(fs).max()
+
+
+@pytest.mark.parametrize("kid,br,sill", [(3, 0.1, 0.1), (101, 0.1, 1.0)])
+def test_config2_one_million_points_mixed_level_tree(kid, br, sill):
+    """BASELINE.json configs[1] (Spheroidal3 base_range 0.1 / sill 0.1, and the labelled
+    multiquadric extension): 1M uniform points, whose adaptive tree mixes levels 4 and 5 (W / X lists live)."""
+    import torch
+    n = 1_000_000
+    pts = np.random.default_rng(42).random((n, 3))
+    t = F.FmmTree(pts, 7, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill), True, True)
+    s = t.stats()
+    assert s.n_points == n and s.n_w > 0 and s.n_x == s.n_w
+    g = torch.Generator(device="cuda").manual_seed(7)
+    w = torch.rand((2, n), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = torch.zeros_like(w)
+    t.matvec_device(w.data_ptr(), n, 2, y.data_ptr(), n, True)
+    a, b = 1.25, -0.5
+    wc = (a * w[0] + b * w[1]).reshape(1, n).contiguous()
+    yc = torch.zeros_like(wc)
+    t.matvec_device(wc.data_ptr(), n, 1, yc.data_ptr(), n, True)
+    lin = (yc[0] - (a * y[0] + b * y[1])).abs().max() / yc.abs().max()
+    assert float(lin) < 1e-12
+    sym = abs(float(torch.dot(w[1], y[0]) - torch.dot(w[0], y[1]))) / float(y[0].norm() * w[1].norm())
+    assert sym < 1e-7
+    idx = np.random.default_rng(3).choice(n, 64, replace=False)
+    wh = w.cpu().numpy().T.copy()
+    yd = O.dense_sum(kid, br, sill, pts[idx], pts, wh)
+    assert relerr(y.cpu().numpy().T[idx], yd) < 2e-6
+    # host-buffer entry points on the same tree: same numbers as the device-resident call
+    yh = t.fast_matrix_vector_product(wh[:, 0].copy())
+    assert relerr(yh, y[0].cpu().numpy()) < 1e-13
+
+
+def test_config4_ten_million_points_eight_rhs_properties():
+    """BASELINE.json configs[3] at full size: 10M points, 8 right-hand sides in one batched matvec."""
+    import torch
+    n, k = 10_000_000, 8
+    pts = np.random.default_rng(42).random((n, 3))
+    t = F.FmmTree(pts, 7, F.KernelParams(F.FmmKernelType.LinearRbf), True, True)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    w = torch.rand((k, n), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = torch.zeros_like(w)
+    t.matvec_device(w.data_ptr(), n, k, y.data_ptr(), n, True)
+    # linearity: a random combination of the 8 columns as a single-rhs product
+    coef = torch.tensor([0.5, -1.0, 2.0, 0.25, -0.75, 1.5, -2.0, 1.0], dtype=torch.float64, device="cuda")
+    wc = (coef[:, None] * w).sum(0, keepdim=True).contiguous()
+    yc = torch.zeros_like(wc)
+    t.matvec_device(wc.data_ptr(), n, 1, yc.data_ptr(), n, True)
+    lin = (yc[0] - (coef[:, None] * y).sum(0)).abs().max() / yc.abs().max()
+    assert float(lin) < 1e-12
+    # every column equals its own single-rhs product (the batch does not mix columns)
+    for j in (0, 4, 7):
+        wj = w[j:j + 1].contiguous()
+        yj = torch.zeros_like(wj)
+        t.matvec_device(wj.data_ptr(), n, 1, yj.data_ptr(), n, True)
+        assert float((yj[0] - y[j]).abs().max() / yj.abs().max()) < 1e-13
+    # symmetry of the kernel matrix across two columns, sampled dense rows for all eight
+    sym = abs(float(torch.dot(w[5], y[2]) - torch.dot(w[2], y[5]))) / float(y[2].norm() * w[5].norm())
+    assert sym < 1e-7
+    idx = np.random.default_rng(5).choice(n, 32, replace=False)
+    yd = O.dense_sum(0, 1.0, 1.0, pts[idx], pts, w.cpu().numpy().T.copy())
+    assert relerr(y.cpu().numpy().T[idx], yd) < 1e-6
+
+
+@pytest.mark.parametrize("kid,order,br,sill,tol", [(1, 9, 1.0, 1.0, 1e-7), (3, 7, 0.3, 0.4, 5e-6)])
+def test_independent_operators_on_a_mixed_level_tree(kid, order, br, sill, tol):
+    """No operator injection: the oracle builds its own ACA + LAPACK operators, the product its own ACA +
+    Householder + Jacobi ones; they agree to the compression tolerance (thin-plate spline p = 9 = config 3's
+    operator; Spheroidal3 = config 2's kernel)."""
+    rng = np.random.default_rng(400 + kid)
+    n = 130000 if order == 7 else 60000
+    pts = rng.random((n, 3)) if order == 7 else clustered_points(rng, n, 3)
+    t, r = _pair(pts, kid, order=order, br=br, sill=sill, inject=False)
+    assert t.stats().n_w > 0
+    w = rng.standard_normal((n, 1))
+    t.set_weights(w)
+    r.set_weights(w)
+    y, yr = t.evaluate(w, pts), r.evaluate(w, pts)
+    assert relerr(y, yr) < tol
+    idx = rng.choice(n, 200, replace=False)
+    yd = O.dense_sum(kid, br, sill, pts[idx], pts, w)
+    assert relerr(y[idx], yd) < 10 * tol and relerr(yr[idx], yd) < 10 * tol
