@@ -48,7 +48,7 @@ EXTRA_CONFIGS = [
     {"name": "config2_spheroidal3_1M", "points": 1_000_000, "kernel": "Spheroidal3Rbf", "order": 7, "nrhs": 1,
      "base_range": 0.1, "total_sill": 0.1},
     {"name": "config2_multiquadric_ext_1M", "points": 1_000_000, "kernel": "MultiquadricExt", "order": 7, "nrhs": 1,
-     "base_range": 0.1, "total_sill": 1.0},
+     "base_range": 0.1, "total_sill": 0.1},
     {"name": "config4_linear_10M_8rhs", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 8,
      "base_range": 1.0, "total_sill": 1.0},
     {"name": "config3_operator_tps_10M_order9", "points": 10_000_000, "kernel": "ThinPlateSplineRbf", "order": 9,
