@@ -833,6 +833,40 @@ int FmmTree::build_source_target_set() {
     return BBFMM_OK;
 }
 
+// Run lists of the symmetric P2P for the target leaves `job_cells` (in job order) when the targets are the
+// sorted sources [pb, pe): the leaf itself and the U points outside [pb, pe) one-sided, the U points after
+// the leaf inside the range two-sided; the U points before the leaf inside the range belong to those leaves'
+// own jobs.  (U lists are symmetric: linear_tree.rs:295-364 collects adjacent leaves from both sides.)
+int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe) {
+    const HostTree &t = tree_;
+    std::vector<int64_t> ptr(job_cells.size() + 1, 0);
+    std::vector<int32_t> runs;
+    runs.reserve(job_cells.size() * 12);
+    auto add = [&](int64_t b, int64_t e, int two) {
+        if (e <= b) return;
+        runs.push_back(static_cast<int32_t>(b));
+        runs.push_back(static_cast<int32_t>(e));
+        runs.push_back(two);
+    };
+    for (size_t j = 0; j < job_cells.size(); ++j) {
+        const int32_t c = job_cells[j];
+        const int64_t a0 = t.pt_begin[c], a1 = t.pt_end[c];
+        add(a0, a1, 0); // self interaction included (bbfmm.rs:1162-1251)
+        for (int64_t r = u_runs_.ptr[c]; r < u_runs_.ptr[c + 1]; ++r) {
+            const int64_t b = u_runs_.idx[2 * r], e = u_runs_.idx[2 * r + 1];
+            add(b, std::min({e, a0, pb}), 0);                       // before the leaf, another rank's
+            add(std::max(b, a1), std::min(e, pe), 1);               // after the leaf, inside the range
+            add(std::max({b, a1, pe}), e, 0);                       // after the leaf, another rank's
+        }
+        ptr[j + 1] = static_cast<int64_t>(runs.size() / 3);
+    }
+    CHK(dupload(&ts->sym_ptr, ptr));
+    CHK(dupload(&ts->sym_runs, runs));
+    ts->sym = true;
+    ts->sym_off = static_cast<int32_t>(pb);
+    return BBFMM_OK;
+}
+
 int FmmTree::build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
                               std::vector<int32_t> *leaves_out) {
     static const int64_t min_rows = [] {
@@ -1035,6 +1069,9 @@ void FmmTree::free_target_set(TargetSet *ts) {
     dfree(&ts->w_end);
     dfree(&ts->out);
     dfree(&ts->grad);
+    dfree(&ts->sym_ptr);
+    dfree(&ts->sym_runs);
+    ts->sym = false;
 }
 
 int FmmTree::upload_weights(const double *w, int64_t rows, int k, int64_t ldw) {
@@ -1065,19 +1102,30 @@ int FmmTree::ensure_pinned(size_t n) {
 }
 
 // upward_pass (bbfmm.rs:666-688)
-int FmmTree::upward(int k) {
+int FmmTree::upward(int k, const DownwardPlan *dp) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
+    const bool part = dp && dp->restrict_upward;
     // reset_multipole_coefficients (bbfmm.rs:619-624): M is zero-initialised once; P2M and M2M assign
-    // every leaf with sources and every parent, the other entries are never written.
+    // every leaf with sources and every parent, the other entries are never written.  A partition computes
+    // only the multipoles its downward and leaf passes read (the others keep stale values nobody reads).
     phase_begin();
-    launch_p2m(cheb_, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_src_leaves_.p, static_cast<int>(src_leaves_.size()),
-               d_pt_begin_.p, d_pt_end_.p, d_centers_.p, d_lengths_.p, d_M_.p, stream_);
+    if (part)
+        launch_p2m(cheb_, src_ptr_, d_w_sorted_.p, t.n_points, k, C, dp->d_up_leaves.p, static_cast<int>(dp->up_leaves_h.size()),
+                   d_pt_begin_.p, d_pt_end_.p, d_centers_.p, d_lengths_.p, d_M_.p, stream_);
+    else
+        launch_p2m(cheb_, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_src_leaves_.p, static_cast<int>(src_leaves_.size()),
+                   d_pt_begin_.p, d_pt_end_.p, d_centers_.p, d_lengths_.p, d_M_.p, stream_);
     phase_end(kPhP2M);
     phase_begin();
-    for (int level = t.depth - 1; level >= 1; --level) // (1..depth).rev(), bbfmm.rs:675
-        launch_m2m(cheb_, k, C, d_m2m_parents_[level].p, static_cast<int>(m2m_parents_[level].size()), d_child_ptr_.p,
-                   d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
+    for (int level = t.depth - 1; level >= 1; --level) { // (1..depth).rev(), bbfmm.rs:675
+        if (part)
+            launch_m2m(cheb_, k, C, dp->d_up_parents[level].p, static_cast<int>(dp->up_parents_h[level].size()),
+                       d_child_ptr_.p, d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
+        else
+            launch_m2m(cheb_, k, C, d_m2m_parents_[level].p, static_cast<int>(m2m_parents_[level].size()), d_child_ptr_.p,
+                       d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
+    }
     phase_end(kPhM2M);
     HIPCHK(hipGetLastError());
     return BBFMM_OK;
@@ -1148,8 +1196,16 @@ int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStre
         HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), st));
         if (with_grads) HIPCHK(hipMemsetAsync(grad, 0, static_cast<size_t>(k) * d_ * ts.m * sizeof(double), st));
         DirectJobs jobs{ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_u_run_ptr_.p, d_u_runs_.p};
+        static const bool sym_on = [] {
+            const char *e = std::getenv("BBFMM_P2P_SYM"); // 0: every ordered pair, as the reference loops
+            return !e || std::atoi(e) != 0;
+        }();
         if (timed) phase_begin();
-        launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
+        if (ts.sym && sym_on && !with_grads) // targets = sources: every unordered pair once
+            launch_p2p_sym(kernel_, ts.n_jobs, ts.tgt_begin.p, ts.tgt_end.p, ts.sym_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_,
+                           d_w_sorted_.p, t.n_points, k, ts.out.p, ts.m, st);
+        else
+            launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
         if (timed) phase_end(kPhP2P);
     }
     if (parts & 2) {
@@ -1300,7 +1356,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipEventRecord(ev_fork_, stream_));
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
         CHK(leaf_pass_near(ts, k, false, stream2_, 1));
-        CHK(upward(k));
+        CHK(upward(k, plan));
         HIPCHK(hipEventRecord(ev_fork_, stream_));
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
         CHK(leaf_pass_near(ts, k, false, stream2_, 2));
@@ -1309,7 +1365,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
         CHK(leaf_pass_far(ts, k, false));
     } else if (overlap == 1) {
-        CHK(upward(k));
+        CHK(upward(k, plan));
         // near field (FP64 VALU) on a second stream beside the far field (FP64 MFMA)
         HIPCHK(hipEventRecord(ev_fork_, stream_));
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
@@ -1319,7 +1375,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
         CHK(leaf_pass_far(ts, k, false));
     } else {
-        CHK(upward(k));
+        CHK(upward(k, plan));
         CHK(downward(k, plan));
         CHK(leaf_pass(ts, k, false));
     }
@@ -1446,7 +1502,7 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
 // bbfmm.rs:468-480): M2L stage 2 on the tiles that hold such a cell, stage 1 on compact tiles (lists
 // of class positions, 128 per tile) of the cells that are a V-list source of one, P2L on such cells.
 // The host part also runs on BBFMM_FLAG_HOST_ONLY handles.
-int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp) {
+int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp, bool restrict_upward) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
     dp->active.assign(static_cast<size_t>(C), 0);
@@ -1612,7 +1668,30 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         xptr.push_back(static_cast<int64_t>(xruns.size() / 2));
     }
     dp->n_x_jobs = static_cast<int>(xc.size());
+    dp->restrict_upward = restrict_upward;
+    dp->up_leaves_h.clear();
+    dp->up_parents_h.assign(static_cast<size_t>(t.depth) + 1, {});
+    if (restrict_upward) {
+        // multipoles read: V-list sources of the active cells (stage 1), W-list cells of the target leaves (M2P);
+        // computing one needs every cell below it.  Cells are numbered by (level, key): parents come first.
+        std::vector<uint8_t> up(needed);
+        for (int32_t leaf : target_leaves)
+            for (int64_t q = t.w.ptr[leaf]; q < t.w.ptr[leaf + 1]; ++q) up[t.w.idx[q]] = 1;
+        for (int64_t c = 0; c < C; ++c)
+            if (up[c])
+                for (int64_t q = t.children.ptr[c]; q < t.children.ptr[c + 1]; ++q) up[t.children.idx[q]] = 1;
+        for (int32_t c : src_leaves_)
+            if (up[c]) dp->up_leaves_h.push_back(c);
+        for (int level = 1; level < t.depth; ++level)
+            for (int32_t c : m2m_parents_[level])
+                if (up[c]) dp->up_parents_h[level].push_back(c);
+    }
     if (host_only_) return BBFMM_OK;
+    if (restrict_upward) {
+        CHK(tupload(&dp->d_up_leaves, dp->up_leaves_h));
+        dp->d_up_parents.resize(dp->up_parents_h.size());
+        for (size_t l = 0; l < dp->up_parents_h.size(); ++l) CHK(tupload(&dp->d_up_parents[l], dp->up_parents_h[l]));
+    }
     CHK(tupload(&dp->d_active, dp->active));
     CHK(tupload(&dp->d_tiles2, dp->tiles2_h));
     CHK(tupload(&dp->d_tiles1, dp->tiles1_h));
@@ -1625,6 +1704,8 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
 }
 
 void FmmTree::free_downward_plan(DownwardPlan *dp) {
+    dfree(&dp->d_up_leaves);
+    for (auto &b : dp->d_up_parents) dfree(&b);
     dfree(&dp->d_active);
     dfree(&dp->d_tiles2);
     dfree(&dp->d_tiles1);
@@ -1801,7 +1882,7 @@ int FmmTree::set_partition(int rank, int world) {
     const size_t lb = rank == 0 ? 0 : cut(rank), le = rank == world - 1 ? nl : cut(rank + 1);
     std::vector<int32_t> owned_leaves(src_leaves_.begin() + static_cast<std::ptrdiff_t>(lb),
                                       src_leaves_.begin() + static_cast<std::ptrdiff_t>(le));
-    CHK(build_downward_plan(owned_leaves, &part_plan_));
+    CHK(build_downward_plan(owned_leaves, &part_plan_, true));
     // owned targets: one contiguous range of the sorted sources
     const int64_t pb = lb < le ? t.pt_begin[src_leaves_[lb]] : 0;
     const int64_t pe = lb < le ? t.pt_end[src_leaves_[le - 1]] : 0;
@@ -1834,6 +1915,7 @@ int FmmTree::set_partition(int rank, int world) {
     CHK(dupload(&ts.w_begin, wb));
     CHK(dupload(&ts.w_end, we));
     CHK(dalloc(&ts.out, static_cast<size_t>(std::max(k_cap_, 1)) * std::max<int64_t>(ts.m, 1)));
+    CHK(build_sym_runs(&ts, jc, pb, pe));
     have_part_ = true;
     return BBFMM_OK;
 }

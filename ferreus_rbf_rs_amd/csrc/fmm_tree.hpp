@@ -53,6 +53,12 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     DevBuf<int64_t> w_begin, w_end;
     int n_w_jobs = 0;
     DevBuf<double> out, grad;  // K x m, K*d x m (sorted order)
+    // targets that are a contiguous sorted range of the sources (the matvec, a partition): run lists of the
+    // symmetric P2P (device.hpp launch_p2p_sym); sym_off = sorted source index of target position 0
+    bool sym = false;
+    int32_t sym_off = 0;
+    DevBuf<int64_t> sym_ptr;
+    DevBuf<int32_t> sym_runs;
 };
 
 // The part of the downward pass a set of target leaves needs (a partition of the sources, or the
@@ -65,6 +71,13 @@ struct DownwardPlan {
     std::vector<int32_t> tile_idx_h;        // class positions of the cells of both tile lists
     std::vector<uint16_t> qlist_h;          // active contraction steps of the stage-2 tiles
     int n_x_jobs = 0;
+    // a partition also restricts the upward pass to the cells whose multipoles it reads (V-list sources and
+    // W-list cells of its targets, and everything below them)
+    bool restrict_upward = false;
+    std::vector<int32_t> up_leaves_h;
+    std::vector<std::vector<int32_t>> up_parents_h; // per level
+    DevBuf<int32_t> d_up_leaves;
+    std::vector<DevBuf<int32_t>> d_up_parents;
     DevBuf<uint8_t> d_active;
     DevBuf<M2lTileDesc> d_tiles2, d_tiles1;
     DevBuf<int32_t> d_tile_idx, d_x_cells, d_x_runs;
@@ -141,7 +154,7 @@ class FmmTree {
                                   std::vector<double> *u_all) const;
     void fill_m2l_operator_arrays(const HostM2lClass &hc, double *vt_all, double *u_all) const;
     int ensure_rhs_capacity(int k);
-    int upward(int k);                                  // P2M + M2M from w_sorted_
+    int upward(int k, const DownwardPlan *dp = nullptr); // P2M + M2M from w_sorted_ (a partition's plan: needed cells only)
     int downward(int k, const DownwardPlan *dp = nullptr); // M2L + P2L + L2L into L_ (restricted by a plan)
     int leaf_pass(const TargetSet &ts, int k, bool with_grads);
     int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts);
@@ -154,6 +167,7 @@ class FmmTree {
     int build_target_set_host(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
                               std::vector<int32_t> *leaves_out);
     int build_source_target_set();
+    int build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe);
     void free_target_set(TargetSet *ts);
     int upload_weights(const double *w, int64_t rows, int k, int64_t ldw);
     void phase_begin();
@@ -197,7 +211,7 @@ class FmmTree {
     DownwardPlan part_plan_;                     // partition: restricted downward pass
     std::vector<std::unique_ptr<SubsetPlan>> subset_plans_; // partial matvecs, least recently used evicted
     uint64_t subset_clock_ = 0;
-    int build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp);
+    int build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp, bool restrict_upward = false);
     void free_downward_plan(DownwardPlan *dp);
     int subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out);
     int fill_subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan *sp);
