@@ -830,6 +830,7 @@ int FmmTree::build_source_target_set() {
     CHK(dupload(&ts.w_tgt_end, wte));
     CHK(dupload(&ts.w_begin, wb));
     CHK(dupload(&ts.w_end, we));
+    CHK(build_sym_runs(&ts, jc, 0, t.n_points));
     return BBFMM_OK;
 }
 
