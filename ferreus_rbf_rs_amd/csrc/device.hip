@@ -732,26 +732,27 @@ __global__ __launch_bounds__(256) void p2p_kernel(KernelSpec ks, int d, DirectJo
 // here takes only the part of its U list that lies AFTER it in the sorted order ("two-sided" runs): each
 // value phi(a_i, b_j) is added to the row sum of a_i (times w_b[j]) and to the column sum of b_j (times
 // w_a[i]).  "One-sided" runs (the leaf itself; for a partition the U points other ranks own) only feed the
-// rows.  One workgroup (8 waves) per leaf: a wave owns up to SYM_TR consecutive targets whose coordinates are
-// wave-uniform, its lanes walk the staged source tile (lane-linear LDS reads); row sums stay in registers and
-// are reduced across the wave by DPP when the wave's rows are done, column sums go to an LDS accumulator by
-// ds_add_f64 (distinct addresses inside a wave) and from there to HBM with one f64 atomic per source and tile.
-constexpr int SYM_TILE = 512;
+// rows.  A job = up to SYM_WAVES * SYM_TR consecutive targets of one leaf, one workgroup (8 waves) each: a wave
+// owns up to SYM_TR targets whose coordinates are wave-uniform (scalar loads), its lanes walk the staged source
+// tile -- the leaf's runs packed back to back, lane-linear LDS reads; row sums stay in registers over all
+// tiles and are reduced across the wave once, column sums go to an LDS accumulator by ds_add_f64 (distinct
+// addresses inside a wave) and from there to HBM with one f64 atomic per source and tile.  One right-hand
+// side per launch (more rhs take the ordered-pair kernel above).
+constexpr int SYM_TILE = 1024;
 constexpr int SYM_TR = 6;
 constexpr int SYM_WAVES = 8;
 
 struct SymJobs {
     int n_jobs;
     const int32_t *tgt_begin, *tgt_end; // targets of job i: positions in the target set (sorted order)
-    const int64_t *run_ptr;             // per job
+    const int64_t *run_range;           // 2 per job: first and one-past-last run of the job's leaf
     const int32_t *runs;                // 3 ints per run: begin, end (sorted source indices), 1 = two-sided
     int32_t tgt_off;                    // sorted source index of target position 0
 };
 
-template <int KB> struct SymTile {
-    double x[SYM_TILE], y[SYM_TILE], z[SYM_TILE];
-    double w[KB][SYM_TILE];
-    double col[KB][SYM_TILE];
+struct SymTile {
+    double x[SYM_TILE], y[SYM_TILE], z[SYM_TILE], w[SYM_TILE], col[SYM_TILE];
+    int32_t cidx[SYM_TILE]; // target position of a two-sided column, -1 for a one-sided one
 };
 
 __device__ inline double wave_sum(double v) {
@@ -760,100 +761,80 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-template <int KID, int KB>
+template <int KID>
 __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, SymJobs jobs, Xyz src,
-                                                                const double *__restrict__ ws, int64_t N, int k0,
-                                                                int kb, double *__restrict__ out, int64_t n_tgt) {
-    __shared__ SymTile<KB> tile;
+                                                                const double *__restrict__ ws,
+                                                                double *__restrict__ out) {
+    __shared__ SymTile tile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int job = blockIdx.x;
     const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
-    const int na = t1 - t0;
-    const int rpw = (na + SYM_WAVES - 1) / SYM_WAVES;                  // rows of this leaf per wave
-    const int r_lo = min(t0 + wave * rpw, t1), r_hi = min(r_lo + rpw, t1);
-    const bool single = rpw <= SYM_TR; // the wave's rows fit one register group: sums persist over all tiles
-    const int64_t q0 = jobs.run_ptr[job], q1 = jobs.run_ptr[job + 1];
-    double racc[SYM_TR][KB];
+    const int rpw = (t1 - t0 + SYM_WAVES - 1) / SYM_WAVES; // rows per wave, <= SYM_TR
+    const int r_lo = min(t0 + wave * rpw, t1);
+    const int nr = min(rpw, t1 - r_lo);
+    double tx[SYM_TR], ty[SYM_TR], tz[SYM_TR], tw[SYM_TR], racc[SYM_TR];
 #pragma unroll
-    for (int r = 0; r < SYM_TR; ++r)
-#pragma unroll
-        for (int kk = 0; kk < KB; ++kk) racc[r][kk] = 0.0;
-    auto flush_rows = [&](int rg, int nr) {
-#pragma unroll
-        for (int r = 0; r < SYM_TR; ++r) {
-            if (r < nr) {
-#pragma unroll
-                for (int kk = 0; kk < KB; ++kk) {
-                    const double s = wave_sum(racc[r][kk]);
-                    if (lane == 0 && kk < kb) unsafeAtomicAdd(&out[(int64_t)(k0 + kk) * n_tgt + rg + r], s);
-                    racc[r][kk] = 0.0;
-                }
+    for (int r = 0; r < SYM_TR; ++r) {
+        const int g = jobs.tgt_off + min(r_lo + min(r, max(nr - 1, 0)), t1 - 1); // sorted source index of the target (wave-uniform)
+        tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g], tw[r] = ws[g];
+        racc[r] = 0.0;
+    }
+    int64_t q = jobs.run_range[2 * job];
+    const int64_t q1 = jobs.run_range[2 * job + 1];
+    int pos = 0; // points of run q already staged
+    while (q < q1) {
+        __syncthreads(); // the previous tile has been read and its columns flushed
+        int fill = 0;
+        while (q < q1 && fill < SYM_TILE) { // pack runs back to back (uniform control flow)
+            const int sb = jobs.runs[3 * q] + pos, se = jobs.runs[3 * q + 1];
+            const bool two = jobs.runs[3 * q + 2] != 0;
+            const int take = min(se - sb, SYM_TILE - fill);
+            for (int j = tid; j < take; j += 64 * SYM_WAVES) {
+                tile.x[fill + j] = src.x[sb + j];
+                tile.y[fill + j] = src.y[sb + j];
+                tile.z[fill + j] = src.z[sb + j];
+                tile.w[fill + j] = ws[sb + j];
+                tile.col[fill + j] = 0.0;
+                tile.cidx[fill + j] = two ? sb + j - jobs.tgt_off : -1;
+            }
+            fill += take;
+            pos += take;
+            if (sb + take == se) {
+                ++q;
+                pos = 0;
             }
         }
-    };
-    for (int64_t q = q0; q < q1; ++q) {
-        const int sb = jobs.runs[3 * q], se = jobs.runs[3 * q + 1];
-        const bool two = jobs.runs[3 * q + 2] != 0;
-        for (int base = sb; base < se; base += SYM_TILE) {
-            const int cnt = min(SYM_TILE, se - base);
-            __syncthreads(); // the previous tile has been read and its columns flushed
-            for (int j = tid; j < cnt; j += 64 * SYM_WAVES) {
-                tile.x[j] = src.x[base + j];
-                tile.y[j] = src.y[base + j];
-                tile.z[j] = src.z[base + j];
-#pragma unroll
-                for (int kk = 0; kk < KB; ++kk) {
-                    tile.w[kk][j] = kk < kb ? ws[(int64_t)(k0 + kk) * N + base + j] : 0.0;
-                    tile.col[kk][j] = 0.0;
-                }
-            }
-            __syncthreads();
-            for (int rg = r_lo; rg < r_hi; rg += SYM_TR) { // wave-uniform
-                const int nr = min(SYM_TR, r_hi - rg);
-                double tx[SYM_TR], ty[SYM_TR], tz[SYM_TR], tw[SYM_TR][KB];
+        __syncthreads();
+        if (nr > 0) {
+            for (int j = lane; j < fill; j += 64) {
+                const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j], wj = tile.w[j];
+                double csum = 0.0;
 #pragma unroll
                 for (int r = 0; r < SYM_TR; ++r) {
-                    const int g = jobs.tgt_off + rg + min(r, nr - 1); // sorted source index of the target
-                    tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
-#pragma unroll
-                    for (int kk = 0; kk < KB; ++kk) tw[r][kk] = (two && kk < kb) ? ws[(int64_t)(k0 + kk) * N + g] : 0.0;
-                }
-                for (int j = lane; j < cnt; j += 64) {
-                    const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j];
-                    double wj[KB], csum[KB];
-#pragma unroll
-                    for (int kk = 0; kk < KB; ++kk) wj[kk] = tile.w[kk][j], csum[kk] = 0.0;
-#pragma unroll
-                    for (int r = 0; r < SYM_TR; ++r) {
-                        if (r < nr) {
-                            const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
-                            const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
-#pragma unroll
-                            for (int kk = 0; kk < KB; ++kk) {
-                                racc[r][kk] += v * wj[kk];
-                                csum[kk] += v * tw[r][kk];
-                            }
-                        }
-                    }
-                    if (two) {
-#pragma unroll
-                        for (int kk = 0; kk < KB; ++kk) unsafeAtomicAdd(&tile.col[kk][j], csum[kk]);
+                    if (r < nr) { // wave-uniform
+                        const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
+                        const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
+                        racc[r] += v * wj;
+                        csum += v * tw[r];
                     }
                 }
-                if (!single) flush_rows(rg, nr);
-            }
-            if (two) {
-                __syncthreads();
-                for (int j = tid; j < cnt; j += 64 * SYM_WAVES) {
-#pragma unroll
-                    for (int kk = 0; kk < KB; ++kk)
-                        if (kk < kb) unsafeAtomicAdd(&out[(int64_t)(k0 + kk) * n_tgt + (base + j - jobs.tgt_off)], tile.col[kk][j]);
-                }
+                if (tile.cidx[j] >= 0) unsafeAtomicAdd(&tile.col[j], csum);
             }
         }
+        __syncthreads();
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
+            const int c = tile.cidx[j];
+            if (c >= 0) unsafeAtomicAdd(&out[c], tile.col[j]);
+        }
     }
-    if (single && r_lo < r_hi) flush_rows(r_lo, r_hi - r_lo);
+#pragma unroll
+    for (int r = 0; r < SYM_TR; ++r) {
+        if (r < nr) {
+            const double s = wave_sum(racc[r]);
+            if (lane == 0) unsafeAtomicAdd(&out[r_lo + r], s);
+        }
+    }
 }
 
 // Stage the Chebyshev nodes of `cell` (scale_cheb_nodes_to_cell, chebyshev.rs:951-968) and
@@ -1527,23 +1508,18 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
 }
 
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                    const int64_t *run_ptr, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
-                    const double *w_sorted, int64_t N, int K, double *out_sorted, int64_t n_tgt, hipStream_t s) {
+                    const int64_t *run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
+                    const double *w_sorted, double *out_sorted, hipStream_t s) {
     if (n_jobs == 0) return;
-    const SymJobs jobs{n_jobs, tgt_begin, tgt_end, run_ptr, runs3, tgt_off};
+    const SymJobs jobs{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
-        for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
-            const int kb = std::min(DIRECT_KB, K - k0);
-            if (kb == 1)
-                hipLaunchKernelGGL((p2p_sym_kernel<ID, 1>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs,
-                                   make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted, n_tgt);
-            else
-                hipLaunchKernelGGL((p2p_sym_kernel<ID, DIRECT_KB>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs,
-                                   make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted, n_tgt);
-        }
+        hipLaunchKernelGGL((p2p_sym_kernel<ID>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, make_xyz(src_xyz),
+                           w_sorted, out_sorted);
     });
 }
+
+int p2p_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
 
 void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin,
                 const int32_t *tgt_end, const int64_t *w_begin, const int64_t *w_end,

@@ -109,14 +109,16 @@ struct DirectJobs {
 void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const double *const *tgt_xyz,
                 int64_t n_tgt, const double *const *src_xyz, const double *w_sorted, int64_t N, int K,
                 double *out_sorted, double *grad_sorted, hipStream_t s);
-// P2P for targets that are (a contiguous sorted range of) the sources: every unordered pair once.  Job i holds
-// the target positions [tgt_begin[i], tgt_end[i]) of one leaf; position p is sorted source tgt_off + p; runs3 =
-// (begin, end, two_sided) triples of sorted source ranges: two-sided runs also receive the column sums (they
-// must lie inside the target range and after the leaf), one-sided runs only feed the leaf's rows.  out_sorted
-// (K x n_tgt, zeroed by the caller) is accumulated with f64 atomics.
+// P2P for targets that are (a contiguous sorted range of) the sources: every unordered pair once, one rhs.
+// Job i holds the target positions [tgt_begin[i], tgt_end[i]) -- at most p2p_sym_rows_per_job() of them, all of
+// one leaf; position p is sorted source tgt_off + p; its leaf's runs are runs3[3 * run_range[2i] .. 3 * run_range[2i+1])
+// = (begin, end, two_sided) triples of sorted source ranges: two-sided runs also receive the column sums (they
+// must lie inside the target range and after the leaf), one-sided runs only feed the job's rows.  out_sorted
+// (n_tgt values, zeroed by the caller) is accumulated with f64 atomics.
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                    const int64_t *run_ptr, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
-                    const double *w_sorted, int64_t N, int K, double *out_sorted, int64_t n_tgt, hipStream_t s);
+                    const int64_t *run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
+                    const double *w_sorted, double *out_sorted, hipStream_t s);
+int p2p_sym_rows_per_job();
 // M2P: sources are the Chebyshev nodes of the W-list cells, weights their multipoles.  Job i
 // covers targets [tgt_begin[i], tgt_end[i]) and the W cells w_cells[w_begin[i] .. w_end[i]).
 void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin,

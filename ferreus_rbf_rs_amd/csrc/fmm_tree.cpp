@@ -840,28 +840,41 @@ int FmmTree::build_source_target_set() {
 // own jobs.  (U lists are symmetric: linear_tree.rs:295-364 collects adjacent leaves from both sides.)
 int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe) {
     const HostTree &t = tree_;
-    std::vector<int64_t> ptr(job_cells.size() + 1, 0);
-    std::vector<int32_t> runs;
-    runs.reserve(job_cells.size() * 12);
+    std::vector<int64_t> range;
+    std::vector<int32_t> runs, tb, te;
+    runs.reserve(job_cells.size() * 24);
     auto add = [&](int64_t b, int64_t e, int two) {
         if (e <= b) return;
         runs.push_back(static_cast<int32_t>(b));
         runs.push_back(static_cast<int32_t>(e));
         runs.push_back(two);
     };
+    const int64_t max_rows = p2p_sym_rows_per_job();
     for (size_t j = 0; j < job_cells.size(); ++j) {
         const int32_t c = job_cells[j];
         const int64_t a0 = t.pt_begin[c], a1 = t.pt_end[c];
+        const int64_t first = static_cast<int64_t>(runs.size() / 3);
         add(a0, a1, 0); // self interaction included (bbfmm.rs:1162-1251)
         for (int64_t r = u_runs_.ptr[c]; r < u_runs_.ptr[c + 1]; ++r) {
             const int64_t b = u_runs_.idx[2 * r], e = u_runs_.idx[2 * r + 1];
-            add(b, std::min({e, a0, pb}), 0);                       // before the leaf, another rank's
-            add(std::max(b, a1), std::min(e, pe), 1);               // after the leaf, inside the range
-            add(std::max({b, a1, pe}), e, 0);                       // after the leaf, another rank's
+            add(b, std::min({e, a0, pb}), 0);         // before the leaf, another rank's
+            add(std::max(b, a1), std::min(e, pe), 1); // after the leaf, inside the range
+            add(std::max({b, a1, pe}), e, 0);         // after the leaf, another rank's
         }
-        ptr[j + 1] = static_cast<int64_t>(runs.size() / 3);
+        const int64_t last = static_cast<int64_t>(runs.size() / 3);
+        // the leaf's rows in equal chunks of at most max_rows
+        const int64_t na = a1 - a0, nj = (na + max_rows - 1) / max_rows;
+        for (int64_t i = 0; i < nj; ++i) {
+            tb.push_back(static_cast<int32_t>(a0 - pb + na * i / nj));
+            te.push_back(static_cast<int32_t>(a0 - pb + na * (i + 1) / nj));
+            range.push_back(first);
+            range.push_back(last);
+        }
     }
-    CHK(dupload(&ts->sym_ptr, ptr));
+    ts->n_sym_jobs = static_cast<int>(tb.size());
+    CHK(dupload(&ts->sym_tb, tb));
+    CHK(dupload(&ts->sym_te, te));
+    CHK(dupload(&ts->sym_ptr, range));
     CHK(dupload(&ts->sym_runs, runs));
     ts->sym = true;
     ts->sym_off = static_cast<int32_t>(pb);
@@ -1070,6 +1083,8 @@ void FmmTree::free_target_set(TargetSet *ts) {
     dfree(&ts->w_end);
     dfree(&ts->out);
     dfree(&ts->grad);
+    dfree(&ts->sym_tb);
+    dfree(&ts->sym_te);
     dfree(&ts->sym_ptr);
     dfree(&ts->sym_runs);
     ts->sym = false;
@@ -1202,9 +1217,9 @@ int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStre
             return !e || std::atoi(e) != 0;
         }();
         if (timed) phase_begin();
-        if (ts.sym && sym_on && !with_grads) // targets = sources: every unordered pair once
-            launch_p2p_sym(kernel_, ts.n_jobs, ts.tgt_begin.p, ts.tgt_end.p, ts.sym_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_,
-                           d_w_sorted_.p, t.n_points, k, ts.out.p, ts.m, st);
+        if (ts.sym && sym_on && !with_grads && k == 1) // targets = sources, one rhs: every unordered pair once
+            launch_p2p_sym(kernel_, ts.n_sym_jobs, ts.sym_tb.p, ts.sym_te.p, ts.sym_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_,
+                           d_w_sorted_.p, ts.out.p, st);
         else
             launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
         if (timed) phase_end(kPhP2P);

@@ -57,7 +57,9 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     // symmetric P2P (device.hpp launch_p2p_sym); sym_off = sorted source index of target position 0
     bool sym = false;
     int32_t sym_off = 0;
-    DevBuf<int64_t> sym_ptr;
+    int n_sym_jobs = 0;
+    DevBuf<int32_t> sym_tb, sym_te; // jobs: row chunks of the leaves
+    DevBuf<int64_t> sym_ptr;        // 2 per job: run range of the job's leaf
     DevBuf<int32_t> sym_runs;
 };
 
