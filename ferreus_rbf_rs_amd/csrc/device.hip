@@ -738,9 +738,10 @@ __global__ __launch_bounds__(256) void p2p_kernel(KernelSpec ks, int d, DirectJo
 // tiles and are reduced across the wave once, column sums go to an LDS accumulator by ds_add_f64 (distinct
 // addresses inside a wave) and from there to HBM with one f64 atomic per source and tile.  One right-hand
 // side per launch (more rhs take the ordered-pair kernel above).
-constexpr int SYM_TILE = 1024;
+constexpr int SYM_TILE = 768;
 constexpr int SYM_TR = 6;
 constexpr int SYM_WAVES = 8;
+constexpr int SYM_SEG = 64; // runs packed into one tile at most
 
 struct SymJobs {
     int n_jobs;
@@ -753,6 +754,9 @@ struct SymJobs {
 struct SymTile {
     double x[SYM_TILE], y[SYM_TILE], z[SYM_TILE], w[SYM_TILE], col[SYM_TILE];
     int32_t cidx[SYM_TILE]; // target position of a two-sided column, -1 for a one-sided one
+    int32_t seg_src[SYM_SEG], seg_off[SYM_SEG], seg_two[SYM_SEG]; // runs packed into the tile
+    int32_t fill, nseg, next_pos;
+    int64_t next_q;
 };
 
 __device__ inline double wave_sum(double v) {
@@ -785,25 +789,57 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
     int pos = 0; // points of run q already staged
     while (q < q1) {
         __syncthreads(); // the previous tile has been read and its columns flushed
-        int fill = 0;
-        while (q < q1 && fill < SYM_TILE) { // pack runs back to back (uniform control flow)
-            const int sb = jobs.runs[3 * q] + pos, se = jobs.runs[3 * q + 1];
-            const bool two = jobs.runs[3 * q + 2] != 0;
-            const int take = min(se - sb, SYM_TILE - fill);
-            for (int j = tid; j < take; j += 64 * SYM_WAVES) {
-                tile.x[fill + j] = src.x[sb + j];
-                tile.y[fill + j] = src.y[sb + j];
-                tile.z[fill + j] = src.z[sb + j];
-                tile.w[fill + j] = ws[sb + j];
-                tile.col[fill + j] = 0.0;
-                tile.cidx[fill + j] = two ? sb + j - jobs.tgt_off : -1;
+        // The tile's segment table: up to SYM_SEG runs packed back to back until SYM_TILE columns are full.  One
+        // wave reads the run triples in one go and scans their lengths; then every thread finds the run of its
+        // column by bisection in LDS, so that all source loads of the tile leave in one batch (one memory round
+        // trip for the table, one for the columns, whatever the number of runs).
+        if (wave == 0) {
+            const int64_t r = q + lane;
+            const bool valid = r < q1;
+            int b = valid ? jobs.runs[3 * r] : 0;
+            const int e = valid ? jobs.runs[3 * r + 1] : 0;
+            const int two = valid ? jobs.runs[3 * r + 2] : 0;
+            if (lane == 0) b += pos;
+            const int len = e - b;
+            int incl = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
             }
-            fill += take;
-            pos += take;
-            if (sb + take == se) {
-                ++q;
-                pos = 0;
+            const int excl = incl - len;
+            const int take = min(len, max(SYM_TILE - excl, 0));
+            tile.seg_src[lane] = b;
+            tile.seg_off[lane] = excl;
+            tile.seg_two[lane] = two;
+            const unsigned long long used = __ballot(take > 0);
+            const int nseg = __popcll(used);
+            if (lane == nseg - 1) {
+                const bool full = take == len;
+                tile.fill = excl + take;
+                tile.nseg = nseg;
+                tile.next_q = q + lane + (full ? 1 : 0);
+                tile.next_pos = full ? 0 : ((lane == 0 ? pos : 0) + take);
             }
+        }
+        __syncthreads();
+        const int fill = tile.fill, nseg = tile.nseg;
+        q = tile.next_q;
+        pos = tile.next_pos;
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
+            int lo = 0, hi = nseg;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (tile.seg_off[mid] <= j) lo = mid;
+                else hi = mid;
+            }
+            const int g = tile.seg_src[lo] + (j - tile.seg_off[lo]);
+            tile.x[j] = src.x[g];
+            tile.y[j] = src.y[g];
+            tile.z[j] = src.z[g];
+            tile.w[j] = ws[g];
+            tile.col[j] = 0.0;
+            tile.cidx[j] = tile.seg_two[lo] ? g - jobs.tgt_off : -1;
         }
         __syncthreads();
         if (nr > 0) {
