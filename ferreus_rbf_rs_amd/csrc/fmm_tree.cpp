@@ -13,6 +13,7 @@
 
 #include "morton.hpp"
 #include "parallel.hpp"
+#include "tree_device.hpp"
 
 namespace bbfmm {
 
@@ -123,6 +124,7 @@ FmmTree::~FmmTree() {
     }
     for (hipEvent_t e : event_pool_) (void)hipEventDestroy(e);
     if (h_pin_) (void)hipHostFree(h_pin_);
+    free_dev_tree_points(&dev_points_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (stream2_) (void)hipStreamDestroy(stream2_);
@@ -238,7 +240,42 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
     if (!(radius > 0.0) || !std::isfinite(radius)) return fail(BBFMM_BAD_ARGUMENT, "degenerate or non-finite extents");
 
     StageTimer timer;
-    build_tree(pts_.data(), n, n, d, center, radius, params_.max_points_per_cell, !sparse, adaptive, &tree_);
+    if (!host_only_) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+            return fail(BBFMM_DEVICE_ERROR, "no HIP device available (the BBFMM passes have no CPU fallback)");
+        {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                prop.multiProcessorCount > 0)
+                n_cu_ = prop.multiProcessorCount;
+        }
+        HIPCHK(hipStreamCreate(&stream_));
+        HIPCHK(hipStreamCreate(&stream2_));
+        HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+    }
+    // The subdivision (Morton codes, sort, cells, per-leaf point lists) runs on the device when there is one and
+    // every point lies inside the root box; the host build (tree.cpp) is the bit-exact checker and the fallback.
+    static const bool tree_on_device = [] {
+        const char *e = std::getenv("BBFMM_TREE_DEVICE");
+        return !e || std::atoi(e) != 0;
+    }();
+    tree_built_on_device_ = false;
+    if (!host_only_ && tree_on_device) {
+        std::vector<BuildCell> cells;
+        const int brc = build_tree_cells_device(pts_.data(), n, n, d, center, radius, params_.max_points_per_cell, !sparse,
+                                                adaptive, &tree_, &cells, &dev_points_, stream_);
+        if (brc < 0) return hip_fail(static_cast<hipError_t>(-brc), "device tree build");
+        if (brc == 0) {
+            timer.lap("tree: subdivision (device)");
+            finish_tree(cells, &tree_);
+            tree_built_on_device_ = true;
+        }
+    }
+    if (!tree_built_on_device_)
+        build_tree(pts_.data(), n, n, d, center, radius, params_.max_points_per_cell, !sparse, adaptive, &tree_);
     timer.lap("tree + interaction lists");
     precompute_operators(order, d, radius, tree_.depth, kernel_, params_.compression_type, params_.epsilon, &ops_);
     timer.lap("operators (ACA/SVD)");
@@ -268,22 +305,6 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
     part_rows_.clear();
     timer.lap("run lists");
 
-    if (!host_only_) {
-        int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
-            return fail(BBFMM_DEVICE_ERROR, "no HIP device available (the BBFMM passes have no CPU fallback)");
-        {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
-                prop.multiProcessorCount > 0)
-                n_cu_ = prop.multiProcessorCount;
-        }
-        HIPCHK(hipStreamCreate(&stream_));
-        HIPCHK(hipStreamCreate(&stream2_));
-        HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
-    }
     CHK(build_m2l_tables());
     timer.lap("stacked M2L tables");
     if (!host_only_) {
@@ -639,7 +660,26 @@ int FmmTree::upload() {
 
     // sorted sources (SoA); unused axes alias one zero array
     CHK(dalloc(&d_zero_axis_, static_cast<size_t>(N), true));
-    {
+    if (dev_points_.order && dev_points_.n == N) {
+        // the device tree build left the points and the hierarchical order in HBM: gather there
+        for (int a = 0; a < 3; ++a) {
+            if (a < d) {
+                CHK(dalloc(&d_src_[a], static_cast<size_t>(N)));
+                src_ptr_[a] = d_src_[a].p;
+            } else {
+                src_ptr_[a] = d_zero_axis_.p;
+            }
+        }
+        launch_gather_targets(dev_points_.xyz[0], dev_points_.xyz[1], dev_points_.xyz[2],
+                              reinterpret_cast<const int32_t *>(dev_points_.order), N, d > 0 ? d_src_[0].p : nullptr,
+                              d > 1 ? d_src_[1].p : nullptr, d > 2 ? d_src_[2].p : nullptr, stream_);
+        d_order_.p = reinterpret_cast<int32_t *>(dev_points_.order); // rows < 2^31: same bits as int32
+        d_order_.n = static_cast<size_t>(N);
+        owned_.push_back(dev_points_.order);
+        dev_points_.order = nullptr;
+        HIPCHK(hipStreamSynchronize(stream_));
+        free_dev_tree_points(&dev_points_);
+    } else {
         std::vector<double> tmp(static_cast<size_t>(N));
         for (int a = 0; a < 3; ++a) {
             if (a < d) {

@@ -15,6 +15,7 @@
 #include "kernels.hpp"
 #include "operators.hpp"
 #include "tree.hpp"
+#include "tree_device.hpp"
 
 namespace bbfmm {
 
@@ -129,6 +130,7 @@ class FmmTree {
     const char *last_error() const { return err_.c_str(); }
     hipStream_t stream() const { return stream_; }
     bool host_only() const { return host_only_; }
+    bool tree_built_on_device() const { return tree_built_on_device_; }
     void stats(bbfmm_tree_stats *out) const;
     void set_profiling(bool on) { profiling_ = on; }
     // Resolves the recorded event pairs (synchronises the stream) and returns the totals.
@@ -180,6 +182,8 @@ class FmmTree {
     // ---- host state
     std::string err_;
     bool host_only_ = false;
+    bool tree_built_on_device_ = false;
+    DevTreePoints dev_points_; // left by the device tree build until upload() has gathered the sorted sources
     int order_ = 0, d_ = 0;
     KernelSpec kernel_{};
     bbfmm_params params_{};

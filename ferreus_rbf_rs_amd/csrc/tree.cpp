@@ -37,13 +37,7 @@ void KeyTable::build(const std::vector<uint64_t> &keys) {
 
 namespace {
 
-struct TmpCell {
-    uint64_t key;
-    int32_t level;
-    int32_t parent;
-    int64_t b, e;
-    bool leaf;
-};
+using TmpCell = BuildCell;
 
 inline uint64_t point_key(const double *pts, int64_t ld, int64_t i, int d, const double *disp,
                           double side, uint64_t level) {
@@ -411,7 +405,18 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
             if (c.leaf && c.e - c.b > 1) std::sort(t.order.begin() + c.b, t.order.begin() + c.e);
         });
     timer.lap("subdivision");
+    finish_tree(cells, out);
+}
 
+// Cell numbering, geometry, children, key table, interaction lists: everything after the subdivision
+// (t.d, t.center, t.radius, t.n_points, t.adaptive, t.depth and t.order are set).  Shared by the host build
+// above and the device build (tree_device.hip), whose cells arrive already in (level, key) order.
+void finish_tree(const std::vector<BuildCell> &cells, HostTree *out) {
+    TreeTimer timer;
+    HostTree &t = *out;
+    const int d = t.d;
+    const double radius = t.radius;
+    const bool adaptive_tree = t.adaptive;
     // number the cells by (level, key)
     const int64_t C = static_cast<int64_t>(cells.size());
     std::vector<int32_t> perm(C);

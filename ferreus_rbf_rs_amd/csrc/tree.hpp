@@ -82,6 +82,16 @@ struct HostTree {
     int64_t n_cells() const { return static_cast<int64_t>(key.size()); }
 };
 
+// A cell as the subdivision produces it (before numbering).
+struct BuildCell {
+    uint64_t key;
+    int32_t level;
+    int32_t parent; // index into the same array, -1 for the root
+    int64_t b, e;   // range of the hierarchically ordered points
+    bool leaf;
+};
+void finish_tree(const std::vector<BuildCell> &cells, HostTree *out);
+
 // linear_tree.rs:20-175 (+ 177-485 for the lists).  pts: n x d column-major (ld).
 void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *center, double radius,
                 int64_t max_points_per_cell, bool store_empty_leaves, bool adaptive_tree,

@@ -311,6 +311,9 @@ class FmmTree:
         self._raise(self._lib.bbfmm_get_tree_stats(self._h, ctypes.byref(s)))
         return s
 
+    def tree_built_on_device(self) -> bool:
+        return bool(self._lib.bbfmm_tree_built_on_device(self._h))
+
     def cells(self):
         s = self.stats()
         keys = np.zeros(s.n_cells, dtype=np.uint64)

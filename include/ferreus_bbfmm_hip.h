@@ -209,6 +209,10 @@ typedef struct {
 } bbfmm_tree_stats;
 
 int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out);
+/* 1 when the source tree (linear_tree.rs:20-175: Morton codes, sort, subdivision, per-leaf point lists) was built
+ * on the device, 0 when the host build ran (BBFMM_FLAG_HOST_ONLY, BBFMM_TREE_DEVICE=0, or a source point outside
+ * the root box).  Both produce the same tree; tests compare them. */
+int bbfmm_tree_built_on_device(const bbfmm_handle *h);
 
 /* Cells in (level, key) order: Morton key (morton.rs:58-119), leaf flag. */
 int bbfmm_get_cells(const bbfmm_handle *h, uint64_t *keys, uint8_t *is_leaf);
