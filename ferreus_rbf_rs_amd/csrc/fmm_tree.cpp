@@ -270,7 +270,12 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
         if (brc < 0) return hip_fail(static_cast<hipError_t>(-brc), "device tree build");
         if (brc == 0) {
             timer.lap("tree: subdivision (device)");
-            finish_tree(cells, &tree_);
+            finish_tree(cells, &tree_, false);
+            timer.lap("tree: numbering (host)");
+            const int lrc = build_lists_device(&tree_, stream_);
+            if (lrc < 0) return hip_fail(static_cast<hipError_t>(-lrc), "device interaction lists");
+            if (lrc == 1) build_lists_host(&tree_);
+            timer.lap(lrc == 0 ? "tree: lists (device)" : "tree: lists (host)");
             tree_built_on_device_ = true;
         }
     }

@@ -411,12 +411,11 @@ void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *c
 // Cell numbering, geometry, children, key table, interaction lists: everything after the subdivision
 // (t.d, t.center, t.radius, t.n_points, t.adaptive, t.depth and t.order are set).  Shared by the host build
 // above and the device build (tree_device.hip), whose cells arrive already in (level, key) order.
-void finish_tree(const std::vector<BuildCell> &cells, HostTree *out) {
+void finish_tree(const std::vector<BuildCell> &cells, HostTree *out, bool with_lists) {
     TreeTimer timer;
     HostTree &t = *out;
     const int d = t.d;
     const double radius = t.radius;
-    const bool adaptive_tree = t.adaptive;
     // number the cells by (level, key)
     const int64_t C = static_cast<int64_t>(cells.size());
     std::vector<int32_t> perm(C);
@@ -466,7 +465,16 @@ void finish_tree(const std::vector<BuildCell> &cells, HostTree *out) {
     t.table.build(t.key);
     timer.lap("numbering, children");
 
-    if (adaptive_tree)
+    if (with_lists) build_lists_host(out);
+}
+
+// linear_tree.rs:177-485 and the M2L transfer index of every V pair
+void build_lists_host(HostTree *out) {
+    TreeTimer timer;
+    HostTree &t = *out;
+    const int d = t.d;
+    const int64_t C = t.n_cells();
+    if (t.adaptive)
         interaction_lists_adaptive(t);
     else
         interaction_lists_regular(t);

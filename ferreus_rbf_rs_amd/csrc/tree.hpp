@@ -90,7 +90,8 @@ struct BuildCell {
     int64_t b, e;   // range of the hierarchically ordered points
     bool leaf;
 };
-void finish_tree(const std::vector<BuildCell> &cells, HostTree *out);
+void finish_tree(const std::vector<BuildCell> &cells, HostTree *out, bool with_lists = true);
+void build_lists_host(HostTree *out); // U / V / W / X + v_tidx (linear_tree.rs:177-485)
 
 // linear_tree.rs:20-175 (+ 177-485 for the lists).  pts: n x d column-major (ld).
 void build_tree(const double *pts, int64_t n, int64_t ld, int d, const double *center, double radius,

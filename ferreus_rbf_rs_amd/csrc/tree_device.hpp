@@ -28,4 +28,9 @@ int build_tree_cells_device(const double *pts, int64_t n, int64_t ld, int d, con
                             int64_t max_points_per_cell, bool store_empty_leaves, bool adaptive_tree, HostTree *out,
                             std::vector<BuildCell> *cells, DevTreePoints *dev_points, hipStream_t s);
 
+// U / V / W / X lists and v_tidx of a numbered tree (finish_tree(..., with_lists = false) has run) on the device.
+// Returns 0 on success, 1 when the device path does not apply (more than 2^31 - 1 entries in a list: use
+// build_lists_host), < 0 on a HIP error.
+int build_lists_device(HostTree *tree, hipStream_t s);
+
 } // namespace bbfmm
