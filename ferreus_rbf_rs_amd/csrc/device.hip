@@ -1682,6 +1682,50 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
     m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
 }
 
+// ------------------------------------------------------------------ stacked M2L operators, assembled in HBM
+// fmm_tree.cpp fill_m2l_operator_arrays on the device: the reference operators of a level (16 in 3-D) and the
+// symmetry tables go up once (MBs), the stacked per-class operators (GBs) are gathered from them here instead
+// of being filled on the host and sent over PCIe.  VtAll[m][first_row(t) + kk] = Vt_ref(t)[kk][invperm_t[m]]
+// (identity rows when uncompressed); UAll[tgt_off(t) + kk][i] = U_ref(t)[invperm_t[i]][kk].
+__global__ __launch_bounds__(256) void assemble_vt_kernel(M2lAssembleClass c, int n, int n_pad, int compressed,
+                                                          const double *__restrict__ ops, const int32_t *__restrict__ invperm,
+                                                          double *__restrict__ vt_all) {
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= static_cast<int64_t>(c.n_src) * n) return;
+    const int pos = static_cast<int>(t / n), m = static_cast<int>(t % n);
+    const M2lAssembleTv tv = c.src[pos];
+    const int im = invperm[static_cast<int64_t>(tv.perm) * n + m];
+    double *dst = vt_all + static_cast<int64_t>(m) * c.r_pad16 + tv.row;
+    if (compressed) {
+        const double *src = ops + tv.vt_off + static_cast<int64_t>(im) * tv.rank;
+        for (int kk = 0; kk < tv.rank; ++kk) dst[kk] = src[kk];
+    } else {
+        dst[im] = 1.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void assemble_u_kernel(M2lAssembleClass c, int n, int n_pad, const double *__restrict__ ops,
+                                                         const int32_t *__restrict__ invperm, double *__restrict__ u_all) {
+    const int pos = blockIdx.y;
+    const M2lAssembleTv tv = c.tgt[pos];
+    const int64_t t = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (t >= static_cast<int64_t>(tv.rank) * n) return;
+    const int kk = static_cast<int>(t / n), i = static_cast<int>(t % n);
+    u_all[static_cast<int64_t>(tv.row + kk) * n_pad + i] = ops[tv.u_off + static_cast<int64_t>(kk) * n + invperm[static_cast<int64_t>(tv.perm) * n + i]];
+}
+
+void launch_m2l_assemble(const M2lAssembleClass &c, int n, int n_pad, bool compressed, const double *ops,
+                         const int32_t *invperm, double *vt_all, double *u_all, hipStream_t s) {
+    (void)hipMemsetAsync(vt_all, 0, static_cast<size_t>(n_pad) * c.r_pad16 * sizeof(double), s);
+    (void)hipMemsetAsync(u_all, 0, static_cast<size_t>(c.k_pad) * n_pad * sizeof(double), s);
+    if (c.n_src > 0)
+        hipLaunchKernelGGL(assemble_vt_kernel, dim3(grid_for(static_cast<int64_t>(c.n_src) * n, 256)), dim3(256), 0, s, c, n, n_pad,
+                           compressed ? 1 : 0, ops, invperm, vt_all);
+    if (c.n_tgt > 0 && c.max_rank > 0)
+        hipLaunchKernelGGL(assemble_u_kernel, dim3(grid_for(static_cast<int64_t>(c.max_rank) * n, 256), c.n_tgt), dim3(256), 0, s, c,
+                           n, n_pad, ops, invperm, u_all);
+}
+
 // ------------------------------------------------------------------ MFMA self test
 // Four independent 4x4x4 products: A[b][i][k], B[b][k][j], D[b][i][j] (row-major per block).
 __global__ void mfma_layout_kernel(const double *A, const double *B, double *D) {

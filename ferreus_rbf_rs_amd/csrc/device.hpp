@@ -95,6 +95,21 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
                        const uint16_t *qlist, double *L, hipStream_t s);
 
+// Assembly of one class's stacked operators on the device (device.hip "stacked M2L operators").
+struct M2lAssembleTv { // one transfer vector of a class list
+    int32_t perm;    // symmetry permutation (row of invperm)
+    int32_t rank;
+    int32_t row;     // source side: first stacked row; target side: offset inside the slot
+    int64_t vt_off;  // offsets of the reference operator's factors inside the level's operator buffer
+    int64_t u_off;
+};
+struct M2lAssembleClass {
+    const M2lAssembleTv *src, *tgt; // device arrays
+    int32_t n_src, n_tgt, r_pad16, k_pad, max_rank;
+};
+void launch_m2l_assemble(const M2lAssembleClass &c, int n, int n_pad, bool compressed, const double *ops,
+                         const int32_t *invperm, double *vt_all, double *u_all, hipStream_t s);
+
 // Direct (kernel-evaluating) interactions.  Targets are sorted by leaf; job i handles
 // the targets [tgt_begin[i], tgt_end[i]) of leaf job_cell[i] against the source runs
 // runs[run_ptr[cell] .. run_ptr[cell+1]) (pairs of [begin, end) into the sorted sources;

@@ -217,29 +217,47 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
     if (params_.compression_type < 0 || params_.compression_type > 2)
         return fail(BBFMM_BAD_ARGUMENT, "unknown compression_type");
 
+    StageTimer timer;
     pts_.resize(static_cast<size_t>(n) * d);
-    for (int a = 0; a < d; ++a) std::copy(pts + a * ld, pts + a * ld + n, pts_.begin() + static_cast<size_t>(a) * n);
+    for (int a = 0; a < d; ++a)
+        parallel_for_chunks(n, int64_t(1) << 18, [&](int64_t b, int64_t e) {
+            std::memcpy(&pts_[static_cast<size_t>(a) * n + b], pts + a * ld + b, static_cast<size_t>(e - b) * sizeof(double));
+        });
 
     double ext[6];
     if (extents) {
         std::copy(extents, extents + 2 * d, ext);
-    } else { // utils.rs:13-46
+    } else { // utils.rs:13-46 (min / max per axis: chunk results combined in order)
+        constexpr int64_t kChunkE = int64_t(1) << 18;
+        const int64_t nch = (n + kChunkE - 1) / kChunkE;
+        std::vector<double> lo_c(static_cast<size_t>(nch)), hi_c(static_cast<size_t>(nch));
         for (int a = 0; a < d; ++a) {
             const double *col = &pts_[static_cast<size_t>(a) * n];
-            double lo = col[0], hi = col[0];
-            for (int64_t i = 1; i < n; ++i) {
-                if (col[i] < lo) lo = col[i];
-                if (col[i] > hi) hi = col[i];
+            parallel_for_chunks(n, kChunkE, [&](int64_t b, int64_t e) {
+                for (int64_t c0 = b; c0 < e; c0 += kChunkE) {
+                    double lo = col[c0], hi = col[c0];
+                    for (int64_t i = c0 + 1; i < std::min(e, c0 + kChunkE); ++i) {
+                        if (col[i] < lo) lo = col[i];
+                        if (col[i] > hi) hi = col[i];
+                    }
+                    lo_c[static_cast<size_t>(c0 / kChunkE)] = lo;
+                    hi_c[static_cast<size_t>(c0 / kChunkE)] = hi;
+                }
+            });
+            double lo = lo_c[0], hi = hi_c[0];
+            for (int64_t c = 1; c < nch; ++c) {
+                if (lo_c[static_cast<size_t>(c)] < lo) lo = lo_c[static_cast<size_t>(c)];
+                if (hi_c[static_cast<size_t>(c)] > hi) hi = hi_c[static_cast<size_t>(c)];
             }
             ext[a] = lo;
             ext[d + a] = hi;
         }
     }
+    timer.lap("copy points, extents");
     double center[3] = {0, 0, 0}, radius = 0;
     calculate_tree_center_and_radius(ext, d, center, &radius);
     if (!(radius > 0.0) || !std::isfinite(radius)) return fail(BBFMM_BAD_ARGUMENT, "degenerate or non-finite extents");
 
-    StageTimer timer;
     if (!host_only_) {
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -255,6 +273,7 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
         HIPCHK(hipStreamCreate(&stream2_));
         HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        timer.lap("device, streams");
     }
     // The subdivision (Morton codes, sort, cells, per-leaf point lists) runs on the device when there is one and
     // every point lies inside the root box; the host build (tree.cpp) is the bit-exact checker and the fallback.
@@ -745,27 +764,29 @@ int FmmTree::upload() {
         CHK(dupload(&d_x_job_run_ptr_, job_ptr));
         CHK(dupload(&d_x_runs_, job_runs));
     }
+    StageTimer ut;
+    HIPCHK(hipStreamSynchronize(stream_));
+    ut.lap("  upload: tree, run lists");
     // M2L tables
     m2l_classes_h_.resize(m2l_host_.size());
-    // the stacked operators (GBs at p = 9) are filled straight into two halves of the pinned staging buffer:
-    // the fill of one class runs beside the DMA of the previous one
-    size_t max_vt = 0, max_u = 0;
-    for (const HostM2lClass &h : m2l_host_) {
-        if (h.cells.empty()) continue;
-        max_vt = std::max(max_vt, static_cast<size_t>(cheb_.n_pad) * h.r_pad16);
-        max_u = std::max(max_u, static_cast<size_t>(h.k_pad) * cheb_.n_pad);
-    }
-    CHK(ensure_pinned(2 * (max_vt + max_u)));
-    hipEvent_t ev_buf[2] = {nullptr, nullptr};
-    for (hipEvent_t &e : ev_buf) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    struct EvGuard {
-        hipEvent_t *e;
-        ~EvGuard() {
-            for (int i = 0; i < 2; ++i)
-                if (e[i]) (void)hipEventDestroy(e[i]);
+    // The stacked operators (GBs at p = 9) are gathered on the device from the levels' reference operators and
+    // the symmetry tables (MBs): per level one buffer [U_ref | Vt_ref] of all reference vectors.
+    const bool compressed = ops_.compression != kCompressionNone;
+    DevBuf<int32_t> d_invperm;
+    CHK(dupload(&d_invperm, ops_.invperm));
+    std::vector<DevBuf<double>> d_level_ops(ops_.m2l.size());
+    std::vector<std::vector<int64_t>> u_off(ops_.m2l.size()), vt_off(ops_.m2l.size());
+    for (size_t lv = 0; lv < ops_.m2l.size(); ++lv) {
+        std::vector<double> buf;
+        for (const M2lOperator &op : ops_.m2l[lv]) {
+            u_off[lv].push_back(static_cast<int64_t>(buf.size()));
+            buf.insert(buf.end(), op.u.begin(), op.u.end());
+            vt_off[lv].push_back(static_cast<int64_t>(buf.size()));
+            buf.insert(buf.end(), op.vt.begin(), op.vt.end());
         }
-    } ev_guard{ev_buf};
-    int n_filled = 0;
+        if (!buf.empty()) CHK(dupload(&d_level_ops[lv], buf));
+    }
+    std::vector<DevBuf<M2lAssembleTv>> assemble_tmp; // per-class tv tables: released once the kernels have run
     for (size_t i = 0; i < m2l_host_.size(); ++i) {
         HostM2lClass &h = m2l_host_[i];
         M2lClass &c = m2l_classes_h_[i];
@@ -780,17 +801,33 @@ int FmmTree::upload() {
         DevBuf<int32_t> rt, ro, ce, cs;
         DevBuf<int64_t> cb;
         {
-            const int b = n_filled & 1;
-            double *pvt = h_pin_ + static_cast<size_t>(b) * (max_vt + max_u), *pu = pvt + max_vt;
-            if (n_filled >= 2) HIPCHK(hipEventSynchronize(ev_buf[b])); // the copy that last read this half is done
-            fill_m2l_operator_arrays(h, pvt, pu);
             const size_t nvt = static_cast<size_t>(cheb_.n_pad) * h.r_pad16, nu = static_cast<size_t>(h.k_pad) * cheb_.n_pad;
             CHK(dalloc(&vt, nvt));
             CHK(dalloc(&ua, nu));
-            HIPCHK(hipMemcpyAsync(vt.p, pvt, nvt * sizeof(double), hipMemcpyHostToDevice, stream_));
-            HIPCHK(hipMemcpyAsync(ua.p, pu, nu * sizeof(double), hipMemcpyHostToDevice, stream_));
-            HIPCHK(hipEventRecord(ev_buf[b], stream_));
-            ++n_filled;
+            const auto &lops = ops_.m2l[h.level];
+            std::vector<M2lAssembleTv> src_tv, tgt_tv;
+            int row = 0, max_rank = 0;
+            for (int tv : h.src_tv) {
+                const int ref = ops_.ref_lookup[tv];
+                const int rank = lops[ref].rank;
+                src_tv.push_back(M2lAssembleTv{ops_.perm_lookup[tv], rank, row, vt_off[h.level][ref], u_off[h.level][ref]});
+                row += round_up(rank, 2);
+            }
+            for (size_t pos = 0; pos < h.tgt_tv.size(); ++pos) {
+                const int tv = h.tgt_tv[pos];
+                const int ref = ops_.ref_lookup[tv];
+                const int rank = lops[ref].rank;
+                max_rank = std::max(max_rank, rank);
+                tgt_tv.push_back(M2lAssembleTv{ops_.perm_lookup[tv], rank, h.tgt_off[pos], vt_off[h.level][ref], u_off[h.level][ref]});
+            }
+            DevBuf<M2lAssembleTv> d_src, d_tgt;
+            CHK(dupload(&d_src, src_tv));
+            CHK(dupload(&d_tgt, tgt_tv));
+            const M2lAssembleClass ac{d_src.p, d_tgt.p, static_cast<int32_t>(src_tv.size()), static_cast<int32_t>(tgt_tv.size()),
+                                      h.r_pad16, h.k_pad, max_rank};
+            launch_m2l_assemble(ac, ops_.n, cheb_.n_pad, compressed, d_level_ops[h.level].p, d_invperm.p, vt.p, ua.p, stream_);
+            assemble_tmp.push_back(d_src);
+            assemble_tmp.push_back(d_tgt);
         }
         CHK(dupload(&rt, h.row_dst));
         CHK(dupload(&ro, h.blk_t0));
@@ -806,7 +843,12 @@ int FmmTree::upload() {
         c.cbase = cb.p;
         std::vector<int32_t>().swap(h.cslot); // only needed for uploading
     }
-    HIPCHK(hipStreamSynchronize(stream_)); // the last operator copies have left the staging buffer
+    HIPCHK(hipStreamSynchronize(stream_)); // the assembly kernels have read their tables
+    HIPCHK(hipGetLastError());
+    for (auto &b : assemble_tmp) dfree(&b);
+    for (auto &b : d_level_ops) dfree(&b);
+    dfree(&d_invperm);
+    ut.lap("  upload: M2L operators, tables");
     CHK(dupload(&d_m2l_classes_, m2l_classes_h_));
     CHK(dupload(&d_m2l_tiles_, m2l_tiles_h_));
     m2l_tiles2_h_ = m2l_tiles_h_;
