@@ -319,12 +319,35 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
               [&](int32_t a, int32_t b) { return t.pt_begin[a] < t.pt_begin[b]; });
     u_runs_.ptr.assign(C + 1, 0);
     x_runs_.ptr.assign(C + 1, 0);
-    for (int64_t c = 0; c < C; ++c) {
-        merged_runs(t, t.u.idx.data() + t.u.ptr[c], t.u.ptr[c + 1] - t.u.ptr[c], &u_runs_.idx);
-        u_runs_.ptr[c + 1] = static_cast<int64_t>(u_runs_.idx.size() / 2);
-        merged_runs(t, t.x.idx.data() + t.x.ptr[c], t.x.ptr[c + 1] - t.x.ptr[c], &x_runs_.idx);
-        x_runs_.ptr[c + 1] = static_cast<int64_t>(x_runs_.idx.size() / 2);
-        if (x_runs_.ptr[c + 1] > x_runs_.ptr[c]) x_cells_.push_back(static_cast<int32_t>(c));
+    { // per chunk of cells into local buffers (threads), concatenated in order
+        constexpr int64_t kChunkR = 4096;
+        const int64_t nch = (C + kChunkR - 1) / kChunkR;
+        std::vector<std::vector<int32_t>> ub(static_cast<size_t>(nch)), xb(static_cast<size_t>(nch));
+        parallel_for_chunks(C, kChunkR, [&](int64_t lo, int64_t hi) {
+            for (int64_t c0 = lo; c0 < hi; c0 += kChunkR) {
+                auto &uu = ub[static_cast<size_t>(c0 / kChunkR)];
+                auto &xx = xb[static_cast<size_t>(c0 / kChunkR)];
+                for (int64_t c = c0; c < std::min(hi, c0 + kChunkR); ++c) {
+                    const size_t u0 = uu.size(), x0 = xx.size();
+                    merged_runs(t, t.u.idx.data() + t.u.ptr[c], t.u.ptr[c + 1] - t.u.ptr[c], &uu);
+                    merged_runs(t, t.x.idx.data() + t.x.ptr[c], t.x.ptr[c + 1] - t.x.ptr[c], &xx);
+                    u_runs_.ptr[c + 1] = static_cast<int64_t>((uu.size() - u0) / 2); // counts, scanned below
+                    x_runs_.ptr[c + 1] = static_cast<int64_t>((xx.size() - x0) / 2);
+                }
+            }
+        });
+        for (int64_t c = 0; c < C; ++c) {
+            if (x_runs_.ptr[c + 1] > 0) x_cells_.push_back(static_cast<int32_t>(c));
+            u_runs_.ptr[c + 1] += u_runs_.ptr[c];
+            x_runs_.ptr[c + 1] += x_runs_.ptr[c];
+        }
+        u_runs_.idx.resize(static_cast<size_t>(2 * u_runs_.ptr[C]));
+        x_runs_.idx.resize(static_cast<size_t>(2 * x_runs_.ptr[C]));
+        parallel_for(nch, 1, [&](int64_t ch) {
+            const int64_t c0 = ch * kChunkR;
+            std::copy(ub[static_cast<size_t>(ch)].begin(), ub[static_cast<size_t>(ch)].end(), u_runs_.idx.begin() + 2 * u_runs_.ptr[c0]);
+            std::copy(xb[static_cast<size_t>(ch)].begin(), xb[static_cast<size_t>(ch)].end(), x_runs_.idx.begin() + 2 * x_runs_.ptr[c0]);
+        });
     }
     part_rows_.clear();
     timer.lap("run lists");
