@@ -157,8 +157,12 @@ def cpu_baseline(args, kernel_id):
     """Times the CPU restatement of the reference algorithm (oracle/, kind "port": C + OpenMP
     passes over a Python-built tree) on a bounded sample: a cloud 64x smaller than the workload,
     which has the same leaf occupancy and list structure two levels shallower; the BBFMM matvec
-    is O(N), so the rate is scaled by the point ratio (validated once at the full 10M points:
-    profiles/r02_cpu_port_full_10M.json)."""
+    is O(N), so the rate is scaled by the point ratio.  The sample is run at the host's full thread
+    count and at a half and a quarter of it (small problems do not always like every hardware thread);
+    the fastest is reported with its thread count.  Run once at the full 10M points the same code
+    measured 46.9 s per matvec = 0.021 matvecs/s on 256 threads
+    (scripts/cpu_port_full_size.py -> profiles/r02_cpu_port_full_10M.json): the scaled sample flatters the
+    CPU by about 2x (caches), which only makes the reported baseline conservative for the GPU."""
     from oracle import bbfmm_oracle as O
     n_cpu = args.cpu_points or max(20000, args.points // 64)
     rng = np.random.default_rng(42)
@@ -166,26 +170,35 @@ def cpu_baseline(args, kernel_id):
     w = np.random.default_rng(43).random((n_cpu, args.nrhs))
     tree = O.FmmTree(pts, args.order, kernel_id, True, True, base_range=args.base_range,
                      total_sill=args.total_sill)
-    tree.set_weights(w)                      # warm-up
-    tree.evaluate(w, pts)
-    times = []
-    t_end = time.time() + 25.0
-    while len(times) < 5 and (len(times) < 2 or time.time() < t_end):
-        t0 = time.time()
-        tree.set_weights(w)
+    hw = int(O.lib().oracle_num_threads())
+    best = None
+    for threads in sorted({hw, max(hw // 2, 1), max(hw // 4, 1)}, reverse=True):
+        O.lib().oracle_set_num_threads(threads)
+        tree.set_weights(w)                      # warm-up
         tree.evaluate(w, pts)
-        times.append(time.time() - t0)
-    t = float(np.median(times))
+        times = []
+        t_end = time.time() + 8.0
+        while len(times) < 5 and (len(times) < 2 or time.time() < t_end):
+            t0 = time.time()
+            tree.set_weights(w)
+            tree.evaluate(w, pts)
+            times.append(time.time() - t0)
+        t = float(np.median(times))
+        if best is None or t < best[0]:
+            best = (t, threads, len(times))
+    O.lib().oracle_set_num_threads(hw)
+    t, threads, reps = best
     scale = n_cpu / float(args.points)
     return {
         "value": (1.0 / t) * scale,
         "unit": "matvecs/s",
-        "cores": int(O.lib().oracle_num_threads()),
+        "cores": threads,
         "kind": "port",
         "sample": (f"CPU restatement of the reference algorithm (not the Rust binary): median of "
-                   f"{len(times)} matvecs on {n_cpu} uniform points ({t:.3f} s each, same kernel/"
-                   f"order/nrhs, same leaf occupancy as the {args.points}-point workload), rate "
-                   f"scaled by {n_cpu}/{args.points} (O(N) algorithm)"),
+                   f"{reps} matvecs on {n_cpu} uniform points ({t:.3f} s each on {threads} of {hw} threads, the "
+                   f"fastest of full / half / quarter thread counts; same kernel/order/nrhs, same leaf occupancy as "
+                   f"the {args.points}-point workload), rate scaled by {n_cpu}/{args.points} (O(N) algorithm); "
+                   f"measured once at the full 10M points: 0.021 matvecs/s (profiles/r02_cpu_port_full_10M.json)"),
     }
 
 

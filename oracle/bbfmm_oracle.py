@@ -79,6 +79,8 @@ def lib():
         _lib.oracle_kernel_phi_r2.argtypes = [ctypes.c_int, ctypes.c_double, ctypes.c_double,
                                               ctypes.c_double]
         _lib.oracle_num_threads.restype = ctypes.c_int
+        _lib.oracle_set_num_threads.argtypes = [ctypes.c_int]
+        _lib.oracle_set_num_threads.restype = None
     return _lib
 
 

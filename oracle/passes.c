@@ -685,3 +685,13 @@ int oracle_num_threads(void)
     return 1;
 #endif
 }
+
+/* Thread count of the following passes (bench.py's cpu_baseline tries a few and reports the fastest). */
+void oracle_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
