@@ -963,6 +963,89 @@ __global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *
     }
 }
 
+// multipole_to_particle and particle_to_local in one pass when targets = sources (one rhs): X = W^T
+// (linear_tree.rs:388-392), so the values phi(x_t, node) of a leaf's points against the Chebyshev nodes of its
+// W cells are exactly the values P2L needs for those cells' X lists.  Same scheme as p2p_sym_kernel with the
+// nodes of the W cells as columns: row sums (x M_W[node]) are M2P (bbfmm.rs:1254-1355), column sums (x w_t)
+// are P2L (bbfmm.rs:1001-1048), added to L with f64 atomics after M2L stage 2 has assigned it.
+struct WxJobs {
+    int n_jobs;
+    const int32_t *tgt_begin, *tgt_end; // rows of job i (sorted source positions, at most SYM_WAVES * SYM_TR, one leaf)
+    const int64_t *w_range;             // 2 per job: the leaf's range in w_cells
+    const int32_t *w_cells;
+};
+
+template <int KID>
+__global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, WxJobs jobs, const DevCheb *__restrict__ chp,
+                                                               const double *__restrict__ centers,
+                                                               const double *__restrict__ lengths, Xyz src,
+                                                               const double *__restrict__ ws, const double *__restrict__ M,
+                                                               double *__restrict__ L, double *__restrict__ out) {
+    __shared__ SymTile tile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int job = blockIdx.x;
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
+    const int rpw = (t1 - t0 + SYM_WAVES - 1) / SYM_WAVES;
+    const int r_lo = min(t0 + wave * rpw, t1);
+    const int nr = min(rpw, t1 - r_lo);
+    double tx[SYM_TR], ty[SYM_TR], tz[SYM_TR], tw[SYM_TR], racc[SYM_TR];
+#pragma unroll
+    for (int r = 0; r < SYM_TR; ++r) {
+        const int g = min(r_lo + min(r, max(nr - 1, 0)), t1 - 1);
+        tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g], tw[r] = ws[g];
+        racc[r] = 0.0;
+    }
+    const int64_t q0 = jobs.w_range[2 * job], q1 = jobs.w_range[2 * job + 1];
+    const int64_t total = (q1 - q0) * n;
+    for (int64_t base = 0; base < total; base += SYM_TILE) {
+        const int fill = static_cast<int>(min<int64_t>(SYM_TILE, total - base));
+        __syncthreads();
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
+            const int64_t P = base + j;
+            const int ci = static_cast<int>(P / n), I = static_cast<int>(P - static_cast<int64_t>(ci) * n);
+            const int cell = jobs.w_cells[q0 + ci];
+            const double half = lengths[cell] * 0.5;
+            const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1); // scale_cheb_nodes_to_cell, chebyshev.rs:951-968
+            tile.x[j] = centers[cell * 3] + half * chp->nodes[i0];
+            tile.y[j] = d > 1 ? centers[cell * 3 + 1] + half * chp->nodes[i1] : 0.0;
+            tile.z[j] = d > 2 ? centers[cell * 3 + 2] + half * chp->nodes[i2] : 0.0;
+            tile.w[j] = M[static_cast<int64_t>(cell) * n_pad + I];
+            tile.col[j] = 0.0;
+            tile.cidx[j] = cell * n_pad + I;
+        }
+        __syncthreads();
+        if (nr > 0) {
+            for (int j = lane; j < fill; j += 64) {
+                const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j], wj = tile.w[j];
+                double csum = 0.0;
+#pragma unroll
+                for (int r = 0; r < SYM_TR; ++r) {
+                    if (r < nr) {
+                        const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
+                        const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
+                        racc[r] += v * wj;
+                        csum += v * tw[r];
+                    }
+                }
+                unsafeAtomicAdd(&tile.col[j], csum);
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) unsafeAtomicAdd(&L[tile.cidx[j]], tile.col[j]);
+    }
+#pragma unroll
+    for (int r = 0; r < SYM_TR; ++r) {
+        if (r < nr) {
+            const double s = wave_sum(racc[r]);
+            if (lane == 0) unsafeAtomicAdd(&out[r_lo + r], s);
+        }
+    }
+}
+
 // particle_to_local (bbfmm.rs:1001-1048).  One workgroup per cell with an X list; the
 // targets are the cell's Chebyshev nodes.
 template <int KID, int KB>
@@ -1556,6 +1639,19 @@ void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, 
 }
 
 int p2p_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
+
+void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
+                   const int64_t *w_range, const int32_t *w_cells, const double *centers, const double *lengths,
+                   const double *const *src_xyz, const double *w_sorted, const double *M, double *L, double *out_sorted,
+                   hipStream_t s) {
+    if (n_jobs == 0) return;
+    const WxJobs jobs{n_jobs, tgt_begin, tgt_end, w_range, w_cells};
+    dispatch_kernel_id(ks.id, [&](auto idc) {
+        constexpr int ID = decltype(idc)::value;
+        hipLaunchKernelGGL((wx_sym_kernel<ID>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, ch.dev, centers, lengths,
+                           make_xyz(src_xyz), w_sorted, M, L, out_sorted);
+    });
+}
 
 void launch_m2p(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin,
                 const int32_t *tgt_end, const int64_t *w_begin, const int64_t *w_end,

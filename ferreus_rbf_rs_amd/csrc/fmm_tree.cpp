@@ -981,6 +981,27 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
             range.push_back(last);
         }
     }
+    ts->n_wx_jobs = 0;
+    if (pb == 0 && pe == t.n_points && !t.w.idx.empty() &&
+        static_cast<int64_t>(t.n_cells()) * cheb_.n_pad < (int64_t(1) << 31)) { // whole source set: M2P + P2L fused
+        std::vector<int32_t> wtb, wte;
+        std::vector<int64_t> wr;
+        for (size_t j = 0; j < job_cells.size(); ++j) {
+            const int32_t c = job_cells[j];
+            if (t.w.ptr[c + 1] == t.w.ptr[c]) continue;
+            const int64_t a0 = t.pt_begin[c], na = t.pt_end[c] - a0, nj = (na + max_rows - 1) / max_rows;
+            for (int64_t i = 0; i < nj; ++i) {
+                wtb.push_back(static_cast<int32_t>(a0 + na * i / nj));
+                wte.push_back(static_cast<int32_t>(a0 + na * (i + 1) / nj));
+                wr.push_back(t.w.ptr[c]);
+                wr.push_back(t.w.ptr[c + 1]);
+            }
+        }
+        ts->n_wx_jobs = static_cast<int>(wtb.size());
+        CHK(dupload(&ts->wx_tb, wtb));
+        CHK(dupload(&ts->wx_te, wte));
+        CHK(dupload(&ts->wx_range, wr));
+    }
     ts->n_sym_jobs = static_cast<int>(tb.size());
     CHK(dupload(&ts->sym_tb, tb));
     CHK(dupload(&ts->sym_te, te));
@@ -1197,6 +1218,10 @@ void FmmTree::free_target_set(TargetSet *ts) {
     dfree(&ts->sym_te);
     dfree(&ts->sym_ptr);
     dfree(&ts->sym_runs);
+    dfree(&ts->wx_tb);
+    dfree(&ts->wx_te);
+    dfree(&ts->wx_range);
+    ts->n_wx_jobs = 0;
     ts->sym = false;
 }
 
@@ -1259,7 +1284,7 @@ int FmmTree::upward(int k, const DownwardPlan *dp) {
 
 // downward_pass (bbfmm.rs:778-857).  All cells are treated as "with targets": locals of
 // cells without targets are never read by the leaf pass, so results are unchanged.
-int FmmTree::downward(int k, const DownwardPlan *dp) {
+int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
     // reset_local_coefficients (bbfmm.rs:627-632): tiles without any V-list entry are not written by
@@ -1285,7 +1310,10 @@ int FmmTree::downward(int k, const DownwardPlan *dp) {
                           cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, d_L_.p, stream_);
     phase_end(kPhM2L2);
     phase_begin();
-    if (t.adaptive) {
+    if (t.adaptive && wx) { // targets = all sources, one rhs: P2L and M2P share their kernel evaluations (X = W^T)
+        launch_wx_sym(kernel_, cheb_, wx->n_wx_jobs, wx->wx_tb.p, wx->wx_te.p, wx->wx_range.p, d_w_idx_.p, d_centers_.p,
+                      d_lengths_.p, src_ptr_, d_w_sorted_.p, d_M_.p, d_L_.p, wx->out.p, stream_);
+    } else if (t.adaptive) {
         if (dp)
             launch_p2l(kernel_, cheb_, dp->n_x_jobs, dp->d_x_cells.p, dp->d_x_ptr.p, dp->d_x_runs.p, d_centers_.p,
                        d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_L_.p, stream_);
@@ -1313,13 +1341,14 @@ int FmmTree::leaf_pass(const TargetSet &ts, int k, bool with_grads) {
 
 // P2P + M2P: need the weights and the multipoles only (can run beside the downward pass)
 // parts: 1 = zero the outputs + P2P (needs the sorted weights), 2 = M2P (needs the multipoles)
-int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts) {
+int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts, bool wx_done) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
     double *grad = with_grads ? ts.grad.p : nullptr;
     const bool timed = st == stream_;
     if (parts & 1) {
-        HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), st));
+        if (!wx_done) // (the fused M2P + P2L pass has already added into the zeroed output)
+            HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), st));
         if (with_grads) HIPCHK(hipMemsetAsync(grad, 0, static_cast<size_t>(k) * d_ * ts.m * sizeof(double), st));
         DirectJobs jobs{ts.n_jobs, ts.job_cell.p, ts.tgt_begin.p, ts.tgt_end.p, d_u_run_ptr_.p, d_u_runs_.p};
         static const bool sym_on = [] {
@@ -1336,7 +1365,7 @@ int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStre
     }
     if (parts & 2) {
         if (timed) phase_begin();
-        if (t.adaptive)
+        if (t.adaptive && !wx_done)
             launch_m2p(kernel_, cheb_, ts.n_w_jobs, ts.w_tgt_begin.p, ts.w_tgt_end.p, ts.w_begin.p, ts.w_end.p,
                        d_w_idx_.p, d_centers_.p, d_lengths_.p, ts.xyz_ptr, ts.m, k, C, d_M_.p, ts.out.p, grad, st);
         if (timed) phase_end(kPhM2P);
@@ -1501,9 +1530,17 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
         CHK(leaf_pass_far(ts, k, false));
     } else {
+        static const bool wx_on = [] {
+            const char *e = std::getenv("BBFMM_WX_FUSED"); // 0: separate P2L and M2P kernels
+            const char *e2 = std::getenv("BBFMM_P2P_SYM");
+            return (!e || std::atoi(e) != 0) && (!e2 || std::atoi(e2) != 0);
+        }();
+        const bool wx = wx_on && k == 1 && !have_part_ && ts.sym && ts.n_wx_jobs > 0;
         CHK(upward(k, plan));
-        CHK(downward(k, plan));
-        CHK(leaf_pass(ts, k, false));
+        if (wx) HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(ts.m) * sizeof(double), stream_));
+        CHK(downward(k, plan, wx ? &ts : nullptr));
+        CHK(leaf_pass_near(ts, k, false, stream_, 3, wx));
+        CHK(leaf_pass_far(ts, k, false));
     }
     phase_begin();
     launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);

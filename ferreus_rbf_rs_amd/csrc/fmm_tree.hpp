@@ -62,6 +62,10 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     DevBuf<int32_t> sym_tb, sym_te; // jobs: row chunks of the leaves
     DevBuf<int64_t> sym_ptr;        // 2 per job: run range of the job's leaf
     DevBuf<int32_t> sym_runs;
+    // M2P + P2L fused (whole source set only): row chunks of the leaves with a W list and their W ranges
+    int n_wx_jobs = 0;
+    DevBuf<int32_t> wx_tb, wx_te;
+    DevBuf<int64_t> wx_range;
 };
 
 // The part of the downward pass a set of target leaves needs (a partition of the sources, or the
@@ -159,9 +163,10 @@ class FmmTree {
     void fill_m2l_operator_arrays(const HostM2lClass &hc, double *vt_all, double *u_all) const;
     int ensure_rhs_capacity(int k);
     int upward(int k, const DownwardPlan *dp = nullptr); // P2M + M2M from w_sorted_ (a partition's plan: needed cells only)
-    int downward(int k, const DownwardPlan *dp = nullptr); // M2L + P2L + L2L into L_ (restricted by a plan)
+    // M2L + P2L + L2L into L_ (restricted by a plan); wx: run P2L fused with M2P into wx->out (zeroed by the caller)
+    int downward(int k, const DownwardPlan *dp = nullptr, const TargetSet *wx = nullptr);
     int leaf_pass(const TargetSet &ts, int k, bool with_grads);
-    int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts);
+    int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts, bool wx_done = false);
     int leaf_pass_far(const TargetSet &ts, int k, bool with_grads);
     int build_target_set(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
                          std::vector<int32_t> *leaves_out = nullptr);

@@ -273,12 +273,16 @@ def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs):
     out = torch.zeros((nrhs, n), dtype=torch.float64, device="cuda")
     t.matvec_device(dw.data_ptr(), n, nrhs, out.data_ptr(), n, True)
     y_sym = out.cpu().numpy().T
+    L_sym = t.debug_get_coefficients("L", nrhs)          # one rhs: P2L ran fused with M2P (X = W^T), atomically into L
     t.set_weights(w)
     y_ord = t.evaluate(w, pts)
     r.set_weights(w)
     yr = r.evaluate(w, pts)
     assert relerr(y_sym, y_ord) < 1e-12
     assert relerr(y_sym, yr) < TOL
+    assert relerr(L_sym, r.L) < TOL
+    if d == 3 and kid != 7:
+        assert t.stats().n_w > 0                          # the W / X lists are live in these trees
     # a 3-way partition of the same product: one- and two-sided runs at the partition boundaries
     acc = torch.full((nrhs, n), float("nan"), dtype=torch.float64, device="cuda")
     for rank in range(3):
