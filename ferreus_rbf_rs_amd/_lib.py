@@ -81,6 +81,7 @@ SIGNATURES = {
     "bbfmm_mfma_f64_selftest": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_debug_dense_m2m": (ctypes.c_int, [c_p, c_i32, c_p]),
     "bbfmm_debug_apply_m2l_tables_host": (ctypes.c_int, [c_p, c_p, c_p]),
+    "bbfmm_debug_m2l_variants": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_debug_get_coefficients": (ctypes.c_int, [c_p, ctypes.c_char, c_i32, c_p]),
     "bbfmm_debug_morton_encode": (ctypes.c_uint64, [c_i32, c_p, ctypes.c_uint64]),
     "bbfmm_debug_morton_decode": (None, [c_i32, ctypes.c_uint64, c_p, c_p]),

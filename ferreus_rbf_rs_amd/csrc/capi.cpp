@@ -366,6 +366,15 @@ int bbfmm_debug_reference_vectors(const bbfmm_handle *h, int32_t *out, int32_t *
     return BBFMM_OK;
 }
 
+int bbfmm_debug_m2l_variants(const bbfmm_handle *h, int64_t *n_variants, int64_t *n_cells) {
+    if (!h) return BBFMM_BAD_ARGUMENT;
+    int64_t nv = 0, nc = 0;
+    h->tree.m2l_variant_stats(&nv, &nc);
+    if (n_variants) *n_variants = nv;
+    if (n_cells) *n_cells = nc;
+    return BBFMM_OK;
+}
+
 int bbfmm_debug_get_coefficients(bbfmm_handle *h, char which, int32_t k, double *out) {
     GUARD(h) return h->tree.debug_get_coefficients(which, k, out);
     END_GUARD(h)

@@ -457,6 +457,9 @@ int FmmTree::build_m2l_tables() {
     const int ncls = 1 << d, nvec = ops_.n_vec;
     const bool compressed = ops_.compression != kCompressionNone;
     m2l_host_.clear();
+    m2l_variants_.clear();
+    m2l_tiles1_h_.clear();
+    m2l_tile_idx1_h_.clear();
     m2l_classes_h_.clear();
     m2l_tiles_h_.clear();
     m2l_qlist_h_.clear();
@@ -518,6 +521,55 @@ int FmmTree::build_m2l_tables() {
             k_pad[o] = round_up(std::max(off, 16), 16);
         }
         const size_t first_class = m2l_host_.size();
+        // Stage-1 row tables of a class-o operator stacked over the transfer vectors `tvs` (the whole admissible
+        // list for the class itself, the present ones for a boundary variant): every transfer vector's rows
+        // start at an even stacked row (the scatter stores pairs of adjacent rows as 16 bytes).
+        auto stage1_rows = [&](int o, const std::vector<int> &tvs, HostM2lClass *hcp) {
+            HostM2lClass &hc = *hcp;
+            hc.n_t = static_cast<int>(tvs.size());
+            hc.n_rows = 0;
+            for (int tv : tvs) hc.n_rows += round_up(rank_of(tv), 2);
+            hc.r_pad16 = round_up(std::max(hc.n_rows, 1), kM2lS1Block);
+            hc.row_tpos.assign(hc.r_pad16, -1);
+            hc.row_off.assign(hc.r_pad16, 0);
+            hc.src_tv = tvs;
+            int row = 0;
+            hc.src_row0.assign(tvs.size(), 0);
+            hc.src_row1.assign(tvs.size(), 0);
+            for (size_t pos = 0; pos < tvs.size(); ++pos) {
+                const int tv = tvs[pos];
+                const int oc = target_class(o, tv);
+                const int base_off = off_tgt[oc][tpos_tgt[oc][tv]];
+                hc.src_row0[pos] = row;
+                for (int kk = 0; kk < rank_of(tv); ++kk, ++row) {
+                    hc.row_tpos[row] = static_cast<int32_t>(pos);
+                    hc.row_off[row] = base_off + kk;
+                }
+                hc.src_row1[pos] = row;
+                row = round_up(row, 2); // the padding row keeps tpos -1 (never stored on its own)
+            }
+            // per column block: first transfer-vector position, and the packed row table
+            const int n_blk = hc.r_pad16 / kM2lS1Block;
+            hc.blk_t0.assign(n_blk, 0);
+            hc.row_dst.assign(hc.r_pad16, -1);
+            for (int b = 0; b < n_blk; ++b) {
+                int t0 = -1, t1 = -1;
+                for (int r = b * kM2lS1Block; r < (b + 1) * kM2lS1Block; ++r) {
+                    if (hc.row_tpos[r] < 0) continue;
+                    if (t0 < 0) t0 = hc.row_tpos[r];
+                    t1 = hc.row_tpos[r];
+                }
+                if (t0 < 0) continue;
+                hc.blk_t0[b] = t0;
+                m2l_slot_t_ = std::max(m2l_slot_t_, t1 - t0 + 1);
+                for (int r = b * kM2lS1Block; r < (b + 1) * kM2lS1Block; ++r) {
+                    if (hc.row_tpos[r] < 0) continue;
+                    if (hc.row_off[r] >= (1 << 24)) return false;
+                    hc.row_dst[r] = ((hc.row_tpos[r] - t0) << 24) | hc.row_off[r];
+                }
+            }
+            return true;
+        };
         m2l_host_.resize(first_class + ncls);
         for (int64_t c = t.level_ptr[level]; c < t.level_ptr[level + 1]; ++c)
             m2l_host_[first_class + t.octant[c]].cells.push_back(static_cast<int32_t>(c));
@@ -555,52 +607,10 @@ int FmmTree::build_m2l_tables() {
             hc.n_t = static_cast<int>(src_list[o].size());
             hc.k_pad = k_pad[o];
             // stage 1 tall operator rows
-            hc.n_rows = 0;
-            // every transfer vector's rows start at an even stacked row (the stage-1 scatter stores
-            // pairs of adjacent rows as 16 bytes)
-            for (int tv : src_list[o]) hc.n_rows += round_up(rank_of(tv), 2);
-            hc.r_pad16 = round_up(std::max(hc.n_rows, 1), kM2lS1Block);
-            hc.row_tpos.assign(hc.r_pad16, -1);
-            hc.row_off.assign(hc.r_pad16, 0);
+            if (!stage1_rows(o, src_list[o], &hc)) return fail(BBFMM_BAD_ARGUMENT, "M2L slot too long for the packed row table");
             if (hc.cells.empty()) continue;
-            hc.src_tv = src_list[o];
             hc.tgt_tv = tgt_list[o];
             hc.tgt_off = off_tgt[o];
-            int row = 0;
-            hc.src_row0.assign(src_list[o].size(), 0);
-            hc.src_row1.assign(src_list[o].size(), 0);
-            for (size_t pos = 0; pos < src_list[o].size(); ++pos) {
-                const int tv = src_list[o][pos];
-                const int oc = target_class(o, tv);
-                const int base_off = off_tgt[oc][tpos_tgt[oc][tv]];
-                hc.src_row0[pos] = row;
-                for (int kk = 0; kk < rank_of(tv); ++kk, ++row) {
-                    hc.row_tpos[row] = static_cast<int32_t>(pos);
-                    hc.row_off[row] = base_off + kk;
-                }
-                hc.src_row1[pos] = row;
-                row = round_up(row, 2); // the padding row keeps tpos -1 (never stored on its own)
-            }
-            // per column block: first transfer-vector position, and the packed row table
-            const int n_blk = hc.r_pad16 / kM2lS1Block;
-            hc.blk_t0.assign(n_blk, 0);
-            hc.row_dst.assign(hc.r_pad16, -1);
-            for (int b = 0; b < n_blk; ++b) {
-                int t0 = -1, t1 = -1;
-                for (int r = b * kM2lS1Block; r < (b + 1) * kM2lS1Block; ++r) {
-                    if (hc.row_tpos[r] < 0) continue;
-                    if (t0 < 0) t0 = hc.row_tpos[r];
-                    t1 = hc.row_tpos[r];
-                }
-                if (t0 < 0) continue;
-                hc.blk_t0[b] = t0;
-                m2l_slot_t_ = std::max(m2l_slot_t_, t1 - t0 + 1);
-                for (int r = b * kM2lS1Block; r < (b + 1) * kM2lS1Block; ++r) {
-                    if (hc.row_tpos[r] < 0) continue;
-                    if (hc.row_off[r] >= (1 << 24)) return fail(BBFMM_BAD_ARGUMENT, "M2L slot too long for the packed row table");
-                    hc.row_dst[r] = ((hc.row_tpos[r] - t0) << 24) | hc.row_off[r];
-                }
-            }
             if (host_only_) fill_m2l_operator_arrays(hc, &hc.vt_all, &hc.u_all);
             hc.cbase.resize(hc.cells.size());
             for (size_t i = 0; i < hc.cells.size(); ++i) {
@@ -678,10 +688,107 @@ int FmmTree::build_m2l_tables() {
                 m2l_tiles_h_.push_back(td);
             }
         }
+            // ---- stage-1 variants (boundary classes).  A source cell computes the compressed vectors of ALL admissible
+        // transfer vectors of its class, also of those whose target does not exist (domain boundary, coarse
+        // neighbours): 6 % of the stage-1 flops of a uniform cube, far more on clustered data.  Cells of a class
+        // are sorted by V-list pattern, so cells that miss the same targets sit together: a run of at least one
+        // full tile of such cells gets its own stacked operator with the missing transfer vectors left out (the
+        // same reference operators, gathered on the device); the remaining cells keep the class operator.  Only
+        // the unrestricted stage 1 (the matvec) uses the variants; plans keep the class tables.
+        static const bool variants_on = [] {
+            const char *e = std::getenv("BBFMM_M2L_VARIANTS");
+            return !e || std::atoi(e) != 0;
+        }();
+        for (int o = 0; o < ncls; ++o) {
+            const HostM2lClass &hc = m2l_host_[first_class + o];
+            const size_t nc = hc.cells.size();
+            if (nc == 0) continue;
+            const int nt = hc.n_t;
+            // pattern signature per cell (which targets exist)
+            std::vector<uint64_t> sig(nc);
+            parallel_for(static_cast<int64_t>(nc), 256, [&](int64_t i) {
+                uint64_t h = 1469598103934665603ull;
+                const int32_t *row = &hc.cslot[static_cast<size_t>(i) * nt];
+                uint64_t word = 0;
+                for (int ps = 0; ps < nt; ++ps) {
+                    word = (word << 1) | (row[ps] >= 0 ? 1u : 0u);
+                    if ((ps & 63) == 63 || ps == nt - 1) {
+                        h = (h ^ word) * 1099511628211ull;
+                        word = 0;
+                    }
+                }
+                sig[static_cast<size_t>(i)] = h;
+            });
+            auto same_pattern = [&](size_t a, size_t b) {
+                if (sig[a] != sig[b]) return false;
+                const int32_t *ra = &hc.cslot[a * nt], *rb = &hc.cslot[b * nt];
+                for (int ps = 0; ps < nt; ++ps)
+                    if ((ra[ps] >= 0) != (rb[ps] >= 0)) return false;
+                return true;
+            };
+            std::vector<int32_t> rest; // class positions that keep the class operator
+            size_t i = 0;
+            while (i < nc) {
+                size_t j = i + 1;
+                while (j < nc && same_pattern(i, j)) ++j;
+                size_t full = 0;
+                if (variants_on && j - i >= static_cast<size_t>(kM2lTile)) {
+                    int present_rows = 0;
+                    std::vector<int> tvs;
+                    for (int ps = 0; ps < nt; ++ps)
+                        if (hc.cslot[i * nt + ps] >= 0) {
+                            tvs.push_back(hc.src_tv[ps]);
+                            present_rows += round_up(rank_of(hc.src_tv[ps]), 2);
+                        }
+                    // worth a variant: at least one column block of 26 saved
+                    if (!tvs.empty() && round_up(present_rows, kM2lS1Block) < hc.r_pad16) {
+                        full = (j - i) / kM2lTile * kM2lTile;
+                        HostM2lClass v;
+                        v.level = level;
+                        v.octant = o;
+                        v.k_pad = 16;
+                        if (!stage1_rows(o, tvs, &v)) return fail(BBFMM_BAD_ARGUMENT, "M2L slot too long for the packed row table");
+                        v.cells.assign(hc.cells.begin() + static_cast<std::ptrdiff_t>(i), hc.cells.begin() + static_cast<std::ptrdiff_t>(i + full));
+                        v.cslot.resize(full * tvs.size());
+                        size_t pv = 0;
+                        std::vector<int> keep;
+                        for (int ps = 0; ps < nt; ++ps)
+                            if (hc.cslot[i * nt + ps] >= 0) keep.push_back(ps);
+                        for (size_t k = 0; k < full; ++k)
+                            for (int ps : keep) v.cslot[pv++] = hc.cslot[(i + k) * nt + ps];
+                        for (size_t f = 0; f < full; f += kM2lTile) {
+                            M2lTileDesc td;
+                            std::memset(&td, 0, sizeof td);
+                            td.level_class = -1 - static_cast<int32_t>(m2l_variants_.size()); // fixed up below
+                            td.first = static_cast<int32_t>(f);
+                            td.count = kM2lTile;
+                            td.pad = 0;
+                            m2l_tiles1_h_.push_back(td);
+                        }
+                        if (host_only_) fill_m2l_operator_arrays(v, &v.vt_all, &v.u_all);
+                        m2l_variants_.push_back(std::move(v));
+                    }
+                }
+                for (size_t k = i + full; k < j; ++k) rest.push_back(static_cast<int32_t>(k));
+                i = j;
+            }
+            for (size_t f = 0; f < rest.size(); f += kM2lTile) {
+                M2lTileDesc td;
+                std::memset(&td, 0, sizeof td);
+                td.level_class = static_cast<int32_t>(first_class + o);
+                td.first = static_cast<int32_t>(m2l_tile_idx1_h_.size() + f);
+                td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, rest.size() - f));
+                td.pad = 1; // first indexes the position list
+                m2l_tiles1_h_.push_back(td);
+            }
+            m2l_tile_idx1_h_.insert(m2l_tile_idx1_h_.end(), rest.begin(), rest.end());
+        }
     }
     if (bad_pairs > 0)
         return fail(BBFMM_UNSUPPORTED,
                     "V-list pairs outside the admissible transfer-vector set (source points outside the root box?)");
+    for (M2lTileDesc &td : m2l_tiles1_h_) // variant classes follow the level classes in the device table
+        if (td.level_class < 0) td.level_class = static_cast<int32_t>(m2l_host_.size()) + (-1 - td.level_class);
     cbuf_len_ = cbuf_cursor + 128; // + dump area for the branch-free stage-1 scatter (never read)
     if (cbuf_len_ / 2 >= (int64_t(1) << 31)) return fail(BBFMM_UNSUPPORTED, "M2L intermediate buffer too large");
     return BBFMM_OK;
@@ -791,7 +898,7 @@ int FmmTree::upload() {
     HIPCHK(hipStreamSynchronize(stream_));
     ut.lap("  upload: tree, run lists");
     // M2L tables
-    m2l_classes_h_.resize(m2l_host_.size());
+    m2l_classes_h_.resize(m2l_host_.size() + m2l_variants_.size());
     // The stacked operators (GBs at p = 9) are gathered on the device from the levels' reference operators and
     // the symmetry tables (MBs): per level one buffer [U_ref | Vt_ref] of all reference vectors.
     const bool compressed = ops_.compression != kCompressionNone;
@@ -810,8 +917,9 @@ int FmmTree::upload() {
         if (!buf.empty()) CHK(dupload(&d_level_ops[lv], buf));
     }
     std::vector<DevBuf<M2lAssembleTv>> assemble_tmp; // per-class tv tables: released once the kernels have run
-    for (size_t i = 0; i < m2l_host_.size(); ++i) {
-        HostM2lClass &h = m2l_host_[i];
+    for (size_t i = 0; i < m2l_host_.size() + m2l_variants_.size(); ++i) {
+        // (the boundary variants of stage 1 follow the level classes: same tables, fewer transfer vectors)
+        HostM2lClass &h = i < m2l_host_.size() ? m2l_host_[i] : m2l_variants_[i - m2l_host_.size()];
         M2lClass &c = m2l_classes_h_[i];
         std::memset(&c, 0, sizeof c);
         c.n_rows = h.n_rows;
@@ -874,6 +982,8 @@ int FmmTree::upload() {
     ut.lap("  upload: M2L operators, tables");
     CHK(dupload(&d_m2l_classes_, m2l_classes_h_));
     CHK(dupload(&d_m2l_tiles_, m2l_tiles_h_));
+    CHK(dupload(&d_m2l_tiles1_, m2l_tiles1_h_));
+    CHK(dupload(&d_tile_idx1_, m2l_tile_idx1_h_));
     m2l_tiles2_h_ = m2l_tiles_h_;
     split_tile_tail(&m2l_tiles2_h_, n_cu_);
     CHK(dupload(&d_m2l_tiles2_, m2l_tiles2_h_));
@@ -1292,14 +1402,13 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_));
     // a plan runs stage 1 on compact tiles of the sources its targets need, stage 2 on the tiles that
     // hold a cell with targets, P2L / L2L on the cells with targets (cells_with_targets, bbfmm.rs:468-480)
-    const int n_all = static_cast<int>(m2l_tiles_h_.size());
     phase_begin();
     if (dp)
         launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles1_h.size()),
                           cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_, dp->tiles1_own_blocks);
     else
-        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles_.p, nullptr, n_all, cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p,
-                          d_cbuf_.p, cbuf_len_, stream_);
+        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p, d_tile_idx1_.p, static_cast<int>(m2l_tiles1_h_.size()), cheb_.n_pad,
+                          m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
     phase_end(kPhM2L1);
     phase_begin();
     if (dp)
@@ -2130,10 +2239,16 @@ int FmmTree::debug_get_coefficients(char which, int k, double *out) {
 int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
     const int n = ops_.n, n_pad = round_up(n, 32);
     std::vector<double> cbuf(static_cast<size_t>(std::max<int64_t>(cbuf_len_, 1)), 0.0);
-    for (const HostM2lClass &hc : m2l_host_) {
-        if (hc.cells.empty()) continue;
+    // stage 1 exactly as the unrestricted device launch walks it: the tile list with the boundary variants
+    std::vector<uint8_t> seen(static_cast<size_t>(tree_.n_cells()), 0);
+    for (const M2lTileDesc &td : m2l_tiles1_h_) {
+        const bool variant = static_cast<size_t>(td.level_class) >= m2l_host_.size();
+        const HostM2lClass &hc = variant ? m2l_variants_[static_cast<size_t>(td.level_class) - m2l_host_.size()]
+                                         : m2l_host_[static_cast<size_t>(td.level_class)];
         if (hc.vt_all.empty()) return BBFMM_UNSUPPORTED; // tables were released after upload
-        for (size_t pos = 0; pos < hc.cells.size(); ++pos) {
+        for (int32_t q = 0; q < td.count; ++q) {
+            const size_t pos = static_cast<size_t>(td.pad ? m2l_tile_idx1_h_[static_cast<size_t>(td.first + q)] : td.first + q);
+            if (seen[hc.cells[pos]]++) return BBFMM_BAD_ARGUMENT; // every source cell belongs to exactly one tile
             const double *Mv = M + static_cast<size_t>(hc.cells[pos]) * n;
             for (int row = 0; row < hc.n_rows; ++row) {
                 if (hc.row_tpos[row] < 0) continue; // padding row
@@ -2145,6 +2260,9 @@ int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
             }
         }
     }
+    for (const HostM2lClass &hc : m2l_host_) // ... and no cell of a level with M2L work was left out
+        for (int32_t c : hc.cells)
+            if (!seen[c]) return BBFMM_BAD_ARGUMENT;
     for (const HostM2lClass &hc : m2l_host_) {
         for (size_t pos = 0; pos < hc.cells.size(); ++pos) {
             double *Lb = L + static_cast<size_t>(hc.cells[pos]) * n;

@@ -148,6 +148,11 @@ class FmmTree {
     const std::vector<int64_t> &partition_rows() const { return part_rows_; }
     bool partitioned() const { return part_world_ > 1; }
     const std::vector<HostM2lClass> &m2l_host() const { return m2l_host_; }
+    void m2l_variant_stats(int64_t *n_variants, int64_t *n_cells) const {
+        *n_variants = static_cast<int64_t>(m2l_variants_.size());
+        *n_cells = 0;
+        for (const HostM2lClass &v : m2l_variants_) *n_cells += static_cast<int64_t>(v.cells.size());
+    }
     // Test hook (host loops over the stacked M2L tables; needs BBFMM_FLAG_HOST_ONLY).
     // M, L: n_cells x n (cell-major, one rhs).  L is accumulated into.
     int debug_apply_m2l_tables_host(const double *M, double *L) const;
@@ -207,6 +212,9 @@ class FmmTree {
     std::vector<int32_t> x_cells_;                      // cells with an X list
     // M2L tables (host copies kept for stats / tests)
     std::vector<HostM2lClass> m2l_host_;
+    std::vector<HostM2lClass> m2l_variants_;       // stage-1 boundary variants (fmm_tree.cpp build_m2l_tables)
+    std::vector<M2lTileDesc> m2l_tiles1_h_;        // unrestricted stage-1 launch: variant tiles + class tiles over the rest
+    std::vector<int32_t> m2l_tile_idx1_h_;         // class positions of the `rest` tiles
     std::vector<M2lClass> m2l_classes_h_;
     std::vector<M2lTileDesc> m2l_tiles_h_;
     std::vector<uint16_t> m2l_qlist_h_;
@@ -279,7 +287,8 @@ class FmmTree {
     DevBuf<int32_t> d_u_runs_, d_x_runs_, d_w_idx_, d_x_cells_;
     DevBuf<int64_t> d_x_job_run_ptr_;
     DevBuf<M2lClass> d_m2l_classes_;
-    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles2_;
+    DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles2_, d_m2l_tiles1_;
+    DevBuf<int32_t> d_tile_idx1_;
     DevBuf<uint16_t> d_m2l_qlist_;
 
     DevBuf<uint8_t> d_active_;

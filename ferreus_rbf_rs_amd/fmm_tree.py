@@ -394,6 +394,12 @@ class FmmTree:
         self._raise(self._lib.bbfmm_debug_dense_m2m(self._h, child_index, out.ctypes.data))
         return out
 
+    def debug_m2l_variants(self):
+        """(number of stage-1 boundary variants, source cells that use one)"""
+        nv, nc = ctypes.c_int64(), ctypes.c_int64()
+        self._raise(self._lib.bbfmm_debug_m2l_variants(self._h, ctypes.byref(nv), ctypes.byref(nc)))
+        return nv.value, nc.value
+
     def debug_get_coefficients(self, which: str, k: int) -> np.ndarray:
         s = self.stats()
         out = np.zeros((k, s.n_cells, s.n_nodes))

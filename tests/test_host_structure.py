@@ -165,6 +165,34 @@ def test_stacked_m2l_tables_reproduce_the_reference_grouping():
         assert relerr(Lp, r.L[0]) < 1e-12
 
 
+def test_stage1_boundary_variants_cover_every_cell_once_and_reproduce_m2l():
+    """A tree deep enough for runs of >= 128 same-class cells that miss the same targets (the faces of a 32^3
+    level): those get stacked stage-1 operators without the transfer vectors towards the missing targets.  The
+    host walk of the SAME tile list the device launch uses (bbfmm_debug_apply_m2l_tables_host) must visit every
+    source cell exactly once and reproduce the reference's M2L."""
+    rng = np.random.default_rng(17)
+    g = (np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing="ij"), -1).reshape(-1, 3)[:, None, :]
+         + 0.15 + 0.7 * rng.random((32 ** 3, 2, 3))).reshape(-1, 3) / 32.0
+    params = (6, 2, 1e-3, 1024)
+    t, r = both(g, order=3, params=params)
+    nv, nc = t.debug_m2l_variants()
+    assert nv >= 6 * 8 and nc >= 128 * nv            # at least the six faces of each of the eight classes of level 5
+    inject_product_operators(t, r)
+    r.set_weights(rng.random((g.shape[0], 1)))
+    M = r.M[0].copy()
+    Lp = t.debug_apply_m2l_tables_host(M)
+    r.L = np.zeros_like(r.M)
+    lib = O.lib()
+    for level in range(2, r.depth + 1):
+        cells = np.ascontiguousarray(r.level_cells[level])
+        buf, u_off, vt_off, rank = r.opbuf[level]
+        lib.oracle_m2l(O.I32(r.ops.n), O.I64(r.C), O.I32(1), O._p(cells), O.I64(len(cells)), O._p(r.v_ptr),
+                       O._p(r.v_idx), O._p(r.v_tidx), O.I32(len(rank)), O._p(u_off), O._p(vt_off), O._p(rank),
+                       O._p(buf), O.I32(1), O._p(r.ops.perm), O._p(r.ops.invperm),
+                       O._p(r.ops.perm_lookup), O._p(r.ops.ref_lookup), O._p(r.M), O._p(r.L))
+    assert relerr(Lp, r.L[0]) < 1e-12
+
+
 def test_partition_rows_cover_all_points_once():
     pts = np.random.default_rng(16).random((20000, 3))
     t = F.FmmTree(pts, 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, host_only=True)
