@@ -1,0 +1,56 @@
+"""bench.py's host-side pieces that need no GPU: the plain-torch dense rows it checks every configuration with
+(restated kernel formulas) against the oracle's kernels, and the rule that committed counters are only quoted
+for the sources they were taken on."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import bbfmm_oracle as O
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+@pytest.mark.parametrize("name,kid,br,sill", [("LinearRbf", 0, 1.0, 1.0), ("ThinPlateSplineRbf", 1, 1.0, 1.0),
+                                               ("Spheroidal3Rbf", 3, 0.1, 0.1), ("Spheroidal3Rbf", 3, 0.7, 0.4),
+                                               ("MultiquadricExt", 101, 0.1, 0.1)])
+def test_dense_rows_torch_equals_the_oracle_dense_sum(name, kid, br, sill):
+    rng = np.random.default_rng(3)
+    pts = rng.random((4000, 3))
+    pts[7] = pts[3]                                   # a coincident pair: phi(0)
+    w = rng.standard_normal((2, 4000))
+    idx = np.array([3, 7, 100, 3999])
+    got = bench.dense_rows_torch(torch, name, br, sill, torch.from_numpy(pts[idx]), torch.from_numpy(pts), torch.from_numpy(w))
+    want = O.dense_sum(kid, br, sill, pts[idx], pts, w.T.copy())
+    assert np.abs(got.numpy() - want).max() <= 1e-12 * np.abs(want).max()
+    assert bench.dense_rows_torch(torch, "CubicRbf", 1.0, 1.0, torch.zeros(1, 3), torch.zeros(2, 3), torch.zeros(1, 2)) is None
+
+
+def test_committed_counters_are_only_quoted_for_the_sources_they_were_taken_on(tmp_path, monkeypatch):
+    h = bench.source_hash()
+    assert len(h) == 16 and h == bench.source_hash()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "ferreus_rbf_rs_amd" / "csrc")
+    (tmp_path / "ferreus_rbf_rs_amd" / "csrc" / "a.hip").write_text("kernel v1")
+    h1 = bench.source_hash()
+    (prof / "r09_counters.json").write_text(json.dumps({"source_hash": h1, "workload": [10, "LinearRbf", 7, 1],
+                                                        "per_launch_bytes": {"P2P": 5.0}}))
+    assert bench.committed_counters((10, "LinearRbf", 7, 1))["per_launch_bytes"]["P2P"] == 5.0
+    assert bench.committed_counters((11, "LinearRbf", 7, 1)) is None          # another workload
+    (tmp_path / "ferreus_rbf_rs_amd" / "csrc" / "a.hip").write_text("kernel v2")
+    assert bench.source_hash() != h1
+    assert bench.committed_counters((10, "LinearRbf", 7, 1)) is None          # the kernels changed: never stale numbers
+
+
+def test_extra_configs_name_baseline_json_configs():
+    names = [c["name"] for c in bench.EXTRA_CONFIGS]
+    assert len(names) == len(set(names)) == 4
+    for c in bench.EXTRA_CONFIGS:
+        assert c["total_sill"] <= c["base_range"]      # KernelParamsBuilder::build asserts this (kernel_helpers.rs:69-70)

@@ -293,3 +293,37 @@ def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs):
         acc[:, rows] = tmp[:, rows]
     t.set_partition(0, 1)
     assert relerr(acc.cpu().numpy().T, yr) < TOL
+
+
+def test_config5_forty_million_points_eight_way_partition():
+    """BASELINE.json configs[4] at full size on one GPU: 40M points, Spheroidal3, the matvec
+    partitioned by target subtree into 8 shares that are run one after another and reassembled from their owned
+    rows -- everything of the 8-GPU run except the RCCL all-gather itself (tests/test_gpu_two_ranks.py runs the
+    exchange with two real processes)."""
+    import torch
+    n, br, sill = 40_000_000, 0.1, 0.1
+    pts = np.random.default_rng(42).random((n, 3))
+    t = F.FmmTree(pts, 7, F.KernelParams(F.KernelType.Spheroidal3Rbf, base_range=br, total_sill=sill), True, True)
+    assert t.tree_built_on_device() and t.stats().n_points == n
+    g = torch.Generator(device="cuda").manual_seed(5)
+    w = torch.rand((1, n), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    ref = torch.zeros_like(w)
+    t.matvec_device(w.data_ptr(), n, 1, ref.data_ptr(), n, True)
+    acc = torch.full((1, n), float("nan"), dtype=torch.float64, device="cuda")
+    tmp = torch.zeros_like(w)
+    owned = 0
+    for rank in range(8):
+        t.set_partition(rank, 8)
+        rows = torch.from_numpy(t.partition_rows()).cuda()
+        assert 0.08 * n < rows.numel() < 0.18 * n                       # balanced shares
+        tmp.zero_()
+        t.matvec_device(w.data_ptr(), n, 1, tmp.data_ptr(), n, True)
+        acc[:, rows] = tmp[:, rows]
+        owned += rows.numel()
+        del rows
+    t.set_partition(0, 1)
+    assert owned == n and not bool(torch.isnan(acc).any())
+    assert float((acc - ref).abs().max() / ref.abs().max()) < 1e-12     # the shares reassemble the product
+    idx = np.random.default_rng(6).choice(n, 16, replace=False)
+    yd = O.dense_sum(3, br, sill, pts[idx], pts, w.cpu().numpy().T.copy())
+    assert relerr(ref.cpu().numpy().T[idx], yd) < 5e-6
