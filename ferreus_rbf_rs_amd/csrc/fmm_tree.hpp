@@ -14,6 +14,7 @@
 #include "ferreus_bbfmm_hip.h"
 #include "kernels.hpp"
 #include "operators.hpp"
+#include "parallel.hpp"
 #include "tree.hpp"
 #include "tree_device.hpp"
 
@@ -129,7 +130,7 @@ class FmmTree {
 
     const HostTree &tree() const { return tree_; }
     const Operators &ops() const { return ops_; }
-    const std::vector<double> &source_points() const { return pts_; } // n x d column-major, ld = n
+    const PodDoubles &source_points() const { return pts_; } // n x d column-major, ld = n
     int order() const { return order_; }
     const char *last_error() const { return err_.c_str(); }
     hipStream_t stream() const { return stream_; }
@@ -197,7 +198,7 @@ class FmmTree {
     int order_ = 0, d_ = 0;
     KernelSpec kernel_{};
     bbfmm_params params_{};
-    std::vector<double> pts_;
+    PodDoubles pts_;
     HostTree tree_;
     Operators ops_;
     int nrhs_ = 0;           // set by set_weights (bbfmm.rs:384); 0 = no weights yet

@@ -6,10 +6,23 @@
 #include <atomic>
 #include <cstdint>
 #include <cstdlib>
+#include <memory>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace bbfmm {
+
+// std::vector without the serial zero fill of resize(): the elements are written by parallel loops right after.
+template <class T> struct DefaultInitAllocator : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = DefaultInitAllocator<U>;
+    };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+using PodDoubles = std::vector<double, DefaultInitAllocator<double>>;
 
 inline int host_threads() {
     static int n = [] {
