@@ -65,7 +65,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     lib_digest = hashlib.sha256("".join(digests).encode()).hexdigest()
     lib_stamp = os.path.join(OBJ, "lib.sha256")
     if force or _stale(LIB, lib_stamp, lib_digest):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread"]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

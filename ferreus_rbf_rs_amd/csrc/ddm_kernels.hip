@@ -655,6 +655,18 @@ void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
     hipLaunchKernelGGL(ddm_cholesky_kernel, dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, make_view(lv), d_fail);
 }
 
+__global__ __launch_bounds__(256) void unpack_symmetric_kernel(const double *__restrict__ packed, int m, double *__restrict__ full) {
+    const int c = blockIdx.x;
+    for (int r = c + threadIdx.x; r < m; r += 256) {
+        const double v = packed[pk(r, c, m)];
+        full[static_cast<int64_t>(c) * m + r] = v;
+        full[static_cast<int64_t>(r) * m + c] = v;
+    }
+}
+void launch_ddm_unpack_symmetric(const double *packed, int m, double *full, hipStream_t s) {
+    if (m > 0) hipLaunchKernelGGL(unpack_symmetric_kernel, dim3(m), dim3(256), 0, s, packed, m, full);
+}
+
 void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s) {
     if (lv.n_dom == 0) return;
     if (ddm_level_is_big(lv)) { // one large domain: work = [d_s | y] (n), z (m), gamma (m)
@@ -664,12 +676,17 @@ void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *
         const double *L = lv.d_fac;
         hipLaunchKernelGGL(big_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, d_values, n);
         if (k) hipLaunchKernelGGL(big_rhs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, v, k, m);
-        for (int jb = 0; jb < m; jb += SB) {
-            const int rest = m - jb - std::min(SB, m - jb);
-            hipLaunchKernelGGL(big_fwd_step_kernel, dim3(std::max(1, (rest + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, y, z);
+        if (lv.d_lu) { // not positive definite: pivoted LU of the full matrix (the reference's LBL^T role)
+            (void)hipMemcpyAsync(g, y, static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToDevice, s);
+            (void)big_lu_solve(lv, g, s);
+        } else {
+            for (int jb = 0; jb < m; jb += SB) {
+                const int rest = m - jb - std::min(SB, m - jb);
+                hipLaunchKernelGGL(big_fwd_step_kernel, dim3(std::max(1, (rest + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, y, z);
+            }
+            for (int jb = ((m - 1) / SB) * SB; jb >= 0; jb -= SB)
+                hipLaunchKernelGGL(big_bwd_step_kernel, dim3(std::max(1, (jb + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, z, g);
         }
-        for (int jb = ((m - 1) / SB) * SB; jb >= 0; jb -= SB)
-            hipLaunchKernelGGL(big_bwd_step_kernel, dim3(std::max(1, (jb + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, z, g);
         if (k) hipLaunchKernelGGL(big_special_kernel, dim3(k), dim3(256), 0, s, v, m, g);
         hipLaunchKernelGGL(big_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, n, k, g, d_out, all_points ? 1 : 0);
         return;

@@ -1,6 +1,8 @@
 // See ddm_solver.hpp.
 #include "ddm_solver.hpp"
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -255,6 +257,74 @@ static int host_domain_inverse(const std::vector<double> *xyz, int64_t o, int k,
     return BBFMM_OK;
 }
 
+// ---- pivoted LU of one large domain through rocSOLVER, bound at run time (dlopen): the library is only needed
+// when a coarse system of more than 2,048 points is not positive definite (e.g. a negative nugget), where the
+// reference switches from Cholesky to a Bunch-Kaufman LBL^T factorisation (domain.rs:60-68, linalg.rs:514-616).
+namespace {
+struct RocSolverApi {
+    void *lib_solver = nullptr, *lib_blas = nullptr;
+    int (*create_handle)(void **) = nullptr;
+    int (*destroy_handle)(void *) = nullptr;
+    int (*set_stream)(void *, hipStream_t) = nullptr;
+    int (*dgetrf)(void *, int, int, double *, int, int *, int *) = nullptr;
+    int (*dgetrs)(void *, int, int, int, double *, int, const int *, double *, int) = nullptr;
+    bool ok = false;
+};
+RocSolverApi &rocsolver_api() {
+    static RocSolverApi api = [] {
+        RocSolverApi a;
+        for (const char *name : {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so"})
+            if (!a.lib_blas) a.lib_blas = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        for (const char *name : {"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so"})
+            if (!a.lib_solver) a.lib_solver = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (!a.lib_solver) return a;
+        auto sym = [&](const char *n) {
+            void *p = dlsym(a.lib_solver, n);
+            if (!p && a.lib_blas) p = dlsym(a.lib_blas, n);
+            return p;
+        };
+        a.create_handle = reinterpret_cast<int (*)(void **)>(sym("rocblas_create_handle"));
+        a.destroy_handle = reinterpret_cast<int (*)(void *)>(sym("rocblas_destroy_handle"));
+        a.set_stream = reinterpret_cast<int (*)(void *, hipStream_t)>(sym("rocblas_set_stream"));
+        a.dgetrf = reinterpret_cast<int (*)(void *, int, int, double *, int, int *, int *)>(sym("rocsolver_dgetrf"));
+        a.dgetrs = reinterpret_cast<int (*)(void *, int, int, int, double *, int, const int *, double *, int)>(sym("rocsolver_dgetrs"));
+        a.ok = a.create_handle && a.destroy_handle && a.set_stream && a.dgetrf && a.dgetrs;
+        return a;
+    }();
+    return api;
+}
+} // namespace
+
+int big_lu_factor(DdmLevelSolver *lv, hipStream_t s) {
+    RocSolverApi &api = rocsolver_api();
+    if (!api.ok) return BBFMM_UNSUPPORTED; // no rocSOLVER on this machine: the large indefinite system cannot be solved
+    const int m = lv->max_m;
+    DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_lu), static_cast<size_t>(m) * m * sizeof(double)));
+    DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_ipiv), (static_cast<size_t>(m) + 1) * sizeof(int)));
+    launch_ddm_unpack_symmetric(lv->d_fac, m, lv->d_lu, s);
+    if (api.create_handle(&lv->lu_handle) != 0 || api.set_stream(lv->lu_handle, s) != 0) return BBFMM_DEVICE_ERROR;
+    int *d_info = lv->d_ipiv + m;
+    if (api.dgetrf(lv->lu_handle, m, m, lv->d_lu, m, lv->d_ipiv, d_info) != 0) return BBFMM_DEVICE_ERROR;
+    int info = 0;
+    DHIP(hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+    DHIP(hipStreamSynchronize(s));
+    return info == 0 ? BBFMM_OK : BBFMM_UNSUPPORTED; // info > 0: exactly singular
+}
+
+int big_lu_solve(const DdmLevelSolver &lv, double *d_rhs, hipStream_t s) {
+    RocSolverApi &api = rocsolver_api();
+    if (!api.ok || !lv.lu_handle) return BBFMM_DEVICE_ERROR;
+    const int m = lv.max_m;
+    if (api.set_stream(lv.lu_handle, s) != 0) return BBFMM_DEVICE_ERROR;
+    return api.dgetrs(lv.lu_handle, 111 /* rocblas_operation_none */, m, 1, lv.d_lu, m, lv.d_ipiv, d_rhs, m) == 0 ? BBFMM_OK
+                                                                                                               : BBFMM_DEVICE_ERROR;
+}
+
+void big_lu_release(DdmLevelSolver *lv) {
+    if (lv->lu_handle && rocsolver_api().ok) (void)rocsolver_api().destroy_handle(lv->lu_handle);
+    lv->lu_handle = nullptr;
+}
+
 int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const KernelSpec &ks, double nugget,
                     int degree, int basis_size, bool solve_for_poly, hipStream_t s, DdmLevelSolver *lv,
                     const double *scaling) {
@@ -346,9 +416,14 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     for (int64_t i = 0; i < nd; ++i)
         if (fail[static_cast<size_t>(i)]) failed.push_back(i);
     if (failed.empty()) return BBFMM_OK;
-    // local systems that are not positive definite: host fallback per domain (not for the one large coarse
-    // matrix, which would take the host hours)
-    if (ddm_level_is_big(*lv)) return BBFMM_UNSUPPORTED;
+    // local systems that are not positive definite: host fallback per domain; the one large coarse matrix
+    // (which would take the host hours) is assembled again, unpacked and factorised by pivoted LU on the device
+    if (ddm_level_is_big(*lv)) {
+        launch_ddm_assemble(ks, nugget, d, *lv, s); // the failed factorisation overwrote the packed matrix
+        rc = big_lu_factor(lv, s);
+        lap("pivoted LU of the coarse domain (LBLT role)", true);
+        return rc;
+    }
     lv->n_fallback = static_cast<int>(failed.size());
     std::vector<uint8_t> mode(static_cast<size_t>(nd), 0);
     std::vector<int> frc(failed.size(), BBFMM_OK);
@@ -387,6 +462,9 @@ void ddm_level_free(DdmLevelSolver *lv) {
     (void)hipFree(lv->d_mode);
     (void)hipFree(lv->d_linv);
     (void)hipFree(lv->d_tmp);
+    (void)hipFree(lv->d_lu);
+    (void)hipFree(lv->d_ipiv);
+    big_lu_release(lv);
     *lv = DdmLevelSolver();
 }
 

@@ -50,6 +50,11 @@ struct DdmLevelSolver {
     double *d_tmp = nullptr;   // n_entries scratch for those domains
     int n_fallback = 0;
     double *d_work = nullptr; // n_entries: rhs / solution per entry (3x for one large domain: + z, gamma)
+    // one large domain whose Cholesky factorisation failed (domain.rs:60-68: the reference switches to LBL^T): the
+    // full m x m matrix factorised by rocSOLVER's pivoted LU, loaded on demand (ddm_solver.cpp big_lu_*)
+    double *d_lu = nullptr;
+    int *d_ipiv = nullptr;
+    void *lu_handle = nullptr; // rocblas_handle
     int max_m = 0;
 };
 
@@ -70,5 +75,11 @@ void launch_ddm_prep(const KernelSpec &ks, double nugget, int d, const DdmLevelS
 void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s);
 void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s);
 void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s);
+// packed lower triangle (column by column) -> full symmetric m x m column-major
+void launch_ddm_unpack_symmetric(const double *packed, int m, double *full, hipStream_t s);
+// gamma = (Q^T A Q)^-1 y through the LU factors of a large domain (y, gamma: m doubles on the device, in place)
+int big_lu_solve(const DdmLevelSolver &lv, double *d_rhs, hipStream_t s);
+int big_lu_factor(DdmLevelSolver *lv, hipStream_t s); // lv->d_fac holds the assembled packed matrix
+void big_lu_release(DdmLevelSolver *lv);
 
 } // namespace bbfmm

@@ -592,13 +592,13 @@ int FmmTree::build_m2l_tables() {
                 // complete lists first; the hash only has to keep equal patterns together
                 key[static_cast<size_t>(c - c_lo)] = (static_cast<uint64_t>(1023 - std::min<int64_t>(nv, 1023)) << 54) | (hsh >> 10);
             }
-            for (int o = 0; o < ncls; ++o) {
-                auto &cells = m2l_host_[first_class + o].cells;
+            parallel_for(ncls, 1, [&](int64_t o) { // the classes are disjoint cell sets
+                auto &cells = m2l_host_[first_class + static_cast<size_t>(o)].cells;
                 std::stable_sort(cells.begin(), cells.end(), [&](int32_t a, int32_t b) {
                     return key[static_cast<size_t>(a - c_lo)] < key[static_cast<size_t>(b - c_lo)];
                 });
                 for (size_t i = 0; i < cells.size(); ++i) pos_in_class[cells[i]] = static_cast<int32_t>(i);
-            }
+            });
         }
         for (int o = 0; o < ncls; ++o) {
             HostM2lClass &hc = m2l_host_[first_class + o];
@@ -617,7 +617,13 @@ int FmmTree::build_m2l_tables() {
                 hc.cbase[i] = cbuf_cursor;
                 cbuf_cursor += hc.k_pad;
             }
-            hc.cslot.assign(hc.cells.size() * static_cast<size_t>(hc.n_t), -1);
+            hc.cslot.resize(hc.cells.size() * static_cast<size_t>(hc.n_t));
+            {
+                int32_t *cs = hc.cslot.data();
+                parallel_for_chunks(static_cast<int64_t>(hc.cslot.size()), int64_t(1) << 18, [&](int64_t b, int64_t e) {
+                    std::fill(cs + b, cs + e, int32_t(-1));
+                });
+            }
         }
         // cslot: for every V pair (B <- V, t) the slot of B as seen from V
         // (threaded: every (V, t) slot has exactly one writer; flop and error counts are reduced per chunk)
@@ -963,7 +969,8 @@ int FmmTree::upload() {
         CHK(dupload(&rt, h.row_dst));
         CHK(dupload(&ro, h.blk_t0));
         CHK(dupload(&ce, h.cells));
-        CHK(dupload(&cs, h.cslot));
+        CHK(dalloc(&cs, h.cslot.size()));
+        if (!h.cslot.empty()) HIPCHK(hipMemcpy(cs.p, h.cslot.data(), h.cslot.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         CHK(dupload(&cb, h.cbase));
         c.vt_all = vt.p;
         c.u_all = ua.p;
@@ -972,7 +979,7 @@ int FmmTree::upload() {
         c.cells = ce.p;
         c.cslot = cs.p;
         c.cbase = cb.p;
-        std::vector<int32_t>().swap(h.cslot); // only needed for uploading
+        decltype(h.cslot)().swap(h.cslot); // only needed for uploading
     }
     HIPCHK(hipStreamSynchronize(stream_)); // the assembly kernels have read their tables
     HIPCHK(hipGetLastError());

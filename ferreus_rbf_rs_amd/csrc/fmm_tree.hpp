@@ -39,7 +39,8 @@ struct HostM2lClass {
     int n_rows = 0, r_pad16 = 16, n_t = 0, k_pad = 16;
     std::vector<double> vt_all, u_all; // kept only on BBFMM_FLAG_HOST_ONLY handles
     std::vector<int> src_tv, tgt_tv, tgt_off; // transfer vectors (source / target side), slot offsets
-    std::vector<int32_t> row_tpos, row_off, row_dst, blk_t0, cells, cslot;
+    std::vector<int32_t> row_tpos, row_off, row_dst, blk_t0, cells;
+    std::vector<int32_t, DefaultInitAllocator<int32_t>> cslot; // cells x n_t, filled by parallel loops
     std::vector<int32_t> src_row0, src_row1; // stacked rows [row0, row1) of each source-side transfer vector
     std::vector<int64_t> cbase;
 };

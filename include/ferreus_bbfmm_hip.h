@@ -378,8 +378,9 @@ int bbfmm_ddm_domain(const bbfmm_ddm *t, int32_t level, int64_t domain, int64_t 
  * per domain.  The two partial matvecs per fine level go through `tree`
  * (IterativeSolver::precon, rbf.rs:140-155).  Global trend transforms are not supported.
  * A domain whose Cholesky factorisation fails is solved through a host-computed inverse instead (the
- * role of the reference's LBL^T fallback, domain.rs:60-68); BBFMM_UNSUPPORTED is returned only when
- * that happens to a coarse domain of more than 2048 points or a local system is singular. */
+ * role of the reference's LBL^T fallback, domain.rs:60-68); the one large coarse domain (more than 2048
+ * points) is then factorised by pivoted LU on the device (rocSOLVER, loaded on demand).  BBFMM_UNSUPPORTED
+ * is returned only when a local system is singular or that library is missing. */
 typedef struct bbfmm_schwarz bbfmm_schwarz;
 typedef struct bbfmm_interpolant { /* InterpolantSettings, interpolant_config.rs:118-147, as the solver reads it */
     int32_t kernel_type;       /* bbfmm_kernel_type 0..6 (Linear, ThinPlateSpline, Cubic, Spheroidal3/5/7/9) */

@@ -156,3 +156,26 @@ def test_reference_sized_domains_and_a_large_coarse_domain(kid):
         z = pre.debug_level_solve(lv, r, True)
         zo = _oracle_level_solve(levels, lv, r, n, ost, ortho)
         assert np.abs(z - zo).max() < 1e-8 * np.abs(zo).max(), f"level {lv}"
+
+
+def test_large_coarse_domain_that_is_not_positive_definite_takes_the_pivoted_lu():
+    """domain.rs:60-68 for the one large coarse domain (> 2,048 points, factorised and solved as launch sequences
+    over the whole chip): a negative nugget makes Q^T A Q indefinite, the blocked Cholesky reports the failure and
+    the level is re-assembled and factorised by pivoted LU (rocSOLVER, bound at run time) -- the role of the
+    reference's Bunch-Kaufman LBL^T.  Every level's correction against the restatement."""
+    rng = np.random.default_rng(91)
+    n, dim, kid, nugget, br = 20000, 3, 3, -0.02, 0.3
+    pts = rng.random((n, dim))
+    prm = (1024, 0.5, 0.125, 2600)
+    st = InterpolantSettings(kid, dim, nugget=nugget, base_range=br, total_sill=br)
+    ost = D.InterpolantSettings(kid, dim, nugget=nugget, base_range=br, total_sill=br)
+    tree = F.FmmTree(pts, 5, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=br), True, True)
+    pre = SchwarzPreconditioner(tree, pts, st, DDMParams(*prm))
+    levels = D.build_ddm_tree(pts, ost, D.DDMParams(*prm))
+    assert pre.num_levels == len(levels) == 2 and len(levels[1].point_indices) > 2048
+    assert levels[1].leaf_domains[0].indefinite is not None          # the coarse system really is indefinite
+    r = rng.standard_normal(n)
+    for lv in range(2):
+        z = pre.debug_level_solve(lv, r, True)
+        zo = _oracle_level_solve(levels, lv, r, n, ost, None)
+        assert np.abs(z - zo).max() < 1e-7 * np.abs(zo).max(), f"level {lv}"
