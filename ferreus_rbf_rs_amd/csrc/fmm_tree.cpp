@@ -697,14 +697,17 @@ int FmmTree::build_m2l_tables() {
             // ---- stage-1 variants (boundary classes).  A source cell computes the compressed vectors of ALL admissible
         // transfer vectors of its class, also of those whose target does not exist (domain boundary, coarse
         // neighbours): 6 % of the stage-1 flops of a uniform cube, far more on clustered data.  Cells of a class
-        // are sorted by V-list pattern, so cells that miss the same targets sit together: a run of at least one
-        // full tile of such cells gets its own stacked operator with the missing transfer vectors left out (the
+        // are sorted by V-list pattern, so cells that miss the same targets sit together: a run of at least four
+        // full tiles of such cells gets its own stacked operator with the missing transfer vectors left out (the
         // same reference operators, gathered on the device); the remaining cells keep the class operator.  Only
         // the unrestricted stage 1 (the matvec) uses the variants; plans keep the class tables.
-        static const bool variants_on = [] {
+        // BBFMM_M2L_VARIANTS = 0: none; n > 0: runs of at least n full tiles (default 4: a variant costs setup
+        // time -- tables, one more operator -- that only a long run of tiles earns back)
+        const int variant_min_tiles = [] {
             const char *e = std::getenv("BBFMM_M2L_VARIANTS");
-            return !e || std::atoi(e) != 0;
+            return e ? std::atoi(e) : 4;
         }();
+        const bool variants_on = variant_min_tiles > 0;
         for (int o = 0; o < ncls; ++o) {
             const HostM2lClass &hc = m2l_host_[first_class + o];
             const size_t nc = hc.cells.size();
@@ -738,7 +741,7 @@ int FmmTree::build_m2l_tables() {
                 size_t j = i + 1;
                 while (j < nc && same_pattern(i, j)) ++j;
                 size_t full = 0;
-                if (variants_on && j - i >= static_cast<size_t>(kM2lTile)) {
+                if (variants_on && j - i >= static_cast<size_t>(variant_min_tiles) * kM2lTile) {
                     int present_rows = 0;
                     std::vector<int> tvs;
                     for (int ps = 0; ps < nt; ++ps)

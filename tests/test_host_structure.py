@@ -165,7 +165,7 @@ def test_stacked_m2l_tables_reproduce_the_reference_grouping():
         assert relerr(Lp, r.L[0]) < 1e-12
 
 
-def test_stage1_boundary_variants_cover_every_cell_once_and_reproduce_m2l():
+def test_stage1_boundary_variants_cover_every_cell_once_and_reproduce_m2l(monkeypatch):
     """A tree deep enough for runs of >= 128 same-class cells that miss the same targets (the faces of a 32^3
     level): those get stacked stage-1 operators without the transfer vectors towards the missing targets.  The
     host walk of the SAME tile list the device launch uses (bbfmm_debug_apply_m2l_tables_host) must visit every
@@ -174,6 +174,7 @@ def test_stage1_boundary_variants_cover_every_cell_once_and_reproduce_m2l():
     g = (np.stack(np.meshgrid(*[np.arange(32)] * 3, indexing="ij"), -1).reshape(-1, 3)[:, None, :]
          + 0.15 + 0.7 * rng.random((32 ** 3, 2, 3))).reshape(-1, 3) / 32.0
     params = (6, 2, 1e-3, 1024)
+    monkeypatch.setenv("BBFMM_M2L_VARIANTS", "1")      # runs of one full tile qualify (default: four; the faces here hold 256 cells)
     t, r = both(g, order=3, params=params)
     nv, nc = t.debug_m2l_variants()
     assert nv >= 6 * 8 and nc >= 128 * nv            # at least the six faces of each of the eight classes of level 5
