@@ -591,15 +591,16 @@ __global__ __launch_bounds__(64 * L2P_WAVES) void l2p_kernel(const DevCheb *__re
 // bandwidth).  acc[t][kk] += K(t, s) * w_kk(s); gradient accumulators optional.
 constexpr int DIRECT_TILE = 512;
 constexpr int DIRECT_KB = 4;
+constexpr int DIRECT_KB_WIDE = 8; // P2P values without gradients: eight rhs per kernel evaluation (config 4)
 
-struct SrcTile {
+template <int KB> struct SrcTile { // LDS per workgroup: 12 KB + 4 KB per right-hand side of the pass
     double2 xy[DIRECT_TILE];
     double zs[DIRECT_TILE];
-    double w[DIRECT_KB][DIRECT_TILE];
+    double w[KB][DIRECT_TILE];
 };
 
 template <int KID, bool GRAD, int KB>
-__device__ inline void direct_tile(const KernelSpec &ks, const SrcTile &tile, int count, int first, int stride,
+__device__ inline void direct_tile(const KernelSpec &ks, const SrcTile<KB> &tile, int count, int first, int stride,
                                    const double (&t)[2][3], double (&acc)[2][KB], double (&gacc)[2][KB][3]) {
     for (int j = first; j < count; j += stride) {
         const double2 xy = tile.xy[j];
@@ -666,7 +667,7 @@ template <int KID, bool GRAD, int KB>
 __global__ __launch_bounds__(256) void p2p_kernel(KernelSpec ks, int d, DirectJobs jobs, Xyz tgt, int64_t n_tgt,
                                                   Xyz src, const double *__restrict__ ws, int64_t N, int k0, int kb,
                                                   double *__restrict__ out, double *__restrict__ grad) {
-    __shared__ SrcTile tile;
+    __shared__ SrcTile<KB> tile;
     __shared__ double red[256];
     const int tid = threadIdx.x;
     const int job = blockIdx.x;
@@ -875,7 +876,8 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
 
 // Stage the Chebyshev nodes of `cell` (scale_cheb_nodes_to_cell, chebyshev.rs:951-968) and
 // its coefficients as a source tile (n <= DIRECT_TILE assumed per chunk).
-__device__ inline void stage_nodes(SrcTile &tile, const DevCheb *chp, int P1, int P2, int j0, int cnt, double cx,
+template <int KB>
+__device__ inline void stage_nodes(SrcTile<KB> &tile, const DevCheb *chp, int P1, int P2, int j0, int cnt, double cx,
                                    double cy, double cz, double half, int d, const double *coef, int64_t coef_stride,
                                    int kb, int tid, int nthreads) {
     for (int j = tid; j < cnt; j += nthreads) {
@@ -887,7 +889,7 @@ __device__ inline void stage_nodes(SrcTile &tile, const DevCheb *chp, int P1, in
         tile.xy[j] = make_double2(x, y);
         tile.zs[j] = z;
 #pragma unroll
-        for (int kk = 0; kk < DIRECT_KB; ++kk) tile.w[kk][j] = (kk < kb && coef) ? coef[kk * coef_stride + I] : 0.0;
+        for (int kk = 0; kk < KB; ++kk) tile.w[kk][j] = (kk < kb && coef) ? coef[kk * coef_stride + I] : 0.0;
     }
 }
 
@@ -904,7 +906,7 @@ __global__ __launch_bounds__(256) void m2p_kernel(KernelSpec ks, const DevCheb *
                                                   const double *__restrict__ lengths, Xyz tgt, int64_t n_tgt, int k0,
                                                   int kb, int64_t C, const double *__restrict__ M,
                                                   double *__restrict__ out, double *__restrict__ grad) {
-    __shared__ SrcTile tile;
+    __shared__ SrcTile<KB> tile;
     __shared__ double red[256];
     const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
     int P0, P1, P2;
@@ -1057,7 +1059,7 @@ __global__ __launch_bounds__(256) void p2l_kernel(KernelSpec ks, const DevCheb *
                                                   const double *__restrict__ lengths, Xyz src,
                                                   const double *__restrict__ ws, int64_t N, int k0, int kb, int64_t C,
                                                   double *__restrict__ L) {
-    __shared__ SrcTile tile;
+    __shared__ SrcTile<KB> tile;
     __shared__ double red[256];
     const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
     int P0, P1, P2;
@@ -1603,8 +1605,9 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
     if (jobs.n_jobs == 0) return;
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
-        for (int k0 = 0; k0 < K; k0 += DIRECT_KB) {
-            const int kb = std::min(DIRECT_KB, K - k0);
+        for (int k0 = 0; k0 < K;) {
+            const bool wide = !grad_sorted && K - k0 > DIRECT_KB; // more than four rhs left: eight per pass
+            const int kb = std::min(wide ? DIRECT_KB_WIDE : DIRECT_KB, K - k0);
             if (grad_sorted && kb == 1) { // single right-hand side: a quarter of the accumulators
                 hipLaunchKernelGGL((p2p_kernel<ID, true, 1>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d, jobs,
                                    make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted,
@@ -1617,11 +1620,16 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
                 hipLaunchKernelGGL((p2p_kernel<ID, false, 1>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d, jobs,
                                    make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb, out_sorted,
                                    grad_sorted);
+            } else if (wide) {
+                hipLaunchKernelGGL((p2p_kernel<ID, false, DIRECT_KB_WIDE>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d,
+                                   jobs, make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb,
+                                   out_sorted, grad_sorted);
             } else {
                 hipLaunchKernelGGL((p2p_kernel<ID, false, DIRECT_KB>), dim3(jobs.n_jobs), dim3(256), 0, s, ks, d,
                                    jobs, make_xyz(tgt_xyz), n_tgt, make_xyz(src_xyz), w_sorted, N, k0, kb,
                                    out_sorted, grad_sorted);
             }
+            k0 += kb;
         }
     });
 }

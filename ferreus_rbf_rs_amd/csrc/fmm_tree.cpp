@@ -1070,35 +1070,63 @@ int FmmTree::build_source_target_set() {
 // own jobs.  (U lists are symmetric: linear_tree.rs:295-364 collects adjacent leaves from both sides.)
 int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe) {
     const HostTree &t = tree_;
+    const int64_t max_rows = p2p_sym_rows_per_job();
+    const int64_t nj_cells = static_cast<int64_t>(job_cells.size());
+    // per chunk of leaves into local buffers (threads), concatenated in order
+    constexpr int64_t kChunkS = 2048;
+    const int64_t nch = (nj_cells + kChunkS - 1) / kChunkS;
+    struct Part {
+        std::vector<int32_t> runs, tb, te;
+        std::vector<int64_t> range; // run ranges relative to the part's first run
+    };
+    std::vector<Part> parts(static_cast<size_t>(std::max<int64_t>(nch, 1)));
+    parallel_for_chunks(nj_cells, kChunkS, [&](int64_t lo, int64_t hi) {
+        for (int64_t c0 = lo; c0 < hi; c0 += kChunkS) {
+            Part &P = parts[static_cast<size_t>(c0 / kChunkS)];
+            auto add = [&](int64_t b, int64_t e, int two) {
+                if (e <= b) return;
+                P.runs.push_back(static_cast<int32_t>(b));
+                P.runs.push_back(static_cast<int32_t>(e));
+                P.runs.push_back(two);
+            };
+            for (int64_t j = c0; j < std::min(hi, c0 + kChunkS); ++j) {
+                const int32_t c = job_cells[static_cast<size_t>(j)];
+                const int64_t a0 = t.pt_begin[c], a1 = t.pt_end[c];
+                const int64_t first = static_cast<int64_t>(P.runs.size() / 3);
+                add(a0, a1, 0); // self interaction included (bbfmm.rs:1162-1251)
+                for (int64_t r = u_runs_.ptr[c]; r < u_runs_.ptr[c + 1]; ++r) {
+                    const int64_t b = u_runs_.idx[2 * r], e = u_runs_.idx[2 * r + 1];
+                    add(b, std::min({e, a0, pb}), 0);         // before the leaf, another rank's
+                    add(std::max(b, a1), std::min(e, pe), 1); // after the leaf, inside the range
+                    add(std::max({b, a1, pe}), e, 0);         // after the leaf, another rank's
+                }
+                const int64_t last = static_cast<int64_t>(P.runs.size() / 3);
+                // the leaf's rows in equal chunks of at most max_rows
+                const int64_t na = a1 - a0, nj = (na + max_rows - 1) / max_rows;
+                for (int64_t i = 0; i < nj; ++i) {
+                    P.tb.push_back(static_cast<int32_t>(a0 - pb + na * i / nj));
+                    P.te.push_back(static_cast<int32_t>(a0 - pb + na * (i + 1) / nj));
+                    P.range.push_back(first);
+                    P.range.push_back(last);
+                }
+            }
+        }
+    });
     std::vector<int64_t> range;
     std::vector<int32_t> runs, tb, te;
-    runs.reserve(job_cells.size() * 24);
-    auto add = [&](int64_t b, int64_t e, int two) {
-        if (e <= b) return;
-        runs.push_back(static_cast<int32_t>(b));
-        runs.push_back(static_cast<int32_t>(e));
-        runs.push_back(two);
-    };
-    const int64_t max_rows = p2p_sym_rows_per_job();
-    for (size_t j = 0; j < job_cells.size(); ++j) {
-        const int32_t c = job_cells[j];
-        const int64_t a0 = t.pt_begin[c], a1 = t.pt_end[c];
-        const int64_t first = static_cast<int64_t>(runs.size() / 3);
-        add(a0, a1, 0); // self interaction included (bbfmm.rs:1162-1251)
-        for (int64_t r = u_runs_.ptr[c]; r < u_runs_.ptr[c + 1]; ++r) {
-            const int64_t b = u_runs_.idx[2 * r], e = u_runs_.idx[2 * r + 1];
-            add(b, std::min({e, a0, pb}), 0);         // before the leaf, another rank's
-            add(std::max(b, a1), std::min(e, pe), 1); // after the leaf, inside the range
-            add(std::max({b, a1, pe}), e, 0);         // after the leaf, another rank's
-        }
-        const int64_t last = static_cast<int64_t>(runs.size() / 3);
-        // the leaf's rows in equal chunks of at most max_rows
-        const int64_t na = a1 - a0, nj = (na + max_rows - 1) / max_rows;
-        for (int64_t i = 0; i < nj; ++i) {
-            tb.push_back(static_cast<int32_t>(a0 - pb + na * i / nj));
-            te.push_back(static_cast<int32_t>(a0 - pb + na * (i + 1) / nj));
-            range.push_back(first);
-            range.push_back(last);
+    {
+        size_t nr = 0, njobs = 0;
+        for (const Part &P : parts) nr += P.runs.size(), njobs += P.tb.size();
+        runs.reserve(nr);
+        tb.reserve(njobs);
+        te.reserve(njobs);
+        range.reserve(2 * njobs);
+        for (const Part &P : parts) {
+            const int64_t base = static_cast<int64_t>(runs.size() / 3);
+            runs.insert(runs.end(), P.runs.begin(), P.runs.end());
+            tb.insert(tb.end(), P.tb.begin(), P.tb.end());
+            te.insert(te.end(), P.te.begin(), P.te.end());
+            for (int64_t v : P.range) range.push_back(base + v);
         }
     }
     ts->n_wx_jobs = 0;
