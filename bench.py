@@ -211,6 +211,9 @@ def roofline_of(stats, K, per_launch, world):
         "M2L_stage1": {"bound": "mfma", "work": m2l_stage_flops, "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "scale": 1e-12},
         "M2L_stage2": {"bound": "mfma", "work": m2l_stage_flops, "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "scale": 1e-12},
         "P2P": {"bound": "hbm", "work": float(p2p_tile_bytes), "unit": "GB/s", "peak": HBM_PEAK_GBPS, "scale": 1e-9},
+        # the adaptive-list kernels (M2P + P2L; fused into the P2L phase for one rhs): FP64-VALU bound like P2P,
+        # quoted against HBM with their tile traffic (points of the leaf + nodes, multipoles and locals of the W cell)
+        "P2L": {"bound": "hbm", "work": float(stats.wx_tile_bytes_k1 * K), "unit": "GB/s", "peak": HBM_PEAK_GBPS, "scale": 1e-9},
     }
     dominant = max(kern, key=lambda k: per_launch[k])
     kd = kern[dominant]

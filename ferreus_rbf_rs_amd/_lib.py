@@ -33,7 +33,7 @@ class TreeStats(ctypes.Structure):
                 ("n_points", c_i64), ("n_cells", c_i64), ("n_leaves", c_i64),
                 ("n_u", c_i64), ("n_v", c_i64), ("n_w", c_i64), ("n_x", c_i64),
                 ("p2p_pairs", c_i64), ("p2p_tile_bytes_k1", c_i64), ("m2l_flops_k1", c_f64),
-                ("center", c_f64 * 3), ("radius", c_f64)]
+                ("center", c_f64 * 3), ("radius", c_f64), ("wx_pairs", c_i64), ("wx_tile_bytes_k1", c_i64)]
 
 
 # every symbol include/ferreus_bbfmm_hip.h declares: name -> (restype, argtypes)

@@ -2255,6 +2255,11 @@ void FmmTree::stats(bbfmm_tree_stats *out) const {
     }
     out->p2p_pairs = pairs;
     out->p2p_tile_bytes_k1 = tile_bytes;
+    for (int32_t c : src_leaves_) {
+        const int64_t nt = t.pt_end[c] - t.pt_begin[c], nw = t.w.ptr[c + 1] - t.w.ptr[c];
+        out->wx_pairs += nt * nw * ops_.n;
+        out->wx_tile_bytes_k1 += nw * (nt * per_pt + 2 * static_cast<int64_t>(ops_.n) * 8);
+    }
     out->m2l_flops_k1 = m2l_flops_k1_;
     for (int a = 0; a < d_; ++a) out->center[a] = t.center[a];
     out->radius = t.radius;

@@ -206,6 +206,8 @@ typedef struct {
     double m2l_flops_k1;                     /* sum_pairs 4*n*r (2*n*n if uncompressed) */
     double center[3];
     double radius;
+    int64_t wx_pairs;                        /* sum over (leaf, W cell) of n_t * n: kernel evaluations of M2P (= of P2L) */
+    int64_t wx_tile_bytes_k1;                /* tile traffic of M2P + P2L at K=1: per (leaf, W cell) n_t*(8d+8) + 2*n*8 */
 } bbfmm_tree_stats;
 
 int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out);

@@ -38,7 +38,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE', 'MfmaUtil', 'MfmaFlopsF64', 'VALUBusy', 'V
                 agg[name]['dur_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 mean = lambda v: sum(v) / len(v) if v else None
 phase = {'m2l_gemm_k4<11, 1, 1>': 'M2L_stage1', 'm2l_gemm_k4<22, 2, 1>': 'M2L_stage2', 'p2p_sym_kernel<0>': 'P2P',
-         'p2p_kernel<0, false, 1>': 'P2P'}
+         'p2p_kernel<0, false, 1>': 'P2P', 'wx_sym_kernel<0>': 'P2L'}
 per_bytes, per_kernel, lines = {}, {}, []
 for k, v in sorted(agg.items()):
     fb = 2 * mean(v.get('FETCH_SIZE')) * 1024 if v.get('FETCH_SIZE') else None
@@ -58,7 +58,7 @@ for k, v in sorted(agg.items()):
                          'executed_fp64_mfma_flops_per_launch': mean(v.get('MfmaFlopsF64')),
                          'valu_busy_pct': mean(v.get('VALUBusy')), 'valu_utilization_pct': mean(v.get('VALUUtilization'))}
 open(root + '/%s_counters.txt' % tag, 'w').write('\n'.join(lines) + '\n')
-print('\n'.join(l for l in lines if any(s in l for s in ('m2l_gemm', 'p2p', 'p2m', 'l2p'))))
+print('\n'.join(l for l in lines if any(s in l for s in ('m2l_gemm', 'p2p', 'p2m', 'l2p', 'wx_sym'))))
 json.dump({'source_hash': bench.source_hash(), 'workload': [10000000, 'LinearRbf', 7, 1], 'per_launch_bytes': per_bytes,
            'per_kernel': per_kernel,
            'note': 'rocprofv3 --kernel-trace --pmc <one counter or derived metric per pass>; bytes = 2*FETCH_SIZE_KiB*1024 + '
