@@ -1211,7 +1211,7 @@ __device__ inline void dma16s(const double *sbase, unsigned voff_bytes, unsigned
 // cells' IN values of step q+1 stream into LDS by DMA while step q is multiplied.
 template <int NG16, int STAGE, int MINW>
 __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restrict__ classes,
-                                                  const M2lTileDesc *__restrict__ tiles, int n_pad, int n_real, int g16_0,
+                                                  const M2lTileDesc *__restrict__ tiles, int n_pad, int g16_0,
                                                   int64_t C, const double *__restrict__ in, int64_t in_len,
                                                   double *__restrict__ out, int64_t out_len,
                                                   const uint16_t *__restrict__ qlist, int slot_t,
@@ -1302,7 +1302,6 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
 
     const int bk = lane >> 4, bj = lane & 3; // B layout (k, j); the block index is broadcast
     const bool wave_live = wave * 16 < tile.count;
-    const int e_last = min(4, (n_real - 16 * (nq - 1) + 3) / 4); // k-slices of the last contraction step that hold real nodes
     const int n_steps = (zb1 - zb0) * nq;
     // epilogue coordinates: D[b][i][j] at lane 16 i + 4 b + j = OUT[cell 4 tg + j][col0 + 16 g + 4 b + i]
     const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
@@ -1363,12 +1362,8 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                     bq[tg][2 * eh] = v.x;
                     bq[tg][2 * eh + 1] = v.y;
                 }
-            // stage 1 contracts over the n real nodes: in the last step of a column block the k-slices that hold
-            // only the zero padding n .. n_pad are skipped (p = 7: rows 344 .. 351 = two of the four slices)
-            const int e_lim = (STAGE == 1 && qcnt == nq - 1) ? e_last : 4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (e >= e_lim) break;
 #pragma unroll
                 for (int pr = 0; pr < NP; ++pr) {
                     const double2 a = op2[(e * NP + pr) * 64];
@@ -1708,7 +1703,7 @@ void launch_p2l(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32
 }
 
 template <int NG16, int STAGE, int MINW>
-static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int n_real, int g16_0,
+static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g16_0,
                             int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
                             int64_t out_len, const uint16_t *qlist, int slot_t, const int32_t *tile_idx, hipStream_t s) {
     const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 128 + 8 * 16 * slot_t) * 4 : 0); // + aux, cell and slot tables
@@ -1719,7 +1714,7 @@ static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, i
         attr_set = true;
     }
     hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, n_colblocks), dim3(512), lds, s, classes,
-                       tiles, n_pad, n_real, g16_0, C, in, in_len, out, out_len, qlist, slot_t, tile_idx);
+                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t, tile_idx);
 }
 
 // Column-chunk plan: 16-column groups per workgroup.  Stage 1 walks column blocks of kM2lS1Block =
@@ -1738,7 +1733,7 @@ template <int STAGE> static int m2l_chunk_pref() {
 
 template <int STAGE>
 static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
-                                int n_pad, int n_real, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
+                                int n_pad, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
                                 double *out, int64_t out_len, const uint16_t *qlist, int slot_t,
                                 const int32_t *tile_idx, hipStream_t s) {
     int done = 0;
@@ -1749,7 +1744,7 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
 #define M2L_GO(NG, MW)                                                                                              \
     {                                                                                                               \
         take = NG;                                                                                                  \
-        m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, n_real, done, n_colblocks, K, C, in, in_len, out, \
+        m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done, n_colblocks, K, C, in, in_len, out,    \
                                        out_len, qlist, slot_t, tile_idx, s);                                        \
     }
         if (pref == 22 && left >= 22) M2L_GO(22, 1)
@@ -1767,7 +1762,7 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
 // Stage 1: every class's stacked operator is padded to a whole number of kM2lS1Block columns;
 // blockIdx.z walks the column blocks, the chunk plan splits a block.
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
-                       int n_pad, int n_real, int max_slot_t, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
+                       int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
                        hipStream_t s, bool own_blocks) {
     if (n_tiles == 0) return;
     int slot_t = 16; // LDS slot-table width: power of two covering the transfer vectors of any block
@@ -1803,7 +1798,7 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
         }
     }
     const int n_colblocks = own_blocks ? 1 : zsplit; // tiles that name their own blocks are not split further
-    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_real, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, slot_t, tile_idx, s);
+    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, slot_t, tile_idx, s);
 }
 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
@@ -1811,7 +1806,7 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
                        double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
 }
 
 // ------------------------------------------------------------------ stacked M2L operators, assembled in HBM

@@ -89,7 +89,7 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
 // tile_idx: NULL, or for tiles with pad != 0 the class positions of the tile's cells
 // (tile.first indexes tile_idx; a partition's compact source tiles)
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
-                       int n_pad, int n_real, int max_slot_t, int K, int64_t C, const double *M, double *cbuf,
+                       int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf,
                        int64_t cbuf_len, hipStream_t s, bool own_blocks = false);
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,

@@ -1443,10 +1443,10 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     phase_begin();
     if (dp)
         launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles1_h.size()),
-                          cheb_.n_pad, cheb_.n, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_, dp->tiles1_own_blocks);
+                          cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_, dp->tiles1_own_blocks);
     else
         launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p, d_tile_idx1_.p, static_cast<int>(m2l_tiles1_h_.size()), cheb_.n_pad,
-                          cheb_.n, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
+                          m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
     phase_end(kPhM2L1);
     phase_begin();
     if (dp)
