@@ -150,7 +150,8 @@ def dense_rows_torch(torch, kernel, br, sill, x, pts, w):
         phi = torch.sqrt(1.0 + r2 / (br * br))
     else:
         return None
-    return phi @ w.T                                                           # rows x K
+    # rows x K (as row sums: rocBLAS picks a very slow kernel for a 32 x N x 1 product)
+    return torch.stack([(phi * w[k]).sum(1) for k in range(w.shape[0])], 1)
 
 
 def cpu_baseline(args, kernel_id):
