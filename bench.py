@@ -92,11 +92,30 @@ def launch_ranks(args) -> int:
                     "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = max(rc, abs(p.wait()))
-    sys.stdout.write(out.decode())
+    # relay rank 0's stdout; if any rank dies, stop the others (they would wait in the rendezvous for minutes)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [p.poll() for p in procs]
+        if any(c not in (None, 0) for c in codes):
+            rc = max(abs(c) for c in codes if c not in (None, 0))
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()          # our own children, by handle
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     return rc
 
