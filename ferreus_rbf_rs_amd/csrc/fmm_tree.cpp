@@ -965,7 +965,15 @@ int FmmTree::upload() {
             CHK(dupload(&d_tgt, tgt_tv));
             const M2lAssembleClass ac{d_src.p, d_tgt.p, static_cast<int32_t>(src_tv.size()), static_cast<int32_t>(tgt_tv.size()),
                                       h.r_pad16, h.k_pad, max_rank};
-            launch_m2l_assemble(ac, ops_.n, cheb_.n_pad, compressed, d_level_ops[h.level].p, d_invperm.p, vt.p, ua.p, stream_);
+            static const bool host_fill = std::getenv("BBFMM_M2L_ASSEMBLE_HOST") != nullptr; // checker: the host fill of round 1
+            if (host_fill) {
+                std::vector<double> hv, hu;
+                fill_m2l_operator_arrays(h, &hv, &hu);
+                HIPCHK(hipMemcpy(vt.p, hv.data(), hv.size() * sizeof(double), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(ua.p, hu.data(), hu.size() * sizeof(double), hipMemcpyHostToDevice));
+            } else {
+                launch_m2l_assemble(ac, ops_.n, cheb_.n_pad, compressed, d_level_ops[h.level].p, d_invperm.p, vt.p, ua.p, stream_);
+            }
             assemble_tmp.push_back(d_src);
             assemble_tmp.push_back(d_tgt);
         }

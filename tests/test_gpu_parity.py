@@ -329,3 +329,16 @@ def test_device_target_grouping_equals_host_grouping(d):
     ts.set_weights(w)
     perm = rng.permutation(n)
     assert relerr(ts.evaluate(w, pts[perm]), ts.evaluate(w, pts)[perm]) < 1e-13
+
+
+def test_twelve_clusters_sparse_levels_order7():
+    """The soak run's cloud (twelve Gaussian clusters of very different widths, clipped to the unit cube): sparse
+    coarse levels, classes with a handful of cells, W / X lists at every level -- values, M and L against the
+    oracle and the dense sum.  (Caught a wrong contraction in M2L stage 1 that uniform clouds did not.)"""
+    rng = np.random.default_rng(123)
+    k, n = 12, 100000
+    c, s, which = rng.random((k, 3)), 0.01 + 0.08 * rng.random(k), rng.integers(0, k, n)
+    pts = np.clip(c[which] + rng.normal(size=(n, 3)) * s[which, None], 0.0, 0.999)
+    t, r, _ = check(pts, nrhs=1, dense_tol=1e-6)
+    assert t.stats().depth >= 7 and t.stats().n_w > 0
+    check(pts, nrhs=3, adaptive=False, dense_tol=1e-6)
