@@ -342,3 +342,28 @@ def test_twelve_clusters_sparse_levels_order7():
     t, r, _ = check(pts, nrhs=1, dense_tol=1e-6)
     assert t.stats().depth >= 7 and t.stats().n_w > 0
     check(pts, nrhs=3, adaptive=False, dense_tol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["coincident", "planar_in_3d", "two_points", "far_from_origin", "negative_box", "collinear"])
+def test_degenerate_clouds(name):
+    """Clouds the tree build has to survive: many coincident points (subdivision down to level 16, one leaf over
+    the limit), a plane or a line embedded in 3-D (most cells empty), two points, coordinates far from the origin
+    (root box from floor / ceil of the extents), a box in the negative octant."""
+    rng = np.random.default_rng(abs(hash(name)) % 1000)
+    if name == "coincident":
+        pts = np.vstack([rng.random((3000, 3)), np.tile(rng.random((1, 3)), (600, 1))])
+    elif name == "planar_in_3d":
+        pts = np.column_stack([rng.random((8000, 2)), np.full(8000, 0.37)])
+    elif name == "two_points":
+        pts = np.array([[0.1, 0.2, 0.3], [0.8, 0.7, 0.9]])
+    elif name == "far_from_origin":
+        pts = rng.random((6000, 3)) * 0.8 + np.array([1.0e5, -3.0e4, 7.0e3])
+    elif name == "negative_box":
+        pts = -rng.random((6000, 3)) * 5.0
+    else:
+        pts = np.outer(rng.random(5000), np.array([0.6, 0.3, 0.2])) + 0.1
+    t, r, w = check(pts, nrhs=1, order=5, params=(50, O.COMPRESSION_ACA, 1e-5, 1024), dense_tol=1e-3)
+    assert t.tree_built_on_device()
+    # the matvec entry point (unordered near field, fused adaptive lists) on the same cloud
+    y = t.fast_matrix_vector_product(w[:, 0].copy())
+    assert relerr(y, r.evaluate(w, pts)[:, 0]) < TOL
