@@ -1735,9 +1735,9 @@ template <int STAGE>
 static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
                                 int n_pad, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
                                 double *out, int64_t out_len, const uint16_t *qlist, int slot_t,
-                                const int32_t *tile_idx, hipStream_t s, int pref_override = 0) {
+                                const int32_t *tile_idx, hipStream_t s) {
     int done = 0;
-    const int pref = pref_override ? pref_override : m2l_chunk_pref<STAGE>();
+    const int pref = m2l_chunk_pref<STAGE>();
     while (done < total_groups) {
         const int left = total_groups - done;
         int take;
@@ -1802,21 +1802,11 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
 }
 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
-// The last n_tail descriptors (a short last round, fmm_tree.cpp split_tile_tail) are launched with half the
-// columns per workgroup (11 groups instead of 22: twice the workgroups, half the time each).
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
-                       int n_tail, int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
+                       int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
                        double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    static const bool tail_split = [] {
-        const char *e = std::getenv("BBFMM_M2L_S2_TAIL_SPLIT");
-        return !e || std::atoi(e) != 0;
-    }();
-    if (!tail_split || n_tail <= 0 || n_tail >= n_tiles || m2l_chunk_pref<2>() != 22) n_tail = 0;
-    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles - n_tail, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
-    if (n_tail > 0)
-        m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles + (n_tiles - n_tail), n_tail, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0,
-                               tile_idx, s, 11);
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
 }
 
 // ------------------------------------------------------------------ stacked M2L operators, assembled in HBM

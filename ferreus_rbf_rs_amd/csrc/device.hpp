@@ -92,7 +92,7 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
                        int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf,
                        int64_t cbuf_len, hipStream_t s, bool own_blocks = false);
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
-                       int n_tail, int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
+                       int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
                        const uint16_t *qlist, double *L, hipStream_t s);
 
 // Assembly of one class's stacked operators on the device (device.hip "stacked M2L operators").

@@ -430,15 +430,11 @@ void FmmTree::fill_m2l_operator_arrays(const HostM2lClass &hc, double *vt_all, d
 // When the last round is at most half full its tiles are halved (a workgroup whose upper four
 // waves hold no cells runs one wave per SIMD and takes about half the time): the tail costs half a
 // round instead of a whole one.
-// Returns the number of descriptors at the end of the list that form such a short last round AND are few
-// enough (at most a quarter of the CUs before halving) for the launcher to split them along the output columns
-// as well (two workgroups of half the columns each: the tail then costs a quarter of a round); 0 otherwise.
-static int split_tile_tail(std::vector<M2lTileDesc> *tiles, int n_cu) {
+static void split_tile_tail(std::vector<M2lTileDesc> *tiles, int n_cu) {
     const size_t T = tiles->size();
     const size_t r = T % static_cast<size_t>(n_cu);
-    if (r == 0 || r > static_cast<size_t>(n_cu) / 2) return 0;
+    if (r == 0 || r > static_cast<size_t>(n_cu) / 2) return;
     std::vector<M2lTileDesc> out(tiles->begin(), tiles->end() - static_cast<std::ptrdiff_t>(r));
-    const size_t head = out.size();
     for (size_t i = T - r; i < T; ++i) {
         const M2lTileDesc td = (*tiles)[i];
         if (td.count <= kM2lTile / 2) {
@@ -453,7 +449,6 @@ static int split_tile_tail(std::vector<M2lTileDesc> *tiles, int n_cu) {
         out.push_back(b);
     }
     tiles->swap(out);
-    return r <= static_cast<size_t>(n_cu) / 4 ? static_cast<int>(tiles->size() - head) : 0;
 }
 
 int FmmTree::build_m2l_tables() {
@@ -1008,7 +1003,7 @@ int FmmTree::upload() {
     CHK(dupload(&d_m2l_tiles1_, m2l_tiles1_h_));
     CHK(dupload(&d_tile_idx1_, m2l_tile_idx1_h_));
     m2l_tiles2_h_ = m2l_tiles_h_;
-    m2l_tiles2_tail_ = split_tile_tail(&m2l_tiles2_h_, n_cu_);
+    split_tile_tail(&m2l_tiles2_h_, n_cu_);
     CHK(dupload(&d_m2l_tiles2_, m2l_tiles2_h_));
     CHK(dupload(&d_m2l_qlist_, m2l_qlist_h_));
     std::vector<uint8_t> act(static_cast<size_t>(C), 1);
@@ -1464,10 +1459,10 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     phase_begin();
     if (dp)
         launch_m2l_stage2(d_m2l_classes_.p, dp->d_tiles2.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles2_h.size()),
-                          dp->tiles2_tail, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, d_L_.p, stream_);
+                          cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, d_L_.p, stream_);
     else
         launch_m2l_stage2(d_m2l_classes_.p, d_m2l_tiles2_.p, nullptr, static_cast<int>(m2l_tiles2_h_.size()),
-                          m2l_tiles2_tail_, cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, d_L_.p, stream_);
+                          cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, d_L_.p, stream_);
     phase_end(kPhM2L2);
     phase_begin();
     if (t.adaptive && wx) { // targets = all sources, one rhs: P2L and M2P share their kernel evaluations (X = W^T)
@@ -1900,7 +1895,7 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
             td.q_count = static_cast<int32_t>(dp->qlist_h.size()) - td.q_first;
         }
     }
-    dp->tiles2_tail = split_tile_tail(&dp->tiles2_h, n_cu_);
+    split_tile_tail(&dp->tiles2_h, n_cu_);
     // Sparse target sets: a needed source cell still needs only the column blocks (kM2lS1Block stacked
     // rows = a few transfer vectors) that hold a transfer vector towards an ACTIVE target.  When that is
     // well under the whole operator, stage 1 runs one tile per (column block, the sources it needs).

@@ -75,7 +75,6 @@ struct TargetSet { // targets sorted by leaf, resident on the device
 struct DownwardPlan {
     std::vector<uint8_t> active;            // cells with targets (leaves and their ancestors)
     std::vector<M2lTileDesc> tiles2_h;      // compact stage-2 tiles over the active cells (tail split)
-    int tiles2_tail = 0;                    // descriptors at the end that the launcher also splits along the columns
     std::vector<M2lTileDesc> tiles1_h;      // compact stage-1 tiles over the V-list sources of active cells
     bool tiles1_own_blocks = false;         // sparse plan: a stage-1 tile per (column block, sources that block needs)
     std::vector<int32_t> tile_idx_h;        // class positions of the cells of both tile lists
@@ -225,7 +224,6 @@ class FmmTree {
     double m2l_flops_k1_ = 0;
     int n_cu_ = 256;      // compute units of the device (tail splitting of the tile lists)
     std::vector<M2lTileDesc> m2l_tiles2_h_; // stage-2 launch list: m2l_tiles_h_ with a split tail
-    int m2l_tiles2_tail_ = 0;               // see split_tile_tail
     int m2l_slot_t_ = 1; // most transfer vectors any stage-1 column block touches
     // partition
     int part_rank_ = 0, part_world_ = 1;
