@@ -1242,12 +1242,6 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     constexpr int NCH = (OP_CHUNKS + 7) / 8;
     constexpr int OP_DOUBLES = OP_CHUNKS * 128;
     constexpr int BUF = OP_DOUBLES + 2048;
-    // LDS buffers of (operator chunk, IN tile): stage 1 streams two steps ahead (three buffers), so that the DMA of
-    // the two steps after a block's scatter is already in flight when the stores go out -- gfx9 retires vector
-    // memory operations of a wave in issue order, and a DMA issued after the stores lands only when they have
-    // drained.  Stage 2 (88 accumulators, twice the operator chunk) has room for two buffers only.
-    constexpr int NBUF = STAGE == 1 ? 3 : 2;
-    constexpr int LA = NBUF - 1;
 
     // Operator image in LDS.  The NG16 column groups are taken as NP pairs (+ one single group when
     // NG16 is odd).  A pair chunk (e, pr) is [k][p = 4b + i][2]: lane 16k + p holds columns
@@ -1321,11 +1315,11 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     //                              (requested two steps before the block ends)
     // and the stores of a block leave together and drain under the next block.
     constexpr int AUX = 192;
-    const int32_t *aux = reinterpret_cast<const int32_t *>(lds + NBUF * BUF);
-    int32_t *ptab = reinterpret_cast<int32_t *>(lds + NBUF * BUF) + 2 * AUX; // class positions of the 128 cells
+    const int32_t *aux = reinterpret_cast<const int32_t *>(lds + 2 * BUF);
+    int32_t *ptab = reinterpret_cast<int32_t *>(lds + 2 * BUF) + 2 * AUX; // class positions of the 128 cells
     const int32_t *slds = aux + 2 * AUX + 128 + wave * 16 * slot_t;
     if (STAGE == 1 && lane < 16) ptab[wave * 16 + lane] = cell_p(wave * 16 + lane); // read by this wave only
-    const unsigned aux0 = lds0 + (unsigned)(NBUF * BUF) * 8u;
+    const unsigned aux0 = lds0 + (unsigned)(2 * BUF) * 8u;
     auto stage_cols = [&](int zb_, int par) {
         if (STAGE == 1 && 64 * wave <= 16 * NG16) {
             const int e = 64 * wave + lane;
@@ -1344,24 +1338,20 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
         }
     };
     if (n_steps > 0) {
-        stage_cols(zb0, 0);
         stage(0, 0);
-        if (LA == 2 && n_steps > 1) stage(1, 1);
+        stage_cols(zb0, 0);
     }
     wait_dma_and_barrier();
-    int qcnt = 0, zb = zb0, cur = 0; // cur = sidx % NBUF
-    bool after_block = false;          // stage 1: the previous step ended a column block (its stores are in flight)
+    int qcnt = 0, zb = zb0;
     for (int sidx = 0; sidx < n_steps; ++sidx) {
-        const double *op = lds + cur * BUF + lane;
-        const double2 *op2 = reinterpret_cast<const double2 *>(lds + cur * BUF) + lane;
-        const double *ct = lds + cur * BUF + OP_DOUBLES + wave * 256 + (bk * 4 + bj) * 2;
-        if (STAGE == 1) { // (table DMA first: the newest operations of a step are always the >= 4 of stage())
+        const double *op = lds + (sidx & 1) * BUF + lane;
+        const double2 *op2 = reinterpret_cast<const double2 *>(lds + (sidx & 1) * BUF) + lane;
+        const double *ct = lds + (sidx & 1) * BUF + OP_DOUBLES + wave * 256 + (bk * 4 + bj) * 2;
+        if (sidx + 1 < n_steps) stage(sidx + 1, (sidx + 1) & 1); // streams in under the MFMAs below
+        if (STAGE == 1) {
             if (qcnt == 0 && zb + 1 < zb1) stage_cols(zb + 1, (zb + 1 - zb0) & 1);
             if (qcnt == nq - 2) stage_slots((zb - zb0) & 1);
         }
-        const bool ahead = sidx + LA < n_steps;
-        if (ahead) stage(sidx + LA, cur + LA >= NBUF ? cur + LA - NBUF : cur + LA); // streams in under the MFMAs below
-        cur = cur + 1 == NBUF ? 0 : cur + 1;
         if (wave_live) { // a wave without cells (short tile) only helps with the DMA and the barriers
             double bq[4][4];
 #pragma unroll
@@ -1449,29 +1439,13 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
             // the 4 * (NP + NS) scatter stores issued after this step's DMA drain under the next block
             // (a wave without cells stored nothing: it waits for its DMA as usual)
             if (STAGE == 1) {
-                // what the next step reads (DMA of step sidx + 1) was issued a step ago; still allowed in flight: this
-                // block's stores and the four newest operations of the DMA of step sidx + 2 issued above
-                constexpr int NST = 4 * (NP + NS);
-                if (!ahead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (wave_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 4 < 63 ? NST + 4 : 63) : "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (wave_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NP + NS) < 63 ? 4 * (NP + NS) : 63) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
-                after_block = true;
                 continue;
             }
         }
-        if (STAGE == 1) {
-            constexpr int NST = 4 * (NP + NS);
-            // the first step of a block: the stores of the previous block may still be draining in front of this
-            // step's DMA; the data of the next step was issued before them, so they need not be waited for
-            if (!ahead) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (after_block && wave_live) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST + 4 < 63 ? NST + 4 : 63) : "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            __syncthreads();
-            after_block = false;
-        } else {
-            wait_dma_and_barrier();
-        }
+        wait_dma_and_barrier();
     }
 }
 
@@ -1732,7 +1706,7 @@ template <int NG16, int STAGE, int MINW>
 static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g16_0,
                             int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
                             int64_t out_len, const uint16_t *qlist, int slot_t, const int32_t *tile_idx, hipStream_t s) {
-    const size_t lds = (STAGE == 1 ? 3 : 2) * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 128 + 8 * 16 * slot_t) * 4 : 0); // buffers + aux, cell and slot tables
+    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 128 + 8 * 16 * slot_t) * 4 : 0); // + aux, cell and slot tables
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_gemm_k4<NG16, STAGE, MINW>),
