@@ -17,7 +17,8 @@ using bbfmm::FmmTree;
 
 #define GUARD(h)                              \
     if (!(h)) return BBFMM_BAD_ARGUMENT;      \
-    try {
+    try {                                     \
+        (h)->tree.bind_device();
 #define END_GUARD(h)                                   \
     }                                                  \
     catch (const std::bad_alloc &) {                   \
@@ -145,7 +146,11 @@ int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t
     END_GUARD(h)
 }
 
-void *bbfmm_stream(bbfmm_handle *h) { return h ? static_cast<void *>(h->tree.stream()) : nullptr; }
+void *bbfmm_stream(bbfmm_handle *h) {
+    if (!h) return nullptr;
+    h->tree.bind_device();
+    return static_cast<void *>(h->tree.stream());
+}
 
 int bbfmm_target_subset_create(bbfmm_handle *h, const int64_t *target_indices, int64_t n_target_indices,
                                int32_t *subset_id) {
@@ -302,6 +307,7 @@ int bbfmm_set_profiling(bbfmm_handle *h, int32_t enable) {
 
 int bbfmm_get_phase_ms(bbfmm_handle *h, double *ms_out, int64_t *count_out) {
     if (!h || !ms_out) return BBFMM_BAD_ARGUMENT;
+    h->tree.bind_device();
     std::memcpy(ms_out, h->tree.phase_ms(), sizeof(double) * BBFMM_N_PHASES);
     if (count_out) std::memcpy(count_out, h->tree.phase_count(), sizeof(int64_t) * BBFMM_N_PHASES);
     return BBFMM_OK;

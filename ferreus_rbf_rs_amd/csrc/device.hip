@@ -1236,7 +1236,9 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     const int nq = STAGE == 1 ? n_pad / 16 : tile.q_count;
     const uint16_t *ql = qlist + tile.q_first;
     if (zb0 >= zb1) return;
-    const double *opbase = (STAGE == 1 ? cls.vt_all : cls.u_all) + 16 * g16_0;
+    // stage 2 with gridDim.z > 1: the z workgroups of a tile take adjacent chunks of NG16 column groups
+    const int g16 = g16_0 + (STAGE == 2 ? (int)blockIdx.z * NG16 : 0);
+    const double *opbase = (STAGE == 1 ? cls.vt_all : cls.u_all) + 16 * g16;
 
     constexpr int OP_CHUNKS = 2 * NG16;
     constexpr int NCH = (OP_CHUNKS + 7) / 8;
@@ -1323,7 +1325,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     auto stage_cols = [&](int zb_, int par) {
         if (STAGE == 1 && 64 * wave <= 16 * NG16) {
             const int e = 64 * wave + lane;
-            const int32_t *src = e < 16 * NG16 ? cls.row_dst + zb_ * kM2lS1Block + 16 * g16_0 + e : cls.blk_t0 + zb_;
+            const int32_t *src = e < 16 * NG16 ? cls.row_dst + zb_ * kM2lS1Block + 16 * g16 + e : cls.blk_t0 + zb_;
             dma4(src, aux0 + (unsigned)(par * AUX + 64 * wave) * 4u);
         }
     };
@@ -1384,7 +1386,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
         }
         if (++qcnt == nq) { // a column block is complete: write it out, start the next one
             qcnt = 0;
-            const int col0 = zb * kM2lS1Block + 16 * g16_0;
+            const int col0 = zb * kM2lS1Block + 16 * g16;
             ++zb;
             if (STAGE == 1 && wave_live) {
                 // Scatter into the target slots, branch-free: entries without a destination (padding
@@ -1744,10 +1746,14 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
 #define M2L_GO(NG, MW)                                                                                              \
     {                                                                                                               \
         take = NG;                                                                                                  \
-        m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done, n_colblocks, K, C, in, in_len, out,    \
-                                       out_len, qlist, slot_t, tile_idx, s);                                        \
+        m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done,                                        \
+                                       STAGE == 2 && !(NG == 11 && left >= 22) ? 1 : n_colblocks, K, C, in, in_len, \
+                                       out, out_len, qlist, slot_t, tile_idx, s);                                   \
     }
-        if (pref == 22 && left >= 22) M2L_GO(22, 1)
+        if (STAGE == 2 && n_colblocks == 2 && left >= 22) { // two workgroups of 11 groups per tile (gridDim.z)
+            M2L_GO(11, 1)
+            take = 22;
+        } else if (pref == 22 && left >= 22) M2L_GO(22, 1)
         else if (pref == 22 && left >= 16) M2L_GO(16, 1)
         else if (pref == 11 && left >= 11) M2L_GO(11, 1)
         else if (left >= 8) M2L_GO(8, 4)
@@ -1757,6 +1763,17 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
 #undef M2L_GO
         done += take;
     }
+}
+
+static int device_cu_count() {
+    static const int n_cu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return prop.multiProcessorCount;
+        return 256;
+    }();
+    return n_cu;
 }
 
 // Stage 1: every class's stacked operator is padded to a whole number of kM2lS1Block columns;
@@ -1774,13 +1791,7 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
         const int v = e ? std::atoi(e) : 0;
         return v >= 1 && v <= 16 ? v : 0;
     }();
-    static const int n_cu = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            return prop.multiProcessorCount;
-        return 256;
-    }();
+    const int n_cu = device_cu_count();
     // One workgroup per CU at a time: n_tiles * z workgroups take ceil(n_tiles * z / CUs) rounds of 1/z of the
     // column-block walk each; z is chosen so that the last, partially filled round is short (a per-workgroup
     // overhead of about half a percent of a walk keeps z small).  Measured at 10M points (2,336 tiles): z = 2 18.2 ms,
@@ -1806,7 +1817,17 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
                        double *L, hipStream_t s) {
     if (n_tiles == 0) return;
-    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, 1, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
+    // Two workgroups per tile, each with half of a 22-group chunk of the output nodes (gridDim.z = 2, 11 groups,
+    // 78 KB of LDS: two fit a CU).  The halves of a tile read the same slot contents at about the same time (L2
+    // hits) and twice as many, shorter workgroups balance tiles of unequal length (per-tile active steps) and fill
+    // the CUs of launches with few tiles.  Measured, stage 2 per matvec: 10M points 16.2 -> 15.8 ms, p = 9 55.1 ->
+    // 53.6, 1M points (about 200 tiles) 2.10 -> 1.54 and 1.12 -> 0.71, one rank of an 8-way partition 2.81 -> 2.28.
+    // (Two separate launches of 11 groups were slower than one of 22.)  BBFMM_M2L_S2_ZSPLIT=1 turns it off.
+    static const int z = [] {
+        const char *e = std::getenv("BBFMM_M2L_S2_ZSPLIT");
+        return e && std::atoi(e) == 1 ? 1 : 2;
+    }();
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, z, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
 }
 
 // ------------------------------------------------------------------ stacked M2L operators, assembled in HBM

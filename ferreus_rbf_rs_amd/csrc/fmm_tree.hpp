@@ -136,6 +136,12 @@ class FmmTree {
     const char *last_error() const { return err_.c_str(); }
     hipStream_t stream() const { return stream_; }
     bool host_only() const { return host_only_; }
+    // The handle may be used from any host thread (a solver's worker threads start with device 0 current):
+    // the C entry points call this first.
+    void bind_device() const {
+        if (device_ >= 0) (void)hipSetDevice(device_);
+    }
+    int device() const { return device_; }
     bool tree_built_on_device() const { return tree_built_on_device_; }
     void stats(bbfmm_tree_stats *out) const;
     void set_profiling(bool on) { profiling_ = on; }
@@ -223,6 +229,7 @@ class FmmTree {
     int64_t cbuf_len_ = 0;
     double m2l_flops_k1_ = 0;
     int n_cu_ = 256;      // compute units of the device (tail splitting of the tile lists)
+    int device_ = -1;     // the HIP device that was current in create(): every entry point binds its thread to it
     std::vector<M2lTileDesc> m2l_tiles2_h_; // stage-2 launch list: m2l_tiles_h_ with a split tail
     int m2l_slot_t_ = 1; // most transfer vectors any stage-1 column block touches
     // partition
@@ -300,6 +307,9 @@ class FmmTree {
     double *h_pin_ = nullptr; // pinned staging for the host-buffer matvec (N doubles up, N down)
     size_t h_pin_n_ = 0;
     int ensure_pinned(size_t n);
+    int stage_weights_to_device(const double *w, int64_t n); // host rows -> d_w_in_, staging and PCIe overlapped
+    static constexpr int64_t kHostPiece = int64_t(1) << 18;  // rows per piece of the host <-> device pipelines (2 MB)
+    std::vector<hipEvent_t> ev_out_;                         // per piece of the pipelined copy back
     TargetSet src_targets_;  // targets = sources (the matvec)
     TargetSet part_targets_; // sources owned by this rank (multi-GPU)
     bool have_part_ = false;

@@ -41,6 +41,7 @@ struct Schwarz {
     std::vector<double> ortho; // N x basis column-major, thin Q of mono (rbf.rs:493-495)
     std::vector<double> a_special; // coarse domain: k x n_coarse rows of A (domain.rs:352-355), row-major
     hipStream_t stream = nullptr;  // the tree's stream (not owned): products and level work stay in order
+    int device = -1;               // the tree's device: the entry points bind the calling thread to it
     // device vectors of a sweep (N doubles each): incoming residual, running correction, level residual,
     // local-solve output, partial product; the orthonormal polynomial basis; projection scratch
     double *d_rg = nullptr, *d_sl = nullptr, *d_res = nullptr, *d_out = nullptr, *d_y = nullptr;
@@ -218,8 +219,9 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
     int rc = build_ddm_tree(points, n, d, ld, p, &S.ddm);
     if (rc) return rc;
     lap("domain decomposition", -1);
-    S.stream = static_cast<hipStream_t>(bbfmm_stream(tree));
+    S.stream = static_cast<hipStream_t>(bbfmm_stream(tree)); // (binds this thread to the tree's device)
     if (!S.stream) return BBFMM_DEVICE_ERROR;
+    if (hipGetDevice(&S.device) != hipSuccess) return BBFMM_DEVICE_ERROR;
     // global monomial matrix on the cube-scaled points and its thin Q (rbf.rs:418-421, 476-495)
     double gscale[6] = {0, 0, 0, 1, 1, 1}; // translation, scale of the global monomial basis
     if (S.basis) {
@@ -333,6 +335,8 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
 
 // Nothing may unwind through the C ABI (the N-sized host vectors can throw std::bad_alloc / length_error).
 #define SCHWARZ_GUARD try {
+#define SCHWARZ_BIND(h) \
+    if ((h)->s.device >= 0) (void)hipSetDevice((h)->s.device);
 #define SCHWARZ_END_GUARD                                   \
     }                                                       \
     catch (const std::bad_alloc &) { return BBFMM_DEVICE_ERROR; } \
@@ -380,6 +384,7 @@ int bbfmm_schwarz_debug_level_solve(bbfmm_schwarz *h, int32_t level, const doubl
         n != h->s.n + h->s.basis)
         return BBFMM_BAD_ARGUMENT;
     SCHWARZ_GUARD
+    SCHWARZ_BIND(h)
     Schwarz &S = h->s;
     const bool coarse = static_cast<size_t>(level) + 1 == S.ddm.levels.size();
     int rc = upload_residual(S, residual);
@@ -395,6 +400,7 @@ int bbfmm_schwarz_apply(void *user, const double *rg, double *sl, int64_t n) {
     bbfmm_schwarz *h = static_cast<bbfmm_schwarz *>(user);
     if (!h || !rg || !sl || n != h->s.n + h->s.basis) return BBFMM_BAD_ARGUMENT;
     SCHWARZ_GUARD
+    SCHWARZ_BIND(h)
     Schwarz &S = h->s;
     const auto t_begin = std::chrono::steady_clock::now();
     int rc = upload_residual(S, rg);

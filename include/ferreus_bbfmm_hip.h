@@ -184,7 +184,10 @@ int bbfmm_target_subset_create(bbfmm_handle *h, const int64_t *target_indices, i
                                int32_t *subset_id);
 int bbfmm_matvec_subset_device(bbfmm_handle *h, int32_t subset_id, const double *d_w, double *d_y, int32_t sync);
 
-/* HIP stream the handle launches on (hipStream_t as void*), for event timing. */
+/* HIP stream the handle launches on (hipStream_t as void*), for event timing and for device work that has to
+ * stay in order with the handle's.  A handle belongs to the HIP device that was current in bbfmm_create; every
+ * entry point that takes the handle (this one included) makes that device current in the calling thread, so the
+ * handle can be used from threads that never selected a device. */
 void *bbfmm_stream(bbfmm_handle *h);
 
 /* Multi-GPU target partition: restrict the downward + leaf pass of
