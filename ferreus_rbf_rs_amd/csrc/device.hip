@@ -1733,6 +1733,14 @@ template <int STAGE> static int m2l_chunk_pref() {
     return v;
 }
 
+static bool m2l_s2_tail8() {
+    static const bool v = [] {
+        const char *e = std::getenv("BBFMM_M2L_S2_TAIL8");
+        return !e || std::atoi(e) != 0;
+    }();
+    return v;
+}
+
 template <int STAGE>
 static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
                                 int n_pad, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
@@ -1750,7 +1758,12 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
                                        STAGE == 2 && !(NG == 11 && left >= 22) ? 1 : n_colblocks, K, C, in, in_len, \
                                        out, out_len, qlist, slot_t, tile_idx, s);                                   \
     }
-        if (STAGE == 2 && n_colblocks == 2 && left >= 22) { // two workgroups of 11 groups per tile (gridDim.z)
+        if (STAGE == 2 && n_colblocks == 2 && left == 24 && m2l_s2_tail8()) { // p = 9: 46 = 2 x 11 + 3 x 8
+            take = 8;
+            m2l_gemm_launch<8, STAGE, 4>(classes, tiles, n_tiles, n_pad, done, 3, K, C, in, in_len, out, out_len, qlist,
+                                         slot_t, tile_idx, s);
+            take = 24;
+        } else if (STAGE == 2 && n_colblocks == 2 && left >= 22) { // two workgroups of 11 groups per tile (gridDim.z)
             M2L_GO(11, 1)
             take = 22;
         } else if (pref == 22 && left >= 22) M2L_GO(22, 1)

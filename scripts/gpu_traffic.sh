@@ -18,7 +18,7 @@ for c in ('FETCH_SIZE','WRITE_SIZE'):
         for r in csv.DictReader(open(f)):
             name=r['Kernel_Name'].split('(')[0].replace('void bbfmm::','').replace('bbfmm::','')[:40]
             agg[name][r['Counter_Name']]+=float(r['Counter_Value']); cnt[name][r['Counter_Name']]+=1
-phase={'m2l_gemm_k4<11, 1, 1>':'M2L_stage1','m2l_gemm_k4<22, 2, 1>':'M2L_stage2','p2p_kernel<0, false, 1>':'P2P'}
+phase={'m2l_gemm_k4<11, 1, 1>':'M2L_stage1','m2l_gemm_k4<22, 2, 1>':'M2L_stage2','m2l_gemm_k4<11, 2, 1>':'M2L_stage2','p2p_kernel<0, false, 1>':'P2P'}
 per={}
 with open(root+'/traffic_summary.txt','w') as o:
     for k,v in sorted(agg.items()):
