@@ -132,7 +132,7 @@ def source_hash() -> str:
 
 
 def committed_counters(workload_key):
-    """PMC summaries of this same command (scripts/gpu_counters.sh -> profiles/r*_counters.json).  bench.py
+    """PMC summaries of this same command (scripts/gpu_round_profiles.sh -> profiles/r*_counters.json).  bench.py
     cannot run rocprofv3 on itself, so the figures come from the committed passes -- and only when they were
     taken on these exact sources and this workload; otherwise null (never stale numbers)."""
     best = None

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(HERE, "libferreus_bbfmm_hip.so")
 # bbfmm_status
 OK, POINT_OUTSIDE_TREE, KERNEL_NO_GRADIENTS, BAD_ARGUMENT, DEVICE_ERROR, UNSUPPORTED = range(6)
 FLAG_HOST_ONLY = 1
+FLAG_M2L_SHARED_BASIS = 2  # extension beyond the reference: M2L stages in one basis per level
 N_PHASES = 11
 PHASE_NAMES = ["gather", "P2M", "M2M", "M2L_stage1", "M2L_stage2", "P2L", "L2L", "P2P", "M2P",
                "L2P", "scatter"]
@@ -33,7 +34,8 @@ class TreeStats(ctypes.Structure):
                 ("n_points", c_i64), ("n_cells", c_i64), ("n_leaves", c_i64),
                 ("n_u", c_i64), ("n_v", c_i64), ("n_w", c_i64), ("n_x", c_i64),
                 ("p2p_pairs", c_i64), ("p2p_tile_bytes_k1", c_i64), ("m2l_flops_k1", c_f64),
-                ("center", c_f64 * 3), ("radius", c_f64), ("wx_pairs", c_i64), ("wx_tile_bytes_k1", c_i64)]
+                ("center", c_f64 * 3), ("radius", c_f64), ("wx_pairs", c_i64), ("wx_tile_bytes_k1", c_i64),
+                ("m2l_basis_rank", c_i32), ("m2l_basis_len", c_i32)]
 
 
 # every symbol include/ferreus_bbfmm_hip.h declares: name -> (restype, argtypes)

@@ -268,6 +268,7 @@ struct RocSolverApi {
     int (*set_stream)(void *, hipStream_t) = nullptr;
     int (*dgetrf)(void *, int, int, double *, int, int *, int *) = nullptr;
     int (*dgetrs)(void *, int, int, int, double *, int, const int *, double *, int) = nullptr;
+    int (*dsyevd)(void *, int, int, int, double *, int, double *, double *, int *) = nullptr;
     bool ok = false;
 };
 RocSolverApi &rocsolver_api() {
@@ -288,12 +289,42 @@ RocSolverApi &rocsolver_api() {
         a.set_stream = reinterpret_cast<int (*)(void *, hipStream_t)>(sym("rocblas_set_stream"));
         a.dgetrf = reinterpret_cast<int (*)(void *, int, int, double *, int, int *, int *)>(sym("rocsolver_dgetrf"));
         a.dgetrs = reinterpret_cast<int (*)(void *, int, int, int, double *, int, const int *, double *, int)>(sym("rocsolver_dgetrs"));
+        a.dsyevd = reinterpret_cast<int (*)(void *, int, int, int, double *, int, double *, double *, int *)>(sym("rocsolver_dsyevd"));
         a.ok = a.create_handle && a.destroy_handle && a.set_stream && a.dgetrf && a.dgetrs;
         return a;
     }();
     return api;
 }
 } // namespace
+
+// Eigen-decomposition of a symmetric n x n matrix on the device (rocSOLVER dsyevd, bound on demand): d_a (column-major,
+// lower triangle read) is overwritten with the eigenvectors, d_eval gets the eigenvalues in ascending order.
+// BBFMM_UNSUPPORTED when rocSOLVER is not on this machine (the caller falls back to the host Jacobi sweep).
+int device_symmetric_eigen(int n, double *d_a, double *d_eval, hipStream_t s) {
+    RocSolverApi &api = rocsolver_api();
+    if (!api.ok || !api.dsyevd) return BBFMM_UNSUPPORTED;
+    void *handle = nullptr;
+    if (api.create_handle(&handle) != 0) return BBFMM_DEVICE_ERROR;
+    int rc = BBFMM_OK;
+    double *d_e = nullptr;
+    int *d_info = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&d_e), static_cast<size_t>(n) * sizeof(double)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&d_info), sizeof(int)) != hipSuccess)
+        rc = BBFMM_DEVICE_ERROR;
+    if (rc == BBFMM_OK && api.set_stream(handle, s) != 0) rc = BBFMM_DEVICE_ERROR;
+    if (rc == BBFMM_OK &&
+        api.dsyevd(handle, 211 /* rocblas_evect_original */, 122 /* rocblas_fill_lower */, n, d_a, n, d_eval, d_e, d_info) != 0)
+        rc = BBFMM_DEVICE_ERROR;
+    int info = 0;
+    if (rc == BBFMM_OK && (hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                           hipStreamSynchronize(s) != hipSuccess))
+        rc = BBFMM_DEVICE_ERROR;
+    if (rc == BBFMM_OK && info != 0) rc = BBFMM_UNSUPPORTED; // no convergence: the caller takes the host path
+    if (d_e) (void)hipFree(d_e);
+    if (d_info) (void)hipFree(d_info);
+    (void)api.destroy_handle(handle);
+    return rc;
+}
 
 int big_lu_factor(DdmLevelSolver *lv, hipStream_t s) {
     RocSolverApi &api = rocsolver_api();

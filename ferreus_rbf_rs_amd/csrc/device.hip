@@ -1204,6 +1204,9 @@ __device__ inline void dma16s(const double *sbase, unsigned voff_bytes, unsigned
 //            col = stacked operator row (t, kk); the result is scattered into the target slots.
 //   stage 2: IN = slot contents (k over the slot, k_pad), OP = UAll (k_pad x n_pad), col = node;
 //            the result is the local expansion L.
+//   stage 3: a plain product per cell, IN = rows of in_len values per cell (like M), OP = cls.u_all
+//            (in_len x n_pad), OUT = rows of n_pad values per cell (like L): the change of basis of the
+//            shared-basis extension (multipoles -> coordinates in the level's basis, and back for the locals).
 // The four MFMA blocks are four groups of four output columns: A_b = operator fragment
 // OP[k][col 4b + i] (one lane-linear ds_read_b64 per 16 columns, feeding four MFMAs), B_b = the
 // IN values of four cells (the same for every block), D_b[i][j] = OUT[cell j][col 4b + i].  A wave
@@ -1233,11 +1236,11 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     const int ld = STAGE == 1 ? cls.r_pad16 : n_pad;            // operator leading dimension
     // contraction steps of 16: all of them in stage 1; in stage 2 only those for which some cell
     // of the tile has a V-list entry (tile.q_first/q_count index the compact list qlist)
-    const int nq = STAGE == 1 ? n_pad / 16 : tile.q_count;
+    const int nq = STAGE == 1 ? n_pad / 16 : STAGE == 2 ? tile.q_count : (int)(in_len / 16);
     const uint16_t *ql = qlist + tile.q_first;
     if (zb0 >= zb1) return;
     // stage 2 with gridDim.z > 1: the z workgroups of a tile take adjacent chunks of NG16 column groups
-    const int g16 = g16_0 + (STAGE == 2 ? (int)blockIdx.z * NG16 : 0);
+    const int g16 = g16_0 + (STAGE >= 2 ? (int)blockIdx.z * NG16 : 0);
     const double *opbase = (STAGE == 1 ? cls.vt_all : cls.u_all) + 16 * g16;
 
     constexpr int OP_CHUNKS = 2 * NG16;
@@ -1277,7 +1280,8 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
         const int tg = 2 * h + (lane >> 5), eh = (lane >> 4) & 1, k = (lane >> 2) & 3, j = lane & 3;
         const int pos = wave * 16 + 4 * tg + j;
         const int p = cell_p(pos);
-        const int64_t base = STAGE == 1 ? ((int64_t)kr * C + cls.cells[p]) * n_pad : (int64_t)kr * in_len + cls.cbase[p];
+        const int64_t base = STAGE == 2 ? (int64_t)kr * in_len + cls.cbase[p]
+                                        : ((int64_t)kr * C + cls.cells[p]) * (STAGE == 1 ? (int64_t)n_pad : in_len);
         cptr[h] = in + base + 4 * k + 2 * eh;
     }
     const unsigned lds0 = lds_offset(lds);
@@ -1285,7 +1289,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     // step s of the flattened (column block, contraction step) loop
     auto stage = [&](int sidx, int buf) {
         const int zb = zb0 + sidx / nq, qi = sidx - (sidx / nq) * nq;
-        const int q = STAGE == 1 ? qi : (int)ql[qi];
+        const int q = STAGE == 2 ? (int)ql[qi] : qi;
 #pragma unroll
         for (int i = 0; i < NCH; ++i)
             if (wave + 8 * i < OP_CHUNKS)
@@ -1419,7 +1423,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                         *dst = acc[tg][NG16 - 1];
                     }
                 }
-            } else if (STAGE == 2) {
+            } else if (STAGE >= 2) {
 #pragma unroll
                 for (int tg = 0; tg < 4; ++tg) {
                     const int tp = wave * 16 + 4 * tg + dj;
@@ -1755,22 +1759,25 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
     {                                                                                                               \
         take = NG;                                                                                                  \
         m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done,                                        \
-                                       STAGE == 2 && !(NG == 11 && left >= 22) ? 1 : n_colblocks, K, C, in, in_len, \
+                                       STAGE >= 2 && !(NG == 11 && left >= 22) ? 1 : n_colblocks, K, C, in, in_len, \
                                        out, out_len, qlist, slot_t, tile_idx, s);                                   \
     }
-        if (STAGE == 2 && n_colblocks == 2 && left == 24 && m2l_s2_tail8()) { // p = 9: 46 = 2 x 11 + 3 x 8
+        if (STAGE >= 2 && n_colblocks == 2 && left == 24 && m2l_s2_tail8()) { // p = 9: 46 = 2 x 11 + 3 x 8
             take = 8;
             m2l_gemm_launch<8, STAGE, 4>(classes, tiles, n_tiles, n_pad, done, 3, K, C, in, in_len, out, out_len, qlist,
                                          slot_t, tile_idx, s);
             take = 24;
-        } else if (STAGE == 2 && n_colblocks == 2 && left >= 22) { // two workgroups of 11 groups per tile (gridDim.z)
+        } else if (STAGE >= 2 && n_colblocks == 2 && left >= 22) { // two workgroups of 11 groups per tile (gridDim.z)
             M2L_GO(11, 1)
             take = 22;
         } else if (pref == 22 && left >= 22) M2L_GO(22, 1)
         else if (pref == 22 && left >= 16) M2L_GO(16, 1)
         else if (pref == 11 && left >= 11) M2L_GO(11, 1)
         else if (left >= 8) M2L_GO(8, 4)
-        else if (left >= 6) M2L_GO(6, 4)
+        else if (left == 7) {
+            if constexpr (STAGE >= 2) M2L_GO(7, 2) // 112 coordinates of the shared basis (p = 7); at 128 VGPRs it spills
+            else M2L_GO(6, 4)
+        } else if (left >= 6) M2L_GO(6, 4)
         else if (left >= 4) M2L_GO(4, 4)
         else M2L_GO(2, 4)
 #undef M2L_GO
@@ -1841,6 +1848,67 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
         return e && std::atoi(e) == 1 ? 1 : 2;
     }();
     m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, z, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
+}
+
+// Shared-basis extension: change of basis of every cell of a level (stage 3 of the GEMM kernel), OUT[cell][0..out_ld) =
+// sum_k IN[cell][k] * OP_level[k][0..out_ld).  classes[].cells / u_all: the level's cells and its in_ld x out_ld operator.
+void launch_m2l_basis(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int in_ld, int out_ld, int K,
+                      int64_t C, const double *in, double *out, hipStream_t s) {
+    if (n_tiles == 0) return;
+    m2l_dispatch_chunks<3>(out_ld / 16, classes, tiles, n_tiles, out_ld, 2, K, C, in, in_ld, out, 0, nullptr, 0, nullptr, s);
+}
+
+// Setup-time product for the projected operators: C[i][j] = sum_k A(i, k) * B[k][j], A(i, k) = A[k * lda + i] (TA) or
+// A[i * lda + k]; 64 x 64 tiles, 4 x 4 per thread, 16 contraction indices per LDS round.
+template <bool TA>
+__global__ __launch_bounds__(256) void small_gemm_kernel(int M, int N, int Kd, const double *__restrict__ A, int64_t lda,
+                                                         const double *__restrict__ B, int64_t ldb, double *__restrict__ Cm,
+                                                         int64_t ldc) {
+    __shared__ double sa[16][64 + 1], sb[16][64 + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+    double acc[4][4] = {};
+    for (int k0 = 0; k0 < Kd; k0 += 16) {
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int kk = TA ? e >> 6 : e & 15, ii = TA ? e & 63 : e >> 4;
+            const int k = k0 + kk, i = i0 + ii;
+            sa[kk][ii] = (k < Kd && i < M) ? (TA ? A[(int64_t)k * lda + i] : A[(int64_t)i * lda + k]) : 0.0;
+        }
+        for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, jj = e & 63;
+            const int k = k0 + kk, j = j0 + jj;
+            sb[kk][jj] = (k < Kd && j < N) ? B[(int64_t)k * ldb + j] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            double a[4], b[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] = sa[kk][ty + 16 * r];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) b[c] = sb[kk][tx + 16 * c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] += a[r] * b[c];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = i0 + ty + 16 * r, j = j0 + tx + 16 * c;
+            if (i < M && j < N) Cm[(int64_t)i * ldc + j] = acc[r][c];
+        }
+}
+
+void launch_small_gemm(bool trans_a, int M, int N, int Kd, const double *A, int64_t lda, const double *B, int64_t ldb,
+                       double *Cm, int64_t ldc, hipStream_t s) {
+    if (M <= 0 || N <= 0) return;
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    if (trans_a) hipLaunchKernelGGL(small_gemm_kernel<true>, grid, dim3(256), 0, s, M, N, Kd, A, lda, B, ldb, Cm, ldc);
+    else hipLaunchKernelGGL(small_gemm_kernel<false>, grid, dim3(256), 0, s, M, N, Kd, A, lda, B, ldb, Cm, ldc);
 }
 
 // ------------------------------------------------------------------ stacked M2L operators, assembled in HBM

@@ -94,6 +94,11 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
                        const uint16_t *qlist, double *L, hipStream_t s);
+// shared-basis extension: per-cell change of basis (OUT[cell] = IN[cell] * OP_level), setup-time dense product
+void launch_m2l_basis(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int in_ld, int out_ld, int K,
+                      int64_t C, const double *in, double *out, hipStream_t s);
+void launch_small_gemm(bool trans_a, int M, int N, int Kd, const double *A, int64_t lda, const double *B, int64_t ldb,
+                       double *Cm, int64_t ldc, hipStream_t s);
 
 // Assembly of one class's stacked operators on the device (device.hip "stacked M2L operators").
 struct M2lAssembleTv { // one transfer vector of a class list

@@ -13,6 +13,7 @@
 
 #include "morton.hpp"
 #include "parallel.hpp"
+#include "ddm_solver.hpp"
 #include "tree_device.hpp"
 
 namespace bbfmm {
@@ -207,6 +208,8 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
     if (!l2p_order_supported(order, d))
         return fail(BBFMM_UNSUPPORTED, "interpolation_order > 12 is not instantiated for 3-D trees");
     host_only_ = (flags & BBFMM_FLAG_HOST_ONLY) != 0;
+    shared_basis_ = (flags & BBFMM_FLAG_M2L_SHARED_BASIS) != 0;
+    if (shared_basis_ && host_only_) return fail(BBFMM_BAD_ARGUMENT, "BBFMM_FLAG_M2L_SHARED_BASIS needs a device");
     order_ = order;
     d_ = d;
     kernel_ = make_kernel_spec(kernel_type, base_range, total_sill);
@@ -467,6 +470,7 @@ int FmmTree::build_m2l_tables() {
     m2l_qlist_h_.clear();
     cbuf_len_ = 0;
     m2l_flops_k1_ = 0;
+    m2l_flops_level_.clear();
     if (t.depth < 2) return BBFMM_OK;
 
     auto comp = [&](int tv, int a) { return ops_.all_vecs[static_cast<size_t>(tv) * d + a]; };
@@ -658,7 +662,11 @@ int FmmTree::build_m2l_tables() {
                 flops_part[static_cast<size_t>(lo / kChunkB)] = fl;
                 bad_part[static_cast<size_t>(lo / kChunkB)] = bad;
             });
-            for (double f : flops_part) m2l_flops_k1_ += f; // fixed order: same total on every run
+            double level_flops = 0.0;
+            for (double f : flops_part) level_flops += f; // fixed order: same total on every run
+            m2l_flops_k1_ += level_flops;
+            if (m2l_flops_level_.size() <= static_cast<size_t>(level)) m2l_flops_level_.resize(static_cast<size_t>(level) + 1, 0.0);
+            m2l_flops_level_[static_cast<size_t>(level)] = level_flops;
             for (int64_t b : bad_part) bad_pairs += b;
         }
         for (int o = 0; o < ncls; ++o) {
@@ -927,6 +935,12 @@ int FmmTree::upload() {
         }
         if (!buf.empty()) CHK(dupload(&d_level_ops[lv], buf));
     }
+    if (shared_basis_) {
+        if (!compressed) return fail(BBFMM_BAD_ARGUMENT, "BBFMM_FLAG_M2L_SHARED_BASIS needs compressed M2L operators (ACA or SVD)");
+        CHK(build_shared_basis(&d_level_ops));
+    }
+    const int m2l_len = shared_basis_ ? basis_pad_ : cheb_.n_pad; // contraction / output length of the stages
+    std::vector<DevBuf<double>> natural_tmp;         // shared basis: the natural-frame operators, until projected
     std::vector<DevBuf<M2lAssembleTv>> assemble_tmp; // per-class tv tables: released once the kernels have run
     for (size_t i = 0; i < m2l_host_.size() + m2l_variants_.size(); ++i) {
         // (the boundary variants of stage 1 follow the level classes: same tables, fewer transfer vectors)
@@ -978,6 +992,18 @@ int FmmTree::upload() {
             }
             assemble_tmp.push_back(d_src);
             assemble_tmp.push_back(d_tgt);
+            if (shared_basis_) { // Vt' = W^T VtAll (m2l_len x r_pad16), U' = UAll W (k_pad x m2l_len)
+                DevBuf<double> vt2, ua2;
+                CHK(dalloc(&vt2, static_cast<size_t>(m2l_len) * h.r_pad16));
+                CHK(dalloc(&ua2, static_cast<size_t>(h.k_pad) * m2l_len));
+                const double *W = d_basis_c_[static_cast<size_t>(h.level)].p; // n_pad x m2l_len
+                launch_small_gemm(true, m2l_len, h.r_pad16, cheb_.n_pad, W, m2l_len, vt.p, h.r_pad16, vt2.p, h.r_pad16, stream_);
+                launch_small_gemm(false, h.k_pad, m2l_len, cheb_.n_pad, ua.p, cheb_.n_pad, W, m2l_len, ua2.p, m2l_len, stream_);
+                natural_tmp.push_back(vt);
+                natural_tmp.push_back(ua);
+                vt = vt2;
+                ua = ua2;
+            }
         }
         CHK(dupload(&rt, h.row_dst));
         CHK(dupload(&ro, h.blk_t0));
@@ -997,6 +1023,7 @@ int FmmTree::upload() {
     HIPCHK(hipStreamSynchronize(stream_)); // the assembly kernels have read their tables
     HIPCHK(hipGetLastError());
     for (auto &b : assemble_tmp) dfree(&b);
+    for (auto &b : natural_tmp) dfree(&b);
     for (auto &b : d_level_ops) dfree(&b);
     dfree(&d_invperm);
     ut.lap("  upload: M2L operators, tables");
@@ -1010,6 +1037,178 @@ int FmmTree::upload() {
     CHK(dupload(&d_m2l_qlist_, m2l_qlist_h_));
     std::vector<uint8_t> act(static_cast<size_t>(C), 1);
     CHK(dupload(&d_active_, act));
+    return BBFMM_OK;
+}
+
+// Shared-basis extension.  For every level: G = sum over the far transfer vectors t of K_t^T K_t + K_t K_t^T with
+// K_t = U_t Vt_t the level's compressed operators in the natural node order (permuted copies of the reference
+// operators), eigen-decomposition of G (n x n) on the device, W = the eigenvectors whose eigenvalues carry all but
+// eps^2 of the trace (the operators' own cutoff rule, aca.rs:210-224, applied to the stack of all of them).
+int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
+    (void)d_level_ops;
+    const int n = ops_.n, n_pad = cheb_.n_pad, d = ops_.d;
+    const size_t n_levels = ops_.m2l.size();
+    basis_rank_.assign(n_levels, 0);
+    std::vector<std::vector<double>> evec(n_levels); // n x n column-major, ascending eigenvalues
+    // the projection cannot resolve singular values below ~1e-8 of the largest through the Gram matrix in f64
+    const double eps_s = std::max(params_.epsilon, 1e-8);
+    for (size_t lv = 2; lv < n_levels; ++lv) {
+        const auto &lops = ops_.m2l[lv];
+        if (lops.empty()) continue;
+        const int n_ref = static_cast<int>(lops.size());
+        // per reference operator: Vt^T Vt + U (Vt Vt^T) U^T  (n x n, symmetric), row-major
+        std::vector<std::vector<double>> gref(static_cast<size_t>(n_ref));
+        parallel_for(n_ref, 1, [&](int64_t r) {
+            const M2lOperator &op = lops[static_cast<size_t>(r)];
+            const int rk = op.rank;
+            std::vector<double> &g = gref[static_cast<size_t>(r)];
+            g.assign(static_cast<size_t>(n) * n, 0.0);
+            if (rk == 0) return;
+            // K = U Vt:  K^T K = Vt^T (U^T U) Vt,  K K^T = U (Vt Vt^T) U^T  (no assumption on which factor is orthonormal)
+            std::vector<double> tv(static_cast<size_t>(rk) * rk, 0.0), tu(static_cast<size_t>(rk) * rk, 0.0);
+            std::vector<double> ut(static_cast<size_t>(n) * rk), vtt(static_cast<size_t>(n) * rk);
+            for (int a = 0; a < rk; ++a)
+                for (int b = 0; b < rk; ++b) {
+                    double av = 0.0, au = 0.0;
+                    for (int m = 0; m < n; ++m) {
+                        av += op.vt[a + static_cast<size_t>(rk) * m] * op.vt[b + static_cast<size_t>(rk) * m];
+                        au += op.u[m + static_cast<size_t>(n) * a] * op.u[m + static_cast<size_t>(n) * b];
+                    }
+                    tv[static_cast<size_t>(a) * rk + b] = av;
+                    tu[static_cast<size_t>(a) * rk + b] = au;
+                }
+            for (int i = 0; i < n; ++i) // ut = U (Vt Vt^T), vtt = Vt^T (U^T U)
+                for (int b = 0; b < rk; ++b) {
+                    double au = 0.0, av = 0.0;
+                    for (int a = 0; a < rk; ++a) {
+                        au += op.u[i + static_cast<size_t>(n) * a] * tv[static_cast<size_t>(a) * rk + b];
+                        av += op.vt[a + static_cast<size_t>(rk) * i] * tu[static_cast<size_t>(a) * rk + b];
+                    }
+                    ut[static_cast<size_t>(i) * rk + b] = au;
+                    vtt[static_cast<size_t>(i) * rk + b] = av;
+                }
+            for (int i = 0; i < n; ++i)
+                for (int j = 0; j < n; ++j) {
+                    double acc = 0.0;
+                    for (int a = 0; a < rk; ++a)
+                        acc += vtt[static_cast<size_t>(i) * rk + a] * op.vt[a + static_cast<size_t>(rk) * j] +
+                               ut[static_cast<size_t>(i) * rk + a] * op.u[j + static_cast<size_t>(n) * a];
+                    g[static_cast<size_t>(i) * n + j] = acc;
+                }
+        });
+        std::vector<double> G(static_cast<size_t>(n) * n, 0.0);
+        std::vector<int> tvs;
+        for (int tv = 0; tv < ops_.n_vec; ++tv) {
+            int mx = 0;
+            for (int a = 0; a < d; ++a) mx = std::max(mx, std::abs(static_cast<int>(ops_.all_vecs[static_cast<size_t>(tv) * d + a])));
+            if (mx >= 2) tvs.push_back(tv);
+        }
+        parallel_for(n, 1, [&](int64_t i) { // natural frame: entry (i, j) of K_t stems from (invperm[i], invperm[j]) of its reference
+            double *row = &G[static_cast<size_t>(i) * n];
+            for (int tv : tvs) {
+                const int32_t *ip = &ops_.invperm[static_cast<size_t>(ops_.perm_lookup[tv]) * n];
+                const double *g = &gref[static_cast<size_t>(ops_.ref_lookup[tv])][static_cast<size_t>(ip[i]) * n];
+                for (int j = 0; j < n; ++j) row[j] += g[ip[j]];
+            }
+        });
+        for (int i = 0; i < n; ++i) // exact symmetry for the solver
+            for (int j = i + 1; j < n; ++j) {
+                const double v = 0.5 * (G[static_cast<size_t>(i) * n + j] + G[static_cast<size_t>(j) * n + i]);
+                G[static_cast<size_t>(i) * n + j] = G[static_cast<size_t>(j) * n + i] = v;
+            }
+        std::vector<double> eval(static_cast<size_t>(n));
+        evec[lv].assign(static_cast<size_t>(n) * n, 0.0);
+        DevBuf<double> d_g, d_ev;
+        CHK(dupload(&d_g, G));
+        CHK(dalloc(&d_ev, static_cast<size_t>(n)));
+        int rc = std::getenv("BBFMM_BASIS_HOST_EIGEN") ? BBFMM_UNSUPPORTED : device_symmetric_eigen(n, d_g.p, d_ev.p, stream_);
+        if (rc == BBFMM_OK) {
+            HIPCHK(hipMemcpy(eval.data(), d_ev.p, static_cast<size_t>(n) * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(evec[lv].data(), d_g.p, static_cast<size_t>(n) * n * sizeof(double), hipMemcpyDeviceToHost));
+        }
+        dfree(&d_g);
+        dfree(&d_ev);
+        if (rc == BBFMM_UNSUPPORTED) { // no rocSOLVER: one-sided Jacobi on the host (slow at high orders, same result)
+            std::vector<double> u, sv, vt;
+            jacobi_svd(G, n, n, &u, &sv, &vt); // G symmetric positive semi-definite: singular values = eigenvalues, descending
+            for (int j = 0; j < n; ++j) {
+                eval[static_cast<size_t>(n - 1 - j)] = sv[static_cast<size_t>(j)];
+                std::copy(u.begin() + static_cast<size_t>(j) * n, u.begin() + static_cast<size_t>(j + 1) * n,
+                          evec[lv].begin() + static_cast<size_t>(n - 1 - j) * n);
+            }
+            rc = BBFMM_OK;
+        }
+        if (rc != BBFMM_OK) return fail(rc, "eigen-decomposition of the shared-basis Gram matrix failed");
+        double total = 0.0;
+        for (double v : eval) total += std::max(v, 0.0);
+        double tail = 0.0;
+        int rank = n;
+        for (int j = 0; j < n; ++j) { // ascending: drop while the dropped part stays below eps^2 of the trace
+            tail += std::max(eval[static_cast<size_t>(j)], 0.0);
+            if (!(tail < eps_s * eps_s * total)) {
+                rank = n - j;
+                break;
+            }
+        }
+        basis_rank_[lv] = rank;
+        if (std::getenv("BBFMM_VERBOSE") && lv == 2) {
+            std::fprintf(stderr, "[bbfmm] shared basis level %zu eigenvalues / largest (descending, every 10th):", lv);
+            for (int j = 0; j < n; j += 10) std::fprintf(stderr, " %.1e", eval[static_cast<size_t>(n - 1 - j)] / eval[static_cast<size_t>(n - 1)]);
+            std::fprintf(stderr, "\n");
+        }
+    }
+    int max_rank = 0;
+    for (int r : basis_rank_) max_rank = std::max(max_rank, r);
+    if (max_rank == 0) return fail(BBFMM_BAD_ARGUMENT, "shared basis: no M2L level");
+    basis_pad_ = round_up(max_rank, 16);
+    if (((basis_pad_ / 16) & 1) && basis_pad_ / 16 != 7) basis_pad_ += 16; // column-group plans: even counts, or 7
+    basis_pad_ = std::min(basis_pad_, n_pad);
+    d_basis_c_.assign(n_levels, DevBuf<double>());
+    d_basis_e_.assign(n_levels, DevBuf<double>());
+    std::vector<M2lClass> classes(2 * n_levels);
+    std::vector<M2lTileDesc> tiles_c, tiles_e;
+    const int64_t C = tree_.n_cells();
+    double flops = 0.0;
+    for (size_t lv = 2; lv < n_levels; ++lv) {
+        std::memset(&classes[2 * lv], 0, 2 * sizeof(M2lClass));
+        if (basis_rank_[lv] == 0 || lv >= level_cells_.size() || level_cells_[lv].empty()) continue;
+        const int rank = basis_rank_[lv];
+        std::vector<double> wc(static_cast<size_t>(n_pad) * basis_pad_, 0.0), we(static_cast<size_t>(basis_pad_) * n_pad, 0.0);
+        for (int j = 0; j < rank; ++j) {
+            const double *col = &evec[lv][static_cast<size_t>(n - 1 - j) * n]; // j-th largest eigenvalue
+            for (int m = 0; m < n; ++m) {
+                wc[static_cast<size_t>(m) * basis_pad_ + j] = col[m];
+                we[static_cast<size_t>(j) * n_pad + m] = col[m];
+            }
+        }
+        CHK(dupload(&d_basis_c_[lv], wc));
+        CHK(dupload(&d_basis_e_[lv], we));
+        const int32_t nc = static_cast<int32_t>(level_cells_[lv].size());
+        for (int e = 0; e < 2; ++e) {
+            M2lClass &c = classes[2 * lv + e];
+            c.u_all = e == 0 ? d_basis_c_[lv].p : d_basis_e_[lv].p;
+            c.cells = d_level_cells_[lv].p;
+            c.n_cells = nc;
+        }
+        for (int32_t first = 0; first < nc; first += kM2lTile) {
+            const int32_t count = std::min<int32_t>(kM2lTile, nc - first);
+            tiles_c.push_back(M2lTileDesc{static_cast<int32_t>(2 * lv), first, count, 0, 0, 0});
+            tiles_e.push_back(M2lTileDesc{static_cast<int32_t>(2 * lv + 1), first, count, 0, 0, 0});
+        }
+        const double lf = lv < m2l_flops_level_.size() ? m2l_flops_level_[lv] : 0.0;
+        flops += lf * rank / n + 4.0 * n * rank * nc; // the stages in the basis + the two changes of basis
+    }
+    m2l_flops_k1_ = flops;
+    n_basis_tiles_ = static_cast<int>(tiles_c.size());
+    CHK(dupload(&d_basis_classes_, classes));
+    CHK(dupload(&d_basis_tiles_c_, tiles_c));
+    CHK(dupload(&d_basis_tiles_e_, tiles_e));
+    (void)C;
+    if (std::getenv("BBFMM_VERBOSE")) {
+        std::fprintf(stderr, "[bbfmm] shared basis: %d coordinates per cell (n = %d), ranks per level:", basis_pad_, n);
+        for (size_t lv = 2; lv < n_levels; ++lv) std::fprintf(stderr, " %d", basis_rank_[lv]);
+        std::fprintf(stderr, "\n");
+    }
     return BBFMM_OK;
 }
 
@@ -1027,6 +1226,12 @@ int FmmTree::ensure_rhs_capacity(int k) {
     CHK(dalloc(&d_w_sorted_, static_cast<size_t>(k) * N));
     CHK(dalloc(&d_M_, coef, true));
     CHK(dalloc(&d_L_, coef, true));
+    if (shared_basis_) {
+        dfree(&d_Mc_);
+        dfree(&d_Lc_);
+        CHK(dalloc(&d_Mc_, static_cast<size_t>(k) * C * basis_pad_, true));
+        CHK(dalloc(&d_Lc_, static_cast<size_t>(k) * C * basis_pad_, true));
+    }
     CHK(dalloc(&d_cbuf_, static_cast<size_t>(k) * std::max<int64_t>(cbuf_len_, 1), true)); // absent pairs stay 0
     CHK(dalloc(&d_out_, static_cast<size_t>(k) * N));
     CHK(dalloc(&src_targets_.out, static_cast<size_t>(k) * N));
@@ -1472,21 +1677,30 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_));
     // a plan runs stage 1 on compact tiles of the sources its targets need, stage 2 on the tiles that
     // hold a cell with targets, P2L / L2L on the cells with targets (cells_with_targets, bbfmm.rs:468-480)
+    const int m2l_len = shared_basis_ ? basis_pad_ : cheb_.n_pad;
+    const double *m_in = shared_basis_ ? d_Mc_.p : d_M_.p;
+    double *l_out = shared_basis_ ? d_Lc_.p : d_L_.p;
     phase_begin();
+    if (shared_basis_) { // coordinates of every multipole in its level's basis; stage 2 leaves untouched tiles at 0
+        launch_m2l_basis(d_basis_classes_.p, d_basis_tiles_c_.p, n_basis_tiles_, cheb_.n_pad, basis_pad_, k, C, d_M_.p, d_Mc_.p, stream_);
+        HIPCHK(hipMemsetAsync(d_Lc_.p, 0, static_cast<size_t>(k) * C * basis_pad_ * sizeof(double), stream_));
+    }
     if (dp)
         launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles1_h.size()),
-                          cheb_.n_pad, m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_, dp->tiles1_own_blocks);
+                          m2l_len, m2l_slot_t_, k, C, m_in, d_cbuf_.p, cbuf_len_, stream_, dp->tiles1_own_blocks);
     else
-        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p, d_tile_idx1_.p, static_cast<int>(m2l_tiles1_h_.size()), cheb_.n_pad,
-                          m2l_slot_t_, k, C, d_M_.p, d_cbuf_.p, cbuf_len_, stream_);
+        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p, d_tile_idx1_.p, static_cast<int>(m2l_tiles1_h_.size()), m2l_len,
+                          m2l_slot_t_, k, C, m_in, d_cbuf_.p, cbuf_len_, stream_);
     phase_end(kPhM2L1);
     phase_begin();
     if (dp)
         launch_m2l_stage2(d_m2l_classes_.p, dp->d_tiles2.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles2_h.size()),
-                          cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, d_L_.p, stream_);
+                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, l_out, stream_);
     else
         launch_m2l_stage2(d_m2l_classes_.p, d_m2l_tiles2_.p, nullptr, static_cast<int>(m2l_tiles2_h_.size()),
-                          cheb_.n_pad, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, d_L_.p, stream_);
+                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, l_out, stream_);
+    if (shared_basis_) // back to the node values (every cell of level >= 2; cells above keep the zeros)
+        launch_m2l_basis(d_basis_classes_.p, d_basis_tiles_e_.p, n_basis_tiles_, basis_pad_, cheb_.n_pad, k, C, d_Lc_.p, d_L_.p, stream_);
     phase_end(kPhM2L2);
     phase_begin();
     if (t.adaptive && wx) { // targets = all sources, one rhs: P2L and M2P share their kernel evaluations (X = W^T)
@@ -2301,6 +2515,8 @@ void FmmTree::stats(bbfmm_tree_stats *out) const {
         out->wx_tile_bytes_k1 += nw * (nt * per_pt + 2 * static_cast<int64_t>(ops_.n) * 8);
     }
     out->m2l_flops_k1 = m2l_flops_k1_;
+    for (int r : basis_rank_) out->m2l_basis_rank = std::max<int32_t>(out->m2l_basis_rank, r);
+    out->m2l_basis_len = shared_basis_ ? basis_pad_ : 0;
     for (int a = 0; a < d_; ++a) out->center[a] = t.center[a];
     out->radius = t.radius;
 }

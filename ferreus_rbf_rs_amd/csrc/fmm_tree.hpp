@@ -304,6 +304,20 @@ class FmmTree {
     // per-rhs-capacity buffers
     int k_cap_ = 0;
     DevBuf<double> d_w_in_, d_w_sorted_, d_M_, d_L_, d_cbuf_, d_out_;
+    // ---- shared-basis M2L (BBFMM_FLAG_M2L_SHARED_BASIS, an extension beyond the reference) ----
+    // Per level one orthonormal basis W (n x rank) of the space the level's M2L operators read from and write to;
+    // the stages run on coordinates in that basis: Mc = W^T M (stage 3 of the GEMM kernel), stage 1 / 2 with the
+    // projected operators Vt_t W and W^T U_t (contraction / output length basis_pad_ instead of n_pad), L = W Lc.
+    bool shared_basis_ = false;
+    int basis_pad_ = 0;                  // coordinates per cell (multiple of 16; the largest level's rank, padded)
+    std::vector<int> basis_rank_;        // per level
+    std::vector<double> m2l_flops_level_; // per level: sum_pairs 4 n r (to restate m2l_flops_k1_ in the basis)
+    std::vector<DevBuf<double>> d_basis_c_, d_basis_e_; // per level: n_pad x basis_pad_ (W), basis_pad_ x n_pad (W^T)
+    DevBuf<M2lClass> d_basis_classes_;   // 2 per level >= 2: [compress, expand], cells = the level's cells
+    DevBuf<M2lTileDesc> d_basis_tiles_c_, d_basis_tiles_e_;
+    int n_basis_tiles_ = 0;
+    DevBuf<double> d_Mc_, d_Lc_;         // k x C x basis_pad_
+    int build_shared_basis(std::vector<DevBuf<double>> *d_level_ops);
     double *h_pin_ = nullptr; // pinned staging for the host-buffer matvec (N doubles up, N down)
     size_t h_pin_n_ = 0;
     int ensure_pinned(size_t n);

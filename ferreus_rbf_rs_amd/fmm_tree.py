@@ -140,7 +140,10 @@ class FmmTree:
 
     def __init__(self, source_points, interpolation_order: int, kernel_params: KernelParams,
                  adaptive_tree: bool, sparse: bool, *, extents=None,
-                 params: Optional[FmmParams] = None, host_only: bool = False):
+                 params: Optional[FmmParams] = None, host_only: bool = False,
+                 m2l_shared_basis: bool = False):
+        """m2l_shared_basis: BBFMM_FLAG_M2L_SHARED_BASIS, an extension beyond the reference (off by default):
+        the M2L stages run in one orthonormal basis per level, cut at params.epsilon."""
         lib = L.load()
         pts = _as_f64_2d(source_points, "source_points")
         n, d = pts.shape
@@ -155,7 +158,8 @@ class FmmTree:
                               kernel_params.total_sill, int(bool(adaptive_tree)), int(bool(sparse)),
                               ext.ctypes.data if ext is not None else None,
                               ctypes.byref(cpar) if cpar is not None else None,
-                              L.FLAG_HOST_ONLY if host_only else 0, ctypes.byref(h))
+                              (L.FLAG_HOST_ONLY if host_only else 0) |
+                              (L.FLAG_M2L_SHARED_BASIS if m2l_shared_basis else 0), ctypes.byref(h))
         self._h = h
         self._lib = lib
         if rc != L.OK:

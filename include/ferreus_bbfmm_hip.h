@@ -79,6 +79,14 @@ typedef struct bbfmm_handle bbfmm_handle;
 #define BBFMM_FLAG_HOST_ONLY 1u /* build tree/lists/operators on the host only; no device is
                                    touched and every compute call returns BBFMM_DEVICE_ERROR.
                                    Used by the CPU-side structure tests. */
+#define BBFMM_FLAG_M2L_SHARED_BASIS 2u /* EXTENSION beyond the reference (off by default): the M2L stages run on
+                                        * coordinates in one orthonormal basis per level (the dominant subspace of
+                                        * all of the level's compressed operators, cut at params.epsilon like the
+                                        * operators themselves: rank 108 of 343 for LinearRbf at order 7), with the
+                                        * reference's factors projected onto it.  About a third of the M2L flops;
+                                        * results differ from the default path by the projection error (a few
+                                        * epsilon relative to the far field; tests/test_gpu_shared_basis.py).
+                                        * Needs a compressed operator type (ACA or SVD) and a device. */
 
 /*
  * FmmTree::new (ferreus_rbf_utils/src/utils.rs:392-421 -> ferreus_bbfmm/src/bbfmm.rs:272-353).
@@ -206,11 +214,14 @@ typedef struct {
     int64_t n_u, n_v, n_w, n_x;              /* total list entries */
     int64_t p2p_pairs;                       /* sum_leaf n_t * sum_{U} n_s, targets = sources */
     int64_t p2p_tile_bytes_k1;               /* SURVEY.md 8(d) tile-traffic bytes at K=1 */
-    double m2l_flops_k1;                     /* sum_pairs 4*n*r (2*n*n if uncompressed) */
+    double m2l_flops_k1;                     /* sum_pairs 4*n*r (2*n*n if uncompressed); shared basis: see m2l_basis_rank */
     double center[3];
     double radius;
     int64_t wx_pairs;                        /* sum over (leaf, W cell) of n_t * n: kernel evaluations of M2P (= of P2L) */
     int64_t wx_tile_bytes_k1;                /* tile traffic of M2P + P2L at K=1: per (leaf, W cell) n_t*(8d+8) + 2*n*8 */
+    int32_t m2l_basis_rank;                  /* BBFMM_FLAG_M2L_SHARED_BASIS: largest rank of a level's basis (0: flag not set); */
+    int32_t m2l_basis_len;                   /* coordinates kept per cell (rank padded to the kernel's column groups);      */
+                                             /* m2l_flops_k1 then counts the stages in the basis + both changes of basis      */
 } bbfmm_tree_stats;
 
 int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out);

@@ -1,0 +1,127 @@
+"""BBFMM_FLAG_M2L_SHARED_BASIS -- an extension beyond the reference (VERDICT r01 "next" 6: "prototype a labelled
+extension compression ... gate it on <= 10 eps vs the ACA oracle and keep ACA the default").
+
+The M2L stages run on coordinates in one orthonormal basis per level (the dominant subspace of all of the level's
+compressed operators, cut at params.epsilon), with the reference's own ACA / SVD factors projected onto it.  The
+gate of every test: the flagged handle agrees with the default handle -- which the rest of the suite holds to the
+oracle at 1e-11 -- within 10 eps, and with sampled rows of the dense sum as well as the default path does (the far
+field itself is only accurate to about eps).  Errors are taken relative to the size of the sum without cancellation
+(max over rows of sum_j |phi_ij| |w_j|, estimated by a product with |w|): that is what both truncations are relative to.  Everything outside the M2L stages is shared code.
+"""
+import numpy as np
+import pytest
+
+import ferreus_rbf_rs_amd as F
+from conftest import clustered_points, relerr
+from oracle import bbfmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _trees(pts, kid, order, br=1.0, sill=1.0, params=None):
+    kp = F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill)
+    fp = None if params is None else F.FmmParams(*params)
+    return (F.FmmTree(pts, order, kp, True, True, params=fp),
+            F.FmmTree(pts, order, kp, True, True, params=fp, m2l_shared_basis=True))
+
+
+@pytest.mark.parametrize("kid,order,br,sill", [(0, 7, 1.0, 1.0), (2, 6, 1.0, 1.0), (3, 7, 0.3, 0.2), (1, 9, 1.0, 1.0)])
+def test_shared_basis_matches_default_path_within_ten_epsilon(kid, order, br, sill):
+    """Mixed-level tree (W / X lists live), three right-hand sides, values at the sources."""
+    rng = np.random.default_rng(900 + kid)
+    n = 60000 if order == 9 else 120000
+    pts = np.vstack([rng.random((n // 2, 3)), clustered_points(rng, n - n // 2, 3)])
+    pts = np.unique(pts, axis=0)
+    n = pts.shape[0]
+    a, b = _trees(pts, kid, order, br, sill)
+    eps = max(10.0 ** -order, 1e-8)                                 # the projection tolerance
+    sa, sb = a.stats(), b.stats()
+    assert sa.m2l_basis_rank == 0 and 0 < sb.m2l_basis_rank <= sb.m2l_basis_len <= sa.n_nodes + 31
+    assert sb.m2l_flops_k1 < sa.m2l_flops_k1                        # fewer flops, or the flag is pointless
+    w = rng.standard_normal((n, 3))
+    a.set_weights(w)
+    b.set_weights(w)
+    ya, yb = a.evaluate(w, pts), b.evaluate(w, pts)
+    # Both truncations (the operators' and the basis') are relative to the operator norms, i.e. to the size of the
+    # sum with the weights' signs removed -- zero-mean weights cancel most of that sum, not of the error.
+    a.set_weights(np.abs(w))
+    scale = max(np.abs(ya).max(), np.abs(a.evaluate(np.abs(w), pts)).max())
+    assert np.abs(yb - ya).max() / scale < 10 * eps
+    rows = rng.choice(n, 48, replace=False)
+    dense = O.dense_sum(kid, br, sill, pts[rows], pts, w)
+    ea, eb = np.abs(ya[rows] - dense).max() / scale, np.abs(yb[rows] - dense).max() / scale
+    assert ea < 10 * eps and eb < max(3 * ea, 10 * eps), (ea, eb)
+
+
+def test_shared_basis_gradients_leaves_and_partial_products():
+    """The flows around the M2L stages with the flag set: gradients at arbitrary targets, the leaves-only
+    evaluator, the host-buffer matvec on a row subset, a two-way partition."""
+    rng = np.random.default_rng(77)
+    n = 90000
+    pts = clustered_points(rng, n, 3)
+    pts = np.unique(pts, axis=0)
+    n = pts.shape[0]
+    a, b = _trees(pts, 2, 7)                                       # CubicRbf: has gradients
+    tol = 10 * 1e-7
+    w = rng.standard_normal((n, 2))
+    tg = np.clip(pts[rng.choice(n, 5000, replace=False)] + 1e-3 * rng.standard_normal((5000, 3)), pts.min(0), pts.max(0))
+    a.set_weights(np.abs(w))                                       # sizes of the sums without cancellation (see above)
+    sy, sg = a.evaluate_with_gradients(np.abs(w), tg)
+    sy, sg = np.abs(sy).max(), np.abs(sg).max()
+    a.set_weights(w)
+    b.set_weights(w)
+    (ya, ga), (yb, gb) = a.evaluate_with_gradients(w, tg), b.evaluate_with_gradients(w, tg)
+    assert np.abs(yb - ya).max() / sy < tol and np.abs(gb - ga).max() / sg < 10 * tol   # a gradient loses a digit
+    a.set_local_coefficients(w)
+    b.set_local_coefficients(w)
+    assert np.abs(b.evaluate_leaves(w, tg) - a.evaluate_leaves(w, tg)).max() / sy < tol
+    idx = np.sort(rng.choice(n, 7000, replace=False)).astype(np.int64)
+    w1 = rng.standard_normal(n)
+    pa = a.fast_matrix_vector_product(w1, target_indices=idx)
+    pb = b.fast_matrix_vector_product(w1, target_indices=idx)
+    assert np.abs(pb - pa).max() / sy < tol and np.all(pb[np.setdiff1d(np.arange(n), idx)] == 0.0)
+    full = b.fast_matrix_vector_product(w1)
+    parts = np.zeros(n)
+    for rank in range(2):                                          # the partition's own plan of tiles, in the basis
+        b.set_partition(rank, 2)
+        rows = b.partition_rows()
+        parts[rows] = b.fast_matrix_vector_product(w1)[rows]
+    b.set_partition(0, 1)
+    assert relerr(parts, full) < 1e-12
+
+
+def test_shared_basis_needs_compressed_operators_and_a_device():
+    rng = np.random.default_rng(5)
+    pts = rng.random((3000, 3))
+    kp = F.KernelParams(F.KernelType(0))
+    with pytest.raises(Exception):
+        F.FmmTree(pts, 5, kp, True, True, params=F.FmmParams(64, F.M2LCompressionType(0), 1e-5, 1024), m2l_shared_basis=True)
+    with pytest.raises(Exception):
+        F.FmmTree(pts, 5, kp, True, True, host_only=True, m2l_shared_basis=True)
+    t = F.FmmTree(pts, 5, kp, True, True, params=F.FmmParams(64, F.M2LCompressionType(1), 1e-5, 1024), m2l_shared_basis=True)
+    d = F.FmmTree(pts, 5, kp, True, True, params=F.FmmParams(64, F.M2LCompressionType(1), 1e-5, 1024))
+    w = rng.standard_normal((3000, 1))
+    t.set_weights(w)
+    d.set_weights(w)
+    assert relerr(t.evaluate(w, pts), d.evaluate(w, pts)) < 1e-4   # SVD factors, eps = 1e-5
+
+
+def test_shared_basis_at_full_size_by_properties():
+    """10M points: linearity and sampled dense rows (the oracle does not finish at this size)."""
+    import torch
+    n = 10_000_000
+    rng = np.random.default_rng(42)
+    pts = rng.random((n, 3))
+    t = F.FmmTree(pts, 7, F.KernelParams(F.KernelType(0)), True, True, m2l_shared_basis=True)
+    assert t.stats().m2l_basis_len == 112
+    w1 = torch.tensor(rng.random(n)).cuda().reshape(1, n)
+    w2 = torch.tensor(rng.standard_normal(n)).cuda().reshape(1, n)
+    y = [torch.zeros_like(w1) for _ in range(3)]
+    for wi, yi in zip((w1, w2, 2.0 * w1 - 3.0 * w2), y):
+        t.matvec_device(wi.data_ptr(), n, 1, yi.data_ptr(), n, True)
+    lin = (2.0 * y[0] - 3.0 * y[1] - y[2]).abs().max().item() / y[2].abs().max().item()
+    assert lin < 1e-12
+    rows = rng.choice(n, 16, replace=False)
+    wn = w1.cpu().numpy().ravel()
+    dense = np.array([-(np.sqrt(((pts - pts[i]) ** 2).sum(1)) * wn).sum() for i in rows])
+    assert relerr(y[0].cpu().numpy().ravel()[rows], dense) < 1e-6
