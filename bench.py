@@ -53,6 +53,10 @@ EXTRA_CONFIGS = [
      "base_range": 1.0, "total_sill": 1.0},
     {"name": "config3_operator_tps_10M_order9", "points": 10_000_000, "kernel": "ThinPlateSplineRbf", "order": 9,
      "nrhs": 1, "base_range": 1.0, "total_sill": 1.0},
+    # EXTENSION beyond the reference, never the headline: the headline workload with BBFMM_FLAG_M2L_SHARED_BASIS
+    # (M2L stages in one basis per level, cut at the operators' epsilon)
+    {"name": "extension_shared_basis_linear_10M", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 1,
+     "base_range": 1.0, "total_sill": 1.0, "m2l_shared_basis": True},
 ]
 
 
@@ -290,7 +294,8 @@ def run_extra_config(torch, F, dev, cfg, tree=None):
     t0 = time.time()
     if tree is None:
         tree = F.FmmTree(pts, cfg["order"], F.KernelParams(F.KernelType[cfg["kernel"]], base_range=cfg["base_range"],
-                                                           total_sill=cfg["total_sill"]), True, True)
+                                                           total_sill=cfg["total_sill"]), True, True,
+                         m2l_shared_basis=bool(cfg.get("m2l_shared_basis")))
     t_build = time.time() - t0
     stats = tree.stats()
     w = torch.from_numpy(np.random.default_rng(43).random((K, N))).to(dev)
@@ -309,7 +314,12 @@ def run_extra_config(torch, F, dev, cfg, tree=None):
         got = out[:, idx].T
         err = float((got - yd).abs().max() / yd.abs().max())
     del pts_d
+    ext = {}
+    if cfg.get("m2l_shared_basis"):
+        ext = {"extension": "BBFMM_FLAG_M2L_SHARED_BASIS (not the reference's M2L arithmetic; results within a few epsilon "
+                            "of the default path)", "m2l_basis_rank": stats.m2l_basis_rank, "m2l_basis_len": stats.m2l_basis_len}
     return {
+        **ext,
         "workload": f"{N} uniform 3D points, {cfg['kernel']}, order {cfg['order']}, {K} rhs",
         "ms_per_step": elapsed / steps * 1e3, "matvecs_per_s": steps / elapsed, "steps": steps,
         "roofline": roof, "phase_ms_per_step": per_step,
@@ -430,7 +440,8 @@ def main():
                 # configs on the headline tree first (more rhs), then the tree is released for the others
                 ordered = sorted(EXTRA_CONFIGS, key=lambda c: (c["points"], c["kernel"], c["order"]) != (N, args.kernel, args.order))
                 for cfg in ordered:
-                    reuse = tree if (cfg["points"], cfg["kernel"], cfg["order"]) == (N, args.kernel, args.order) else None
+                    reuse = tree if (cfg["points"], cfg["kernel"], cfg["order"]) == (N, args.kernel, args.order) and \
+                        not cfg.get("m2l_shared_basis") else None
                     if reuse is None and tree is not None:
                         del tree, w, out, stream
                         tree = w = out = stream = None
