@@ -1050,8 +1050,9 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
     const size_t n_levels = ops_.m2l.size();
     basis_rank_.assign(n_levels, 0);
     std::vector<std::vector<double>> evec(n_levels); // n x n column-major, ascending eigenvalues
-    // the projection cannot resolve singular values below ~1e-8 of the largest through the Gram matrix in f64
-    const double eps_s = std::max(params_.epsilon, 1e-8);
+    // through the Gram matrix f64 resolves the stack's singular values down to about 1e-8 of the largest: the basis is
+    // cut at max(epsilon, 3e-8)
+    const double eps_s = std::max(params_.epsilon, 3e-8);
     for (size_t lv = 2; lv < n_levels; ++lv) {
         const auto &lops = ops_.m2l[lv];
         if (lops.empty()) continue;
@@ -1139,17 +1140,25 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
             rc = BBFMM_OK;
         }
         if (rc != BBFMM_OK) return fail(rc, "eigen-decomposition of the shared-basis Gram matrix failed");
+        // The rounding noise of G (sums of products in f64) shows as eigenvalues of either sign around 1e-17 of the
+        // largest: anything below 1e-16 of it is treated as 0, otherwise hundreds of such values add up past eps^2 of
+        // the trace and the cut lands in the noise.
+        const double lam_max = std::max(eval[static_cast<size_t>(n - 1)], 0.0);
+        const double noise = 1e-16 * lam_max;
         double total = 0.0;
-        for (double v : eval) total += std::max(v, 0.0);
+        for (double v : eval)
+            if (v > noise) total += v;
         double tail = 0.0;
-        int rank = n;
+        int rank = 0;
         for (int j = 0; j < n; ++j) { // ascending: drop while the dropped part stays below eps^2 of the trace
-            tail += std::max(eval[static_cast<size_t>(j)], 0.0);
+            const double v = eval[static_cast<size_t>(j)];
+            if (v > noise) tail += v;
             if (!(tail < eps_s * eps_s * total)) {
                 rank = n - j;
                 break;
             }
         }
+        if (rank == 0) rank = 1;
         basis_rank_[lv] = rank;
         if (std::getenv("BBFMM_VERBOSE") && lv == 2) {
             std::fprintf(stderr, "[bbfmm] shared basis level %zu eigenvalues / largest (descending, every 10th):", lv);
@@ -1162,7 +1171,20 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
     if (max_rank == 0) return fail(BBFMM_BAD_ARGUMENT, "shared basis: no M2L level");
     basis_pad_ = round_up(max_rank, 16);
     if (((basis_pad_ / 16) & 1) && basis_pad_ / 16 != 7) basis_pad_ += 16; // column-group plans: even counts, or 7
+    if (const char *e = std::getenv("BBFMM_BASIS_PAD")) { // experiments: a wider (zero-padded) coordinate vector
+        const int v = std::atoi(e);
+        if (v >= basis_pad_ && v % 32 == 0) basis_pad_ = v;
+    }
     basis_pad_ = std::min(basis_pad_, n_pad);
+    if (basis_pad_ * 5 > n_pad * 3) { // the union of the operators fills most of the node space (e.g. Spheroidal3 with a
+        // short range): the stages would not get cheaper -- the handle keeps the reference's arithmetic
+        if (std::getenv("BBFMM_VERBOSE"))
+            std::fprintf(stderr, "[bbfmm] shared basis: rank %d of %d nodes, not used\n", max_rank, n);
+        shared_basis_ = false;
+        basis_rank_.assign(n_levels, 0);
+        basis_pad_ = 0;
+        return BBFMM_OK;
+    }
     d_basis_c_.assign(n_levels, DevBuf<double>());
     d_basis_e_.assign(n_levels, DevBuf<double>());
     std::vector<M2lClass> classes(2 * n_levels);

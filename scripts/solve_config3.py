@@ -21,6 +21,9 @@ ap.add_argument("--leaf-threshold", type=int, default=1024)
 ap.add_argument("--precon-order", type=int, default=0,
                 help="interpolation order of a second tree that serves only the preconditioner's partial matvecs "
                      "(0: the reference's arrangement, one tree for both)")
+ap.add_argument("--precon-shared-basis", action="store_true",
+                help="extension: the preconditioner's partial matvecs run on a second tree with BBFMM_FLAG_M2L_SHARED_BASIS "
+                     "(FGMRES is flexible; the operator keeps the reference's arithmetic)")
 ap.add_argument("--clustered", action="store_true", help="points from a mixture of 12 Gaussian clusters instead of uniform")
 a = ap.parse_args()
 kid = {"LinearRbf": 0, "ThinPlateSplineRbf": 1, "CubicRbf": 2, "Spheroidal3Rbf": 3}[a.kernel]
@@ -38,9 +41,10 @@ t_tree = time.time() - t0
 st = InterpolantSettings(kid, 3, nugget=a.nugget)
 t0 = time.time()
 ptree = tree
-if a.precon_order and a.precon_order != a.order:
+if (a.precon_order and a.precon_order != a.order) or a.precon_shared_basis:
     # FGMRES is flexible: the preconditioner may use cheaper (less accurate) products than the operator
-    ptree = F.FmmTree(pts, a.precon_order, F.KernelParams(F.KernelType(kid)), True, True)
+    ptree = F.FmmTree(pts, a.precon_order or a.order, F.KernelParams(F.KernelType(kid)), True, True,
+                      m2l_shared_basis=a.precon_shared_basis)
 ct = a.coarse_threshold or DDMParams.for_points(n).coarse_threshold
 pre = SchwarzPreconditioner(ptree, pts, st, DDMParams(leaf_threshold=a.leaf_threshold, coarse_threshold=ct))
 t_ddm = time.time() - t0
@@ -52,7 +56,7 @@ x, hist = S.fgmres(op, rhs, pre, None, 20, 5, S.FittingAccuracy(a.tol), callback
 t_solve = time.time() - t0
 idx = rng.choice(n, 2000, replace=False)
 fit = op(x)[idx]
-print(json.dumps({"points": n, "kernel": a.kernel, "order": a.order, "precon_order": a.precon_order or a.order, "levels": pre.num_levels, "basis": st.basis_size,
+print(json.dumps({"points": n, "kernel": a.kernel, "order": a.order, "precon_order": a.precon_order or a.order, "precon_shared_basis": bool(a.precon_shared_basis), "levels": pre.num_levels, "basis": st.basis_size,
                   "fmm_tree_build_s": round(t_tree, 2), "ddm_build_and_factor_s": round(t_ddm, 2),
                   "solve_s": round(t_solve, 2), "iterations": len(hist),
                   "s_per_iteration": round(t_solve / max(len(hist), 1), 3),

@@ -34,14 +34,19 @@ def test_shared_basis_matches_default_path_within_ten_epsilon(kid, order, br, si
     pts = np.unique(pts, axis=0)
     n = pts.shape[0]
     a, b = _trees(pts, kid, order, br, sill)
-    eps = max(10.0 ** -order, 1e-8)                                 # the projection tolerance
+    eps = max(10.0 ** -order, 3e-8)                                 # the projection tolerance
     sa, sb = a.stats(), b.stats()
-    assert sa.m2l_basis_rank == 0 and 0 < sb.m2l_basis_rank <= sb.m2l_basis_len <= sa.n_nodes + 31
-    assert sb.m2l_flops_k1 < sa.m2l_flops_k1                        # fewer flops, or the flag is pointless
     w = rng.standard_normal((n, 3))
     a.set_weights(w)
     b.set_weights(w)
     ya, yb = a.evaluate(w, pts), b.evaluate(w, pts)
+    assert sa.m2l_basis_rank == 0
+    if sb.m2l_basis_len == 0:
+        # the union of this kernel's operators fills most of the node space: the handle keeps the default stages
+        assert kid == 3 and sb.m2l_flops_k1 == sa.m2l_flops_k1 and relerr(yb, ya) < 1e-12
+        return
+    assert 0 < sb.m2l_basis_rank <= sb.m2l_basis_len <= 0.6 * (sa.n_nodes + 31)
+    assert sb.m2l_flops_k1 < 0.7 * sa.m2l_flops_k1                  # fewer flops, or the flag is pointless
     # Both truncations (the operators' and the basis') are relative to the operator norms, i.e. to the size of the
     # sum with the weights' signs removed -- zero-mean weights cancel most of that sum, not of the error.
     a.set_weights(np.abs(w))
