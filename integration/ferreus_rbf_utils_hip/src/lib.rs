@@ -87,6 +87,17 @@ fn kernel_id(k: KernelType) -> i32 {
     }
 }
 
+/// `BBFMM_FLAG_M2L_SHARED_BASIS` (include/ferreus_bbfmm_hip.h): an extension beyond the reference, off by default.
+/// The reference's constructor has no argument for it, so the shim reads `FERREUS_BBFMM_M2L_SHARED_BASIS=1` from the
+/// environment; without it the handle computes exactly what `ferreus_bbfmm` does.
+pub const BBFMM_FLAG_M2L_SHARED_BASIS: u32 = 2;
+fn creation_flags() -> u32 {
+    match std::env::var("FERREUS_BBFMM_M2L_SHARED_BASIS") {
+        Ok(v) if v == "1" => BBFMM_FLAG_M2L_SHARED_BASIS,
+        _ => 0,
+    }
+}
+
 impl FmmTree {
     fn last_error(&self) -> String {
         unsafe { CStr::from_ptr(bbfmm_last_error(self.h)) }.to_string_lossy().into_owned()
@@ -133,7 +144,7 @@ impl FmmTree {
                 sparse as i32,
                 extents.as_ref().map_or(std::ptr::null(), |e| e.as_ptr()),
                 p.as_ref().map_or(std::ptr::null(), |p| p as *const BbfmmParams),
-                0,
+                creation_flags(),
                 &mut h,
             )
         };
