@@ -1159,6 +1159,16 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
             }
         }
         if (rank == 0) rank = 1;
+        // The operators of a level are permuted copies of each other, so the eigenvalues come in multiplets (the
+        // symmetry group's irreducible dimensions): a cut inside one would keep an arbitrary part of its eigenspace
+        // (and a different part with another solver).  The whole multiplet is kept.
+        // (members agree to the noise of G, a few 1e-17 of the largest eigenvalue; a multiplet of the cube's symmetry
+        // group has at most six members here.)
+        for (int extra = 0; extra < 8 && rank < n; ++extra) {
+            const double kept = eval[static_cast<size_t>(n - rank)], next = eval[static_cast<size_t>(n - rank - 1)];
+            if (next > noise && kept - next <= 1e-3 * kept + 6e-17 * lam_max) ++rank;
+            else break;
+        }
         basis_rank_[lv] = rank;
         if (std::getenv("BBFMM_VERBOSE") && lv == 2) {
             std::fprintf(stderr, "[bbfmm] shared basis level %zu eigenvalues / largest (descending, every 10th):", lv);

@@ -111,6 +111,23 @@ def test_shared_basis_needs_compressed_operators_and_a_device():
     assert relerr(t.evaluate(w, pts), d.evaluate(w, pts)) < 1e-4   # SVD factors, eps = 1e-5
 
 
+def test_shared_basis_host_eigen_fallback_gives_the_same_basis(monkeypatch):
+    """Without rocSOLVER the Gram matrix is decomposed by the host's one-sided Jacobi sweep: same rank, same results."""
+    rng = np.random.default_rng(11)
+    pts = rng.random((20000, 3))
+    kp = F.KernelParams(F.KernelType(0))
+    dev = F.FmmTree(pts, 5, kp, True, True, m2l_shared_basis=True)
+    monkeypatch.setenv("BBFMM_BASIS_HOST_EIGEN", "1")
+    host = F.FmmTree(pts, 5, kp, True, True, m2l_shared_basis=True)
+    monkeypatch.delenv("BBFMM_BASIS_HOST_EIGEN")
+    assert 0 < dev.stats().m2l_basis_rank == host.stats().m2l_basis_rank
+    w = rng.standard_normal((20000, 1))
+    dev.set_weights(w)
+    host.set_weights(w)
+    assert relerr(host.evaluate(w, pts), dev.evaluate(w, pts)) < 1e-7   # eps = 1e-5 here; the two solvers resolve the
+    # eigenvectors next to the cut differently (their eigenvalues are 1e-10 of the largest)
+
+
 def test_shared_basis_at_full_size_by_properties():
     """10M points: linearity and sampled dense rows (the oracle does not finish at this size)."""
     import torch
