@@ -1236,11 +1236,18 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     const int ld = STAGE == 1 ? cls.r_pad16 : n_pad;            // operator leading dimension
     // contraction steps of 16: all of them in stage 1; in stage 2 only those for which some cell
     // of the tile has a V-list entry (tile.q_first/q_count index the compact list qlist)
-    const int nq = STAGE == 1 ? n_pad / 16 : STAGE == 2 ? tile.q_count : (int)(in_len / 16);
-    const uint16_t *ql = qlist + tile.q_first;
+    // Stage 2 of a launch with few tiles is split over the contraction as well (slot_t = number of parts, the
+    // parameter is stage 1's otherwise): a tile's chain of ~290 steps is what a small tree's matvec waits for.
+    // blockIdx.z = part * column chunks + column chunk; the parts add their results to the zeroed L with atomics.
+    const int ksplit = STAGE == 2 && slot_t > 1 ? slot_t : 1;
+    const int zcols = STAGE == 2 ? (int)gridDim.z / ksplit : 1;
+    const int zk = STAGE == 2 ? (int)blockIdx.z / zcols : 0, zc = STAGE == 2 ? (int)blockIdx.z - zk * zcols : (int)blockIdx.z;
+    const int q_lo = STAGE == 2 ? tile.q_count * zk / ksplit : 0;
+    const int nq = STAGE == 1 ? n_pad / 16 : STAGE == 2 ? tile.q_count * (zk + 1) / ksplit - q_lo : (int)(in_len / 16);
+    const uint16_t *ql = qlist + tile.q_first + q_lo;
     if (zb0 >= zb1) return;
     // stage 2 with gridDim.z > 1: the z workgroups of a tile take adjacent chunks of NG16 column groups
-    const int g16 = g16_0 + (STAGE >= 2 ? (int)blockIdx.z * NG16 : 0);
+    const int g16 = g16_0 + (STAGE >= 2 ? zc * NG16 : 0);
     const double *opbase = (STAGE == 1 ? cls.vt_all : cls.u_all) + 16 * g16;
 
     constexpr int OP_CHUNKS = 2 * NG16;
@@ -1430,11 +1437,20 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                     if (tp < tile.count) {
                         const int cell = cls.cells[cell_p(tp)];
                         double *Lc = out + ((int64_t)kr * C + cell) * n_pad + col0;
+                        if (ksplit > 1) { // one of several parts of the contraction
 #pragma unroll
-                        for (int pr = 0; pr < NP; ++pr)
-                            *reinterpret_cast<double2 *>(Lc + 32 * pr + 2 * (4 * db + di)) =
-                                make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
-                        if (NS) Lc[32 * NP + 4 * db + di] = acc[tg][NG16 - 1];
+                            for (int pr = 0; pr < NP; ++pr) {
+                                unsafeAtomicAdd(Lc + 32 * pr + 2 * (4 * db + di), acc[tg][2 * pr]);
+                                unsafeAtomicAdd(Lc + 32 * pr + 2 * (4 * db + di) + 1, acc[tg][2 * pr + 1]);
+                            }
+                            if (NS) unsafeAtomicAdd(Lc + 32 * NP + 4 * db + di, acc[tg][NG16 - 1]);
+                        } else {
+#pragma unroll
+                            for (int pr = 0; pr < NP; ++pr)
+                                *reinterpret_cast<double2 *>(Lc + 32 * pr + 2 * (4 * db + di)) =
+                                    make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
+                            if (NS) Lc[32 * NP + 4 * db + di] = acc[tg][NG16 - 1];
+                        }
                     }
                 }
             }
@@ -1719,7 +1735,8 @@ static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, i
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, n_colblocks), dim3(512), lds, s, classes,
+    const int zdim = STAGE == 2 && slot_t > 1 ? n_colblocks * slot_t : n_colblocks; // stage 2: slot_t = parts of the contraction
+    hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, zdim), dim3(512), lds, s, classes,
                        tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t, tile_idx);
 }
 
@@ -1733,6 +1750,15 @@ template <int STAGE> static int m2l_chunk_pref() {
         const char *e = std::getenv("BBFMM_M2L_NG16_S2");
         const int x = e ? std::atoi(e) : 22;
         return (x == 8 || x == 11 || x == 22) ? x : 22;
+    }();
+    return v;
+}
+
+static int m2l_s2_ksplit_fill() { // workgroups per CU up to which stage 2 keeps splitting the contraction
+    static const int v = [] {
+        const char *e = std::getenv("BBFMM_M2L_S2_KSPLIT_FILL");
+        const int x = e ? std::atoi(e) : 4;
+        return x >= 1 && x <= 64 ? x : 4;
     }();
     return v;
 }
@@ -1847,7 +1873,24 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
         const char *e = std::getenv("BBFMM_M2L_S2_ZSPLIT");
         return e && std::atoi(e) == 1 ? 1 : 2;
     }();
-    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, z, K, C, cbuf, cbuf_len, L, 0, qlist, 0, tile_idx, s);
+    // Few tiles (a small tree, a thin slice of a partition): also split the contraction, so that about two
+    // workgroups per CU exist and none walks more than a few dozen steps alone.  The parts add to L (zeroed by the
+    // caller before every downward pass) with f64 atomics; launches that fill the chip keep plain stores.
+    // Stage 2 per matvec: 50k points 0.50 -> 0.11 ms (the whole matvec 0.79 -> 0.39 ms), 200k 0.52 -> 0.43, 1M 0.95 -> 0.78;
+    // from 3M points on the launch fills the chip and nothing changes.  BBFMM_M2L_S2_KSPLIT=<n> overrides (1: off).
+    static const int ks_env = [] {
+        const char *e = std::getenv("BBFMM_M2L_S2_KSPLIT");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 1 && v <= 32 ? v : 0;
+    }();
+    int ksplit = ks_env;
+    if (ksplit == 0) {
+        const int n_cu = device_cu_count();
+        const int64_t wgs = static_cast<int64_t>(n_tiles) * z * K;
+        ksplit = 1;
+        while (ksplit < 16 && wgs * ksplit * 2 <= static_cast<int64_t>(m2l_s2_ksplit_fill()) * n_cu) ksplit *= 2;
+    }
+    m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, z, K, C, cbuf, cbuf_len, L, 0, qlist, ksplit > 1 ? ksplit : 0, tile_idx, s);
 }
 
 // Shared-basis extension: change of basis of every cell of a level (stage 3 of the GEMM kernel), OUT[cell][0..out_ld) =
