@@ -29,7 +29,8 @@ for name, gen, order, kernel, br, sill, K in cases:
     n, d = pts.shape
     kid = O.KERNEL_IDS[kernel]
     t0 = time.time()
-    tree = F.FmmTree(pts, order, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill), True, True)
+    tree = F.FmmTree(pts, order, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill), True, True,
+                     m2l_shared_basis="--shared-basis" in sys.argv)   # the extension of DESIGN.md section 5 on the same shapes
     build = time.time() - t0
     w = torch.rand((K + 1, n), dtype=torch.float64, device="cuda")
     y = torch.zeros_like(w)
@@ -44,5 +45,5 @@ for name, gen, order, kernel, br, sill, K in cases:
     err = float(np.abs(yc[0, idx].cpu().numpy() - ref).max() / np.abs(ref).max())
     s = tree.stats()
     print(json.dumps({"case": name, "build_s": round(build, 2), "ms_k1": round(ms, 1), "depth": s.depth, "cells": s.n_cells,
-                      "w_pairs": s.n_w, "x_pairs": s.n_x, "linearity": lin, "rel_err_vs_dense": err}), flush=True)
+                      "w_pairs": s.n_w, "x_pairs": s.n_x, "m2l_basis_len": s.m2l_basis_len, "linearity": lin, "rel_err_vs_dense": err}), flush=True)
     del tree
