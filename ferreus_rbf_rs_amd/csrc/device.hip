@@ -1763,14 +1763,6 @@ static int m2l_s2_ksplit_fill() { // workgroups per CU up to which stage 2 keeps
     return v;
 }
 
-static bool m2l_s2_tail8() {
-    static const bool v = [] {
-        const char *e = std::getenv("BBFMM_M2L_S2_TAIL8");
-        return !e || std::atoi(e) != 0;
-    }();
-    return v;
-}
-
 template <int STAGE>
 static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
                                 int n_pad, int n_colblocks, int K, int64_t C, const double *in, int64_t in_len,
@@ -1785,25 +1777,41 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
     {                                                                                                               \
         take = NG;                                                                                                  \
         m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done,                                        \
-                                       STAGE >= 2 && !(NG == 11 && left >= 22) ? 1 : n_colblocks, K, C, in, in_len, \
+                                       STAGE >= 2 ? 1 : n_colblocks, K, C, in, in_len,                            \
                                        out, out_len, qlist, slot_t, tile_idx, s);                                   \
     }
-        if (STAGE >= 2 && n_colblocks == 2 && left == 24 && m2l_s2_tail8()) { // p = 9: 46 = 2 x 11 + 3 x 8
-            take = 8;
-            m2l_gemm_launch<8, STAGE, 4>(classes, tiles, n_tiles, n_pad, done, 3, K, C, in, in_len, out, out_len, qlist,
-                                         slot_t, tile_idx, s);
-            take = 24;
-        } else if (STAGE >= 2 && n_colblocks == 2 && left >= 22) { // two workgroups of 11 groups per tile (gridDim.z)
-            M2L_GO(11, 1)
-            take = 22;
+        if (STAGE >= 2 && !(n_colblocks == 1 && left >= 16)) { // (one workgroup per tile and a wide chunk: the plan below)
+            // stage 2 / 3 with several workgroups per tile (gridDim.z = zc): the largest NG x zc <= left from the
+            // kernels without spills, at most 2 x 11 or 3 x (8, 7, 6, 4, 2) -- 22 = 2 x 11, 46 = 3 x 8 + 2 x 11,
+            // 18 = 3 x 6, 16 = 2 x 8, 7 = 1 x 7
+            int best_ng = 2, best_z = 1;
+            for (int ng : {11, 8, 7, 6, 4, 2})
+                for (int zc = 1; zc <= (n_colblocks == 1 ? 1 : ng == 11 ? 2 : 3); ++zc)
+                    if (ng * zc <= left && ((left - ng * zc) % 2 == 0 || left - ng * zc == 7) && // what remains must be coverable
+                        (ng * zc > best_ng * best_z || (ng * zc == best_ng * best_z && ng > best_ng))) {
+                        best_ng = ng;
+                        best_z = zc;
+                    }
+            take = best_ng * best_z;
+#define M2L_ZGO(NG, MW)                                                                                             \
+    m2l_gemm_launch<NG, STAGE, MW>(classes, tiles, n_tiles, n_pad, done, best_z, K, C, in, in_len, out, out_len,    \
+                                   qlist, slot_t, tile_idx, s);
+            if constexpr (STAGE >= 2) {
+                switch (best_ng) {
+                case 11: M2L_ZGO(11, 1) break;
+                case 8: M2L_ZGO(8, 4) break;
+                case 7: M2L_ZGO(7, 2) break;
+                case 6: M2L_ZGO(6, 4) break;
+                case 4: M2L_ZGO(4, 4) break;
+                default: M2L_ZGO(2, 4) break;
+                }
+            }
+#undef M2L_ZGO
         } else if (pref == 22 && left >= 22) M2L_GO(22, 1)
         else if (pref == 22 && left >= 16) M2L_GO(16, 1)
         else if (pref == 11 && left >= 11) M2L_GO(11, 1)
         else if (left >= 8) M2L_GO(8, 4)
-        else if (left == 7) {
-            if constexpr (STAGE >= 2) M2L_GO(7, 2) // 112 coordinates of the shared basis (p = 7); at 128 VGPRs it spills
-            else M2L_GO(6, 4)
-        } else if (left >= 6) M2L_GO(6, 4)
+        else if (left >= 6) M2L_GO(6, 4)
         else if (left >= 4) M2L_GO(4, 4)
         else M2L_GO(2, 4)
 #undef M2L_GO
@@ -1867,8 +1875,9 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
     // 78 KB of LDS: two fit a CU).  The halves of a tile read the same slot contents at about the same time (L2
     // hits) and twice as many, shorter workgroups balance tiles of unequal length (per-tile active steps) and fill
     // the CUs of launches with few tiles.  Measured, stage 2 per matvec: 10M points 16.2 -> 15.8 ms, p = 9 55.1 ->
-    // 53.6, 1M points (about 200 tiles) 2.10 -> 1.54 and 1.12 -> 0.71, one rank of an 8-way partition 2.81 -> 2.28.
-    // (Two separate launches of 11 groups were slower than one of 22.)  BBFMM_M2L_S2_ZSPLIT=1 turns it off.
+    // 53.6 (52.5 with the remainder as 3 x 8 instead of 22 + 2), 1M points (about 200 tiles) 2.10 -> 1.54 and 1.12 -> 0.71,
+    // one rank of an 8-way partition 2.81 -> 2.28.  (Two separate launches of 11 groups were slower than one of 22.)
+    // BBFMM_M2L_S2_ZSPLIT=1 turns it off.
     static const int z = [] {
         const char *e = std::getenv("BBFMM_M2L_S2_ZSPLIT");
         return e && std::atoi(e) == 1 ? 1 : 2;

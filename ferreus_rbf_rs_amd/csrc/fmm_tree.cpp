@@ -1049,15 +1049,21 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
     const int n = ops_.n, n_pad = cheb_.n_pad, d = ops_.d;
     const size_t n_levels = ops_.m2l.size();
     basis_rank_.assign(n_levels, 0);
-    std::vector<std::vector<double>> evec(n_levels); // n x n column-major, ascending eigenvalues
-    // through the Gram matrix f64 resolves the stack's singular values down to about 1e-8 of the largest: the basis is
-    // cut at max(epsilon, 3e-8)
-    const double eps_s = std::max(params_.epsilon, 3e-8);
-    for (size_t lv = 2; lv < n_levels; ++lv) {
+    std::vector<std::vector<double>> basis(n_levels); // n x rank column-major, most important direction first
+    const double eps_s = std::max(params_.epsilon, 1e-13);
+    std::vector<int> tvs; // the far transfer vectors
+    for (int tv = 0; tv < ops_.n_vec; ++tv) {
+        int mx = 0;
+        for (int a = 0; a < d; ++a) mx = std::max(mx, std::abs(static_cast<int>(ops_.all_vecs[static_cast<size_t>(tv) * d + a])));
+        if (mx >= 2) tvs.push_back(tv);
+    }
+    // G = sum_t (K_t P)^T (K_t P) + (P K_t)(P K_t)^T over the level's operators in the natural node order, P = I - W1 W1^T
+    // (k1 = 0: P = I).  K_t = Pi K_ref Pi^T with the symmetry permutations, and P commutes with them when W1 is a union
+    // of whole eigenspaces of the undeflated G (which commutes with every Pi): the deflation is applied to the 16
+    // reference factor pairs, K = U Vt:  (K P)^T (K P) = Vt'^T (U^T U) Vt',  (P K)(P K)^T = U' (Vt Vt^T) U'^T.
+    auto gram = [&](size_t lv, const std::vector<double> &w1, int k1, std::vector<double> *G_out) {
         const auto &lops = ops_.m2l[lv];
-        if (lops.empty()) continue;
         const int n_ref = static_cast<int>(lops.size());
-        // per reference operator: Vt^T Vt + U (Vt Vt^T) U^T  (n x n, symmetric), row-major
         std::vector<std::vector<double>> gref(static_cast<size_t>(n_ref));
         parallel_for(n_ref, 1, [&](int64_t r) {
             const M2lOperator &op = lops[static_cast<size_t>(r)];
@@ -1065,9 +1071,7 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
             std::vector<double> &g = gref[static_cast<size_t>(r)];
             g.assign(static_cast<size_t>(n) * n, 0.0);
             if (rk == 0) return;
-            // K = U Vt:  K^T K = Vt^T (U^T U) Vt,  K K^T = U (Vt Vt^T) U^T  (no assumption on which factor is orthonormal)
             std::vector<double> tv(static_cast<size_t>(rk) * rk, 0.0), tu(static_cast<size_t>(rk) * rk, 0.0);
-            std::vector<double> ut(static_cast<size_t>(n) * rk), vtt(static_cast<size_t>(n) * rk);
             for (int a = 0; a < rk; ++a)
                 for (int b = 0; b < rk; ++b) {
                     double av = 0.0, au = 0.0;
@@ -1078,12 +1082,39 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
                     tv[static_cast<size_t>(a) * rk + b] = av;
                     tu[static_cast<size_t>(a) * rk + b] = au;
                 }
-            for (int i = 0; i < n; ++i) // ut = U (Vt Vt^T), vtt = Vt^T (U^T U)
+            std::vector<double> u(op.u), vt(op.vt); // u[i + n a], vt[a + rk m]
+            if (k1 > 0) {
+                std::vector<double> c(static_cast<size_t>(k1) * rk);
+                for (int q = 0; q < k1; ++q) // W1^T U
+                    for (int a2 = 0; a2 < rk; ++a2) {
+                        double acc = 0.0;
+                        for (int i = 0; i < n; ++i) acc += w1[i + static_cast<size_t>(n) * q] * op.u[i + static_cast<size_t>(n) * a2];
+                        c[static_cast<size_t>(q) * rk + a2] = acc;
+                    }
+                for (int q = 0; q < k1; ++q)
+                    for (int a2 = 0; a2 < rk; ++a2) {
+                        const double cv = c[static_cast<size_t>(q) * rk + a2];
+                        for (int i = 0; i < n; ++i) u[i + static_cast<size_t>(n) * a2] -= w1[i + static_cast<size_t>(n) * q] * cv;
+                    }
+                for (int q = 0; q < k1; ++q) // Vt W1
+                    for (int a2 = 0; a2 < rk; ++a2) {
+                        double acc = 0.0;
+                        for (int m = 0; m < n; ++m) acc += op.vt[a2 + static_cast<size_t>(rk) * m] * w1[m + static_cast<size_t>(n) * q];
+                        c[static_cast<size_t>(q) * rk + a2] = acc;
+                    }
+                for (int q = 0; q < k1; ++q)
+                    for (int a2 = 0; a2 < rk; ++a2) {
+                        const double cv = c[static_cast<size_t>(q) * rk + a2];
+                        for (int m = 0; m < n; ++m) vt[a2 + static_cast<size_t>(rk) * m] -= cv * w1[m + static_cast<size_t>(n) * q];
+                    }
+            }
+            std::vector<double> ut(static_cast<size_t>(n) * rk), vtt(static_cast<size_t>(n) * rk);
+            for (int i = 0; i < n; ++i) // ut = U' (Vt Vt^T), vtt = Vt'^T (U^T U)
                 for (int b = 0; b < rk; ++b) {
                     double au = 0.0, av = 0.0;
-                    for (int a = 0; a < rk; ++a) {
-                        au += op.u[i + static_cast<size_t>(n) * a] * tv[static_cast<size_t>(a) * rk + b];
-                        av += op.vt[a + static_cast<size_t>(rk) * i] * tu[static_cast<size_t>(a) * rk + b];
+                    for (int a2 = 0; a2 < rk; ++a2) {
+                        au += u[i + static_cast<size_t>(n) * a2] * tv[static_cast<size_t>(a2) * rk + b];
+                        av += vt[a2 + static_cast<size_t>(rk) * i] * tu[static_cast<size_t>(a2) * rk + b];
                     }
                     ut[static_cast<size_t>(i) * rk + b] = au;
                     vtt[static_cast<size_t>(i) * rk + b] = av;
@@ -1091,19 +1122,14 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
             for (int i = 0; i < n; ++i)
                 for (int j = 0; j < n; ++j) {
                     double acc = 0.0;
-                    for (int a = 0; a < rk; ++a)
-                        acc += vtt[static_cast<size_t>(i) * rk + a] * op.vt[a + static_cast<size_t>(rk) * j] +
-                               ut[static_cast<size_t>(i) * rk + a] * op.u[j + static_cast<size_t>(n) * a];
+                    for (int a2 = 0; a2 < rk; ++a2)
+                        acc += vtt[static_cast<size_t>(i) * rk + a2] * vt[a2 + static_cast<size_t>(rk) * j] +
+                               ut[static_cast<size_t>(i) * rk + a2] * u[j + static_cast<size_t>(n) * a2];
                     g[static_cast<size_t>(i) * n + j] = acc;
                 }
         });
-        std::vector<double> G(static_cast<size_t>(n) * n, 0.0);
-        std::vector<int> tvs;
-        for (int tv = 0; tv < ops_.n_vec; ++tv) {
-            int mx = 0;
-            for (int a = 0; a < d; ++a) mx = std::max(mx, std::abs(static_cast<int>(ops_.all_vecs[static_cast<size_t>(tv) * d + a])));
-            if (mx >= 2) tvs.push_back(tv);
-        }
+        std::vector<double> &G = *G_out;
+        G.assign(static_cast<size_t>(n) * n, 0.0);
         parallel_for(n, 1, [&](int64_t i) { // natural frame: entry (i, j) of K_t stems from (invperm[i], invperm[j]) of its reference
             double *row = &G[static_cast<size_t>(i) * n];
             for (int tv : tvs) {
@@ -1117,64 +1143,112 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
                 const double v = 0.5 * (G[static_cast<size_t>(i) * n + j] + G[static_cast<size_t>(j) * n + i]);
                 G[static_cast<size_t>(i) * n + j] = G[static_cast<size_t>(j) * n + i] = v;
             }
-        std::vector<double> eval(static_cast<size_t>(n));
-        evec[lv].assign(static_cast<size_t>(n) * n, 0.0);
+    };
+    // eigenvalues descending, eigenvectors as columns in the same order
+    auto eigen = [&](const std::vector<double> &G, std::vector<double> *eval, std::vector<double> *evec) -> int {
+        eval->assign(static_cast<size_t>(n), 0.0);
+        evec->assign(static_cast<size_t>(n) * n, 0.0);
+        std::vector<double> asc(static_cast<size_t>(n)), vasc(static_cast<size_t>(n) * n);
         DevBuf<double> d_g, d_ev;
         CHK(dupload(&d_g, G));
         CHK(dalloc(&d_ev, static_cast<size_t>(n)));
         int rc = std::getenv("BBFMM_BASIS_HOST_EIGEN") ? BBFMM_UNSUPPORTED : device_symmetric_eigen(n, d_g.p, d_ev.p, stream_);
         if (rc == BBFMM_OK) {
-            HIPCHK(hipMemcpy(eval.data(), d_ev.p, static_cast<size_t>(n) * sizeof(double), hipMemcpyDeviceToHost));
-            HIPCHK(hipMemcpy(evec[lv].data(), d_g.p, static_cast<size_t>(n) * n * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(asc.data(), d_ev.p, static_cast<size_t>(n) * sizeof(double), hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(vasc.data(), d_g.p, static_cast<size_t>(n) * n * sizeof(double), hipMemcpyDeviceToHost));
+            for (int j = 0; j < n; ++j) {
+                (*eval)[static_cast<size_t>(j)] = asc[static_cast<size_t>(n - 1 - j)];
+                std::copy(vasc.begin() + static_cast<size_t>(n - 1 - j) * n, vasc.begin() + static_cast<size_t>(n - j) * n,
+                          evec->begin() + static_cast<size_t>(j) * n);
+            }
         }
         dfree(&d_g);
         dfree(&d_ev);
         if (rc == BBFMM_UNSUPPORTED) { // no rocSOLVER: one-sided Jacobi on the host (slow at high orders, same result)
-            std::vector<double> u, sv, vt;
-            jacobi_svd(G, n, n, &u, &sv, &vt); // G symmetric positive semi-definite: singular values = eigenvalues, descending
-            for (int j = 0; j < n; ++j) {
-                eval[static_cast<size_t>(n - 1 - j)] = sv[static_cast<size_t>(j)];
-                std::copy(u.begin() + static_cast<size_t>(j) * n, u.begin() + static_cast<size_t>(j + 1) * n,
-                          evec[lv].begin() + static_cast<size_t>(n - 1 - j) * n);
-            }
+            std::vector<double> sv, vt;
+            jacobi_svd(G, n, n, evec, &sv, &vt); // G symmetric positive semi-definite: singular values = eigenvalues, descending
+            *eval = sv;
             rc = BBFMM_OK;
         }
         if (rc != BBFMM_OK) return fail(rc, "eigen-decomposition of the shared-basis Gram matrix failed");
-        // The rounding noise of G (sums of products in f64) shows as eigenvalues of either sign around 1e-17 of the
-        // largest: anything below 1e-16 of it is treated as 0, otherwise hundreds of such values add up past eps^2 of
-        // the trace and the cut lands in the noise.
-        const double lam_max = std::max(eval[static_cast<size_t>(n - 1)], 0.0);
-        const double noise = 1e-16 * lam_max;
-        double total = 0.0;
-        for (double v : eval)
-            if (v > noise) total += v;
-        double tail = 0.0;
-        int rank = 0;
-        for (int j = 0; j < n; ++j) { // ascending: drop while the dropped part stays below eps^2 of the trace
-            const double v = eval[static_cast<size_t>(j)];
-            if (v > noise) tail += v;
-            if (!(tail < eps_s * eps_s * total)) {
-                rank = n - j;
-                break;
-            }
-        }
-        if (rank == 0) rank = 1;
-        // The operators of a level are permuted copies of each other, so the eigenvalues come in multiplets (the
-        // symmetry group's irreducible dimensions): a cut inside one would keep an arbitrary part of its eigenspace
-        // (and a different part with another solver).  The whole multiplet is kept.
-        // (members agree to the noise of G, a few 1e-17 of the largest eigenvalue; a multiplet of the cube's symmetry
-        // group has at most six members here.)
-        for (int extra = 0; extra < 8 && rank < n; ++extra) {
-            const double kept = eval[static_cast<size_t>(n - rank)], next = eval[static_cast<size_t>(n - rank - 1)];
-            if (next > noise && kept - next <= 1e-3 * kept + 6e-17 * lam_max) ++rank;
+        return BBFMM_OK;
+    };
+    // The operators of a level are permuted copies of each other, so the eigenvalues come in multiplets (the symmetry
+    // group's irreducible dimensions, at most six members here): a cut inside one would keep an arbitrary part of
+    // its eigenspace -- a different part with another solver, and not invariant under the permutations.  `count`
+    // leading values of a descending list are extended to the end of their multiplet.
+    auto whole_multiplet = [&](const std::vector<double> &ev, int count, double noise) {
+        for (int extra = 0; extra < 8 && count > 0 && count < n; ++extra) {
+            const double kept = ev[static_cast<size_t>(count - 1)], next = ev[static_cast<size_t>(count)];
+            if (next > noise && kept - next <= 1e-3 * kept + 0.6 * noise) ++count;
             else break;
         }
-        basis_rank_[lv] = rank;
+        return count;
+    };
+    for (size_t lv = 2; lv < n_levels; ++lv) {
+        if (ops_.m2l[lv].empty()) continue;
+        // Pass 1.  G squares the singular values of the stack, and its f64 rounding noise shows as eigenvalues of
+        // either sign around 1e-17 of the largest: values below 1e-16 of it are treated as 0 (hundreds of them would
+        // otherwise add up past eps^2 of the trace and put the cut into the noise).
+        std::vector<double> G, ev1, vec1;
+        gram(lv, std::vector<double>(), 0, &G);
+        CHK(eigen(G, &ev1, &vec1));
+        const double lam_max = std::max(ev1[0], 0.0), noise1 = 1e-16 * lam_max;
         if (std::getenv("BBFMM_VERBOSE") && lv == 2) {
-            std::fprintf(stderr, "[bbfmm] shared basis level %zu eigenvalues / largest (descending, every 10th):", lv);
-            for (int j = 0; j < n; j += 10) std::fprintf(stderr, " %.1e", eval[static_cast<size_t>(n - 1 - j)] / eval[static_cast<size_t>(n - 1)]);
+            std::fprintf(stderr, "[bbfmm] shared basis level %zu eigenvalues / largest (every 10th):", lv);
+            for (int j = 0; j < n; j += 10) std::fprintf(stderr, " %.1e", ev1[static_cast<size_t>(j)] / ev1[0]);
             std::fprintf(stderr, "\n");
         }
+        auto cut = [&](const std::vector<double> &ev, double head, double noise) { // values kept of a descending list
+            double total = head;
+            for (double v : ev)
+                if (v > noise) total += v;
+            double tail = 0.0;
+            for (int j = n - 1; j >= 0; --j) {
+                if (ev[static_cast<size_t>(j)] > noise) tail += ev[static_cast<size_t>(j)];
+                if (!(tail < eps_s * eps_s * total)) return j + 1;
+            }
+            return 0;
+        };
+        int rank = 0;
+        if (eps_s >= 1e-6) { // the cut lies far above the noise: one pass
+            rank = whole_multiplet(ev1, std::max(1, cut(ev1, 0.0, noise1)), noise1);
+            basis[lv].assign(vec1.begin(), vec1.begin() + static_cast<size_t>(rank) * n);
+        } else {
+            // Pass 2: everything above 1e-10 of the largest eigenvalue (whole multiplets) is accurate and kept; the
+            // Gram matrix of the stack deflated by those directions carries the rest at its own scale, so the cut at
+            // eps^2 of the trace is resolved down to eps ~ 1e-13 instead of 3e-8.
+            int k1 = 0;
+            while (k1 < n && ev1[static_cast<size_t>(k1)] > 1e-10 * lam_max) ++k1;
+            k1 = whole_multiplet(ev1, std::max(1, k1), noise1);
+            std::vector<double> w1(vec1.begin(), vec1.begin() + static_cast<size_t>(k1) * n), ev2, vec2;
+            double head = 0.0;
+            for (int j = 0; j < k1; ++j) head += ev1[static_cast<size_t>(j)];
+            gram(lv, w1, k1, &G);
+            CHK(eigen(G, &ev2, &vec2));
+            const double noise2 = std::max(1e-16 * std::max(ev2[0], 0.0), 1e-30 * lam_max);
+            int r2 = cut(ev2, head, noise2);
+            if (r2 > 0) r2 = whole_multiplet(ev2, r2, noise2);
+            r2 = std::min(r2, n - k1);
+            rank = k1 + r2;
+            basis[lv] = w1;
+            basis[lv].insert(basis[lv].end(), vec2.begin(), vec2.begin() + static_cast<size_t>(r2) * n);
+            for (int pass = 0; pass < 2; ++pass) // the second set is orthogonal to the first up to rounding: tidy up
+                for (int j = k1; j < rank; ++j) {
+                    double *cj = &basis[lv][static_cast<size_t>(j) * n];
+                    for (int q = 0; q < j; ++q) {
+                        const double *cq = &basis[lv][static_cast<size_t>(q) * n];
+                        double dot = 0.0;
+                        for (int i = 0; i < n; ++i) dot += cq[i] * cj[i];
+                        for (int i = 0; i < n; ++i) cj[i] -= dot * cq[i];
+                    }
+                    double nn = 0.0;
+                    for (int i = 0; i < n; ++i) nn += cj[i] * cj[i];
+                    nn = nn > 0.0 ? 1.0 / std::sqrt(nn) : 0.0;
+                    for (int i = 0; i < n; ++i) cj[i] *= nn;
+                }
+        }
+        basis_rank_[lv] = rank;
     }
     int max_rank = 0;
     for (int r : basis_rank_) max_rank = std::max(max_rank, r);
@@ -1207,7 +1281,7 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
         const int rank = basis_rank_[lv];
         std::vector<double> wc(static_cast<size_t>(n_pad) * basis_pad_, 0.0), we(static_cast<size_t>(basis_pad_) * n_pad, 0.0);
         for (int j = 0; j < rank; ++j) {
-            const double *col = &evec[lv][static_cast<size_t>(n - 1 - j) * n]; // j-th largest eigenvalue
+            const double *col = &basis[lv][static_cast<size_t>(j) * n];
             for (int m = 0; m < n; ++m) {
                 wc[static_cast<size_t>(m) * basis_pad_ + j] = col[m];
                 we[static_cast<size_t>(j) * n_pad + m] = col[m];

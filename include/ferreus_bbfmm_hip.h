@@ -81,10 +81,10 @@ typedef struct bbfmm_handle bbfmm_handle;
                                    Used by the CPU-side structure tests. */
 #define BBFMM_FLAG_M2L_SHARED_BASIS 2u /* EXTENSION beyond the reference (off by default): the M2L stages run on
                                         * coordinates in one orthonormal basis per level (the dominant subspace of
-                                        * all of the level's compressed operators, cut at max(params.epsilon, 3e-8)
-                                        * by the operators' own rule: rank 108 of 343 for LinearRbf at order 7, about
-                                        * 115 of 729 for the thin-plate spline at order 9), with the reference's
-                                        * factors projected onto it.  A third to a sixth of the M2L flops; results
+                                        * all of the level's compressed operators, cut at params.epsilon by the
+                                        * operators' own rule: rank 107 of 343 for LinearRbf at order 7, 183-259 of 729
+                                        * for the thin-plate spline at order 9), with the reference's factors
+                                        * projected onto it.  About a third of the M2L flops; results
                                         * differ from the default path by the projection error (a few epsilon of the
                                         * far field; tests/test_gpu_shared_basis.py).  Needs a compressed operator
                                         * type (ACA or SVD) and a device; when the basis would keep more than 60 % of

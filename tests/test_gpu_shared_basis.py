@@ -34,7 +34,7 @@ def test_shared_basis_matches_default_path_within_ten_epsilon(kid, order, br, si
     pts = np.unique(pts, axis=0)
     n = pts.shape[0]
     a, b = _trees(pts, kid, order, br, sill)
-    eps = max(10.0 ** -order, 3e-8)                                 # the projection tolerance
+    eps = 10.0 ** -order                                            # the operators' and the basis' tolerance
     sa, sb = a.stats(), b.stats()
     w = rng.standard_normal((n, 3))
     a.set_weights(w)
