@@ -57,6 +57,8 @@ EXTRA_CONFIGS = [
     # (M2L stages in one basis per level, cut at the operators' epsilon)
     {"name": "extension_shared_basis_linear_10M", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 1,
      "base_range": 1.0, "total_sill": 1.0, "m2l_shared_basis": True},
+    {"name": "extension_shared_basis_linear_10M_8rhs", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 8,
+     "base_range": 1.0, "total_sill": 1.0, "m2l_shared_basis": True},
 ]
 
 
