@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(HERE, "libferreus_bbfmm_hip.so")
 OK, POINT_OUTSIDE_TREE, KERNEL_NO_GRADIENTS, BAD_ARGUMENT, DEVICE_ERROR, UNSUPPORTED = range(6)
 FLAG_HOST_ONLY = 1
 FLAG_M2L_SHARED_BASIS = 2  # extension beyond the reference: M2L stages in one basis per level
+FLAG_DIRECT_SMALL_W_LEAVES = 4  # extension beyond the reference: small W-list leaves as near field
 N_PHASES = 11
 PHASE_NAMES = ["gather", "P2M", "M2M", "M2L_stage1", "M2L_stage2", "P2L", "L2L", "P2P", "M2P",
                "L2P", "scatter"]

@@ -194,6 +194,66 @@ static void merged_runs(const HostTree &t, const int32_t *cells, int64_t count, 
     }
 }
 
+// BBFMM_FLAG_DIRECT_SMALL_W_LEAVES (extension): every W-list entry (B, w) whose cell w is a leaf with at most `n_nodes`
+// points moves to the U lists of both cells, and B leaves the X list of w (X = W^T, linear_tree.rs:388-392).  Returns the
+// number of entries moved.  Lists stay sorted by cell index inside a row.
+static int64_t direct_small_w_leaves(HostTree *t, int64_t n_nodes) {
+    const int64_t C = t->n_cells();
+    std::vector<std::pair<int32_t, int32_t>> moved; // (B, w)
+    Csr w2;
+    w2.ptr.assign(static_cast<size_t>(C) + 1, 0);
+    w2.idx.reserve(t->w.idx.size());
+    for (int64_t B = 0; B < C; ++B) {
+        for (int64_t q = t->w.ptr[B]; q < t->w.ptr[B + 1]; ++q) {
+            const int32_t w = t->w.idx[q];
+            const int64_t npts = t->pt_end[w] - t->pt_begin[w];
+            if (t->is_leaf[w] && npts <= n_nodes) moved.emplace_back(static_cast<int32_t>(B), w);
+            else w2.idx.push_back(w);
+        }
+        w2.ptr[B + 1] = static_cast<int64_t>(w2.idx.size());
+    }
+    if (moved.empty()) return 0;
+    t->w = std::move(w2);
+    // X = transpose of the remaining W (rows ascending in B because B ascends in the outer loop)
+    Csr x2;
+    x2.ptr.assign(static_cast<size_t>(C) + 1, 0);
+    for (int32_t w : t->w.idx) ++x2.ptr[static_cast<size_t>(w) + 1];
+    for (int64_t c = 0; c < C; ++c) x2.ptr[c + 1] += x2.ptr[c];
+    x2.idx.resize(t->w.idx.size());
+    {
+        std::vector<int64_t> fill(x2.ptr.begin(), x2.ptr.end() - 1);
+        for (int64_t B = 0; B < C; ++B)
+            for (int64_t q = t->w.ptr[B]; q < t->w.ptr[B + 1]; ++q) x2.idx[fill[t->w.idx[q]]++] = static_cast<int32_t>(B);
+    }
+    t->x = std::move(x2);
+    // U: both directions
+    std::vector<std::pair<int32_t, int32_t>> add;
+    add.reserve(2 * moved.size());
+    for (const auto &m : moved) {
+        add.emplace_back(m.first, m.second);
+        add.emplace_back(m.second, m.first);
+    }
+    std::sort(add.begin(), add.end());
+    add.erase(std::unique(add.begin(), add.end()), add.end());
+    Csr u2;
+    u2.ptr.assign(static_cast<size_t>(C) + 1, 0);
+    u2.idx.reserve(t->u.idx.size() + add.size());
+    size_t a = 0;
+    for (int64_t c = 0; c < C; ++c) {
+        const size_t row0 = u2.idx.size();
+        for (int64_t q = t->u.ptr[c]; q < t->u.ptr[c + 1]; ++q) u2.idx.push_back(t->u.idx[q]);
+        const size_t a0 = a;
+        while (a < add.size() && add[a].first == c) u2.idx.push_back(add[a++].second);
+        if (a > a0) {
+            std::sort(u2.idx.begin() + row0, u2.idx.end());
+            u2.idx.erase(std::unique(u2.idx.begin() + row0, u2.idx.end()), u2.idx.end());
+        }
+        u2.ptr[c + 1] = static_cast<int64_t>(u2.idx.size());
+    }
+    t->u = std::move(u2);
+    return static_cast<int64_t>(moved.size());
+}
+
 int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, int kernel_type, double base_range,
                     double total_sill, bool adaptive, bool sparse, const double *extents,
                     const bbfmm_params *params, uint32_t flags) {
@@ -306,6 +366,14 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
     if (!tree_built_on_device_)
         build_tree(pts_.data(), n, n, d, center, radius, params_.max_points_per_cell, !sparse, adaptive, &tree_);
     timer.lap("tree + interaction lists");
+    if ((flags & BBFMM_FLAG_DIRECT_SMALL_W_LEAVES) && adaptive) {
+        int64_t n_nodes = 1;
+        for (int a = 0; a < d; ++a) n_nodes *= order;
+        const int64_t moved = direct_small_w_leaves(&tree_, n_nodes);
+        if (std::getenv("BBFMM_VERBOSE"))
+            std::fprintf(stderr, "[bbfmm] direct small W leaves: %lld W-list entries became near field\n", static_cast<long long>(moved));
+        timer.lap("W leaves -> near field");
+    }
     precompute_operators(order, d, radius, tree_.depth, kernel_, params_.compression_type, params_.epsilon, &ops_);
     timer.lap("operators (ACA/SVD)");
 

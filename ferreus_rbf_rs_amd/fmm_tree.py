@@ -141,9 +141,11 @@ class FmmTree:
     def __init__(self, source_points, interpolation_order: int, kernel_params: KernelParams,
                  adaptive_tree: bool, sparse: bool, *, extents=None,
                  params: Optional[FmmParams] = None, host_only: bool = False,
-                 m2l_shared_basis: bool = False):
+                 m2l_shared_basis: bool = False, direct_small_w_leaves: bool = False):
         """m2l_shared_basis: BBFMM_FLAG_M2L_SHARED_BASIS, an extension beyond the reference (off by default):
-        the M2L stages run in one orthonormal basis per level, cut at params.epsilon."""
+        the M2L stages run in one orthonormal basis per level, cut at params.epsilon.
+        direct_small_w_leaves: BBFMM_FLAG_DIRECT_SMALL_W_LEAVES, likewise an extension: W-list leaves with no
+        more points than nodes are summed directly instead of through M2P / P2L."""
         lib = L.load()
         pts = _as_f64_2d(source_points, "source_points")
         n, d = pts.shape
@@ -159,7 +161,8 @@ class FmmTree:
                               ext.ctypes.data if ext is not None else None,
                               ctypes.byref(cpar) if cpar is not None else None,
                               (L.FLAG_HOST_ONLY if host_only else 0) |
-                              (L.FLAG_M2L_SHARED_BASIS if m2l_shared_basis else 0), ctypes.byref(h))
+                              (L.FLAG_M2L_SHARED_BASIS if m2l_shared_basis else 0) |
+                              (L.FLAG_DIRECT_SMALL_W_LEAVES if direct_small_w_leaves else 0), ctypes.byref(h))
         self._h = h
         self._lib = lib
         if rc != L.OK:
