@@ -59,6 +59,12 @@ EXTRA_CONFIGS = [
      "base_range": 1.0, "total_sill": 1.0, "m2l_shared_basis": True},
     {"name": "extension_shared_basis_linear_10M_8rhs", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 8,
      "base_range": 1.0, "total_sill": 1.0, "m2l_shared_basis": True},
+    # EXTENSION beyond the reference: config 2's workloads with BBFMM_FLAG_DIRECT_SMALL_W_LEAVES (W-list leaves with no
+    # more points than nodes are summed directly instead of through M2P / P2L)
+    {"name": "extension_direct_w_leaves_spheroidal3_1M", "points": 1_000_000, "kernel": "Spheroidal3Rbf", "order": 7, "nrhs": 1,
+     "base_range": 0.1, "total_sill": 0.1, "direct_small_w_leaves": True},
+    {"name": "extension_direct_w_leaves_multiquadric_ext_1M", "points": 1_000_000, "kernel": "MultiquadricExt", "order": 7,
+     "nrhs": 1, "base_range": 0.1, "total_sill": 0.1, "direct_small_w_leaves": True},
 ]
 
 
@@ -297,7 +303,8 @@ def run_extra_config(torch, F, dev, cfg, tree=None):
     if tree is None:
         tree = F.FmmTree(pts, cfg["order"], F.KernelParams(F.KernelType[cfg["kernel"]], base_range=cfg["base_range"],
                                                            total_sill=cfg["total_sill"]), True, True,
-                         m2l_shared_basis=bool(cfg.get("m2l_shared_basis")))
+                         m2l_shared_basis=bool(cfg.get("m2l_shared_basis")),
+                         direct_small_w_leaves=bool(cfg.get("direct_small_w_leaves")))
     t_build = time.time() - t0
     stats = tree.stats()
     w = torch.from_numpy(np.random.default_rng(43).random((K, N))).to(dev)
@@ -317,6 +324,9 @@ def run_extra_config(torch, F, dev, cfg, tree=None):
         err = float((got - yd).abs().max() / yd.abs().max())
     del pts_d
     ext = {}
+    if cfg.get("direct_small_w_leaves"):
+        ext = {"extension": "BBFMM_FLAG_DIRECT_SMALL_W_LEAVES (W-list leaves with no more points than nodes summed directly: "
+                            "exact where the reference's M2P / P2L approximate)"}
     if cfg.get("m2l_shared_basis"):
         ext = {"extension": "BBFMM_FLAG_M2L_SHARED_BASIS (not the reference's M2L arithmetic; results within a few epsilon "
                             "of the default path)", "m2l_basis_rank": stats.m2l_basis_rank, "m2l_basis_len": stats.m2l_basis_len}
@@ -443,7 +453,7 @@ def main():
                 ordered = sorted(EXTRA_CONFIGS, key=lambda c: (c["points"], c["kernel"], c["order"]) != (N, args.kernel, args.order))
                 for cfg in ordered:
                     reuse = tree if (cfg["points"], cfg["kernel"], cfg["order"]) == (N, args.kernel, args.order) and \
-                        not cfg.get("m2l_shared_basis") else None
+                        not cfg["name"].startswith("extension_") else None
                     if reuse is None and tree is not None:
                         del tree, w, out, stream
                         tree = w = out = stream = None

@@ -91,11 +91,12 @@ fn kernel_id(k: KernelType) -> i32 {
 /// The reference's constructor has no argument for it, so the shim reads `FERREUS_BBFMM_M2L_SHARED_BASIS=1` from the
 /// environment; without it the handle computes exactly what `ferreus_bbfmm` does.
 pub const BBFMM_FLAG_M2L_SHARED_BASIS: u32 = 2;
+/// `BBFMM_FLAG_DIRECT_SMALL_W_LEAVES`: the other extension (`FERREUS_BBFMM_DIRECT_SMALL_W_LEAVES=1`).
+pub const BBFMM_FLAG_DIRECT_SMALL_W_LEAVES: u32 = 4;
 fn creation_flags() -> u32 {
-    match std::env::var("FERREUS_BBFMM_M2L_SHARED_BASIS") {
-        Ok(v) if v == "1" => BBFMM_FLAG_M2L_SHARED_BASIS,
-        _ => 0,
-    }
+    let on = |name: &str| matches!(std::env::var(name), Ok(v) if v == "1");
+    (if on("FERREUS_BBFMM_M2L_SHARED_BASIS") { BBFMM_FLAG_M2L_SHARED_BASIS } else { 0 })
+        | (if on("FERREUS_BBFMM_DIRECT_SMALL_W_LEAVES") { BBFMM_FLAG_DIRECT_SMALL_W_LEAVES } else { 0 })
 }
 
 impl FmmTree {

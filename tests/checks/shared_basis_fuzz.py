@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random small cases of the shared-basis extension against the default path: orders, kernels, dimensions, tolerances,
+"""Random small cases of the two extensions (shared basis, direct small W leaves; one or both per case) against the default path: orders, kernels, dimensions, tolerances,
 right-hand sides, compression types -- every (coordinates per cell, column-group plan) combination the chunk plans of
 stages 2 / 3 can meet.  Prints one JSON line per case and a summary; exit code 1 on a failure.  args: [cases] [seed]"""
 import json, os, sys
@@ -26,7 +26,8 @@ for it in range(cases):
     kp = F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill)
     par = F.FmmParams(int(rng.choice([32, 64, 256])), F.M2LCompressionType(comp), eps, 1024)
     a = F.FmmTree(pts, order, kp, True, True, params=par)
-    b = F.FmmTree(pts, order, kp, True, True, params=par, m2l_shared_basis=True)
+    shared, direct = [(True, False), (False, True), (True, True)][int(rng.integers(0, 3))]
+    b = F.FmmTree(pts, order, kp, True, True, params=par, m2l_shared_basis=shared, direct_small_w_leaves=direct)
     w = rng.standard_normal((n, nrhs))
     a.set_weights(w); b.set_weights(w)
     ya, yb = a.evaluate(w, pts), b.evaluate(w, pts)
@@ -37,7 +38,7 @@ for it in range(cases):
     ok = diff < 20 * eps and np.isfinite(yb).all()
     bad += not ok
     seen.add((sb.n_nodes, sb.m2l_basis_len))
-    print(json.dumps({"d": d, "order": order, "kernel": kid, "eps": eps, "compression": comp, "nrhs": nrhs, "n": n,
+    print(json.dumps({"shared_basis": shared, "direct_w_leaves": direct, "n_w": [int(a.stats().n_w), int(sb.n_w)], "d": d, "order": order, "kernel": kid, "eps": eps, "compression": comp, "nrhs": nrhs, "n": n,
                       "depth": sb.depth, "nodes": sb.n_nodes, "basis_rank": sb.m2l_basis_rank, "basis_len": sb.m2l_basis_len,
                       "diff_over_eps": round(diff / eps, 3), "ok": bool(ok)}), flush=True)
     del a, b

@@ -30,7 +30,8 @@ for name, gen, order, kernel, br, sill, K in cases:
     kid = O.KERNEL_IDS[kernel]
     t0 = time.time()
     tree = F.FmmTree(pts, order, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill), True, True,
-                     m2l_shared_basis="--shared-basis" in sys.argv)   # the extension of DESIGN.md section 5 on the same shapes
+                     m2l_shared_basis="--shared-basis" in sys.argv,   # the extensions of DESIGN.md section 5 on the same shapes
+                     direct_small_w_leaves="--direct-w-leaves" in sys.argv)
     build = time.time() - t0
     w = torch.rand((K + 1, n), dtype=torch.float64, device="cuda")
     y = torch.zeros_like(w)

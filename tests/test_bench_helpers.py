@@ -51,9 +51,9 @@ def test_committed_counters_are_only_quoted_for_the_sources_they_were_taken_on(t
 
 def test_extra_configs_name_baseline_json_configs():
     names = [c["name"] for c in bench.EXTRA_CONFIGS]
-    assert len(names) == len(set(names)) == 6
-    assert sum(1 for c in bench.EXTRA_CONFIGS if not c.get("m2l_shared_basis")) == 4   # configs 2 (x2), 3, 4
-    assert all(c["name"].startswith("extension_") for c in bench.EXTRA_CONFIGS if c.get("m2l_shared_basis"))
-    assert not any(c["name"].startswith("extension_") for c in bench.EXTRA_CONFIGS if not c.get("m2l_shared_basis"))
+    assert len(names) == len(set(names)) == 8
+    flagged = lambda c: bool(c.get("m2l_shared_basis") or c.get("direct_small_w_leaves"))
+    assert sum(1 for c in bench.EXTRA_CONFIGS if not flagged(c)) == 4                   # configs 2 (x2), 3, 4
+    assert all(c["name"].startswith("extension_") == flagged(c) for c in bench.EXTRA_CONFIGS)   # extensions say so
     for c in bench.EXTRA_CONFIGS:
         assert c["total_sill"] <= c["base_range"]      # KernelParamsBuilder::build asserts this (kernel_helpers.rs:69-70)
