@@ -16,6 +16,8 @@ ap.add_argument("--base-range", type=float, default=1.0)
 ap.add_argument("--total-sill", type=float, default=1.0)
 ap.add_argument("--samples", type=int, default=64)
 ap.add_argument("--steps", type=int, default=4)
+ap.add_argument("--shared-basis", action="store_true", help="extension BBFMM_FLAG_M2L_SHARED_BASIS")
+ap.add_argument("--direct-w-leaves", action="store_true", help="extension BBFMM_FLAG_DIRECT_SMALL_W_LEAVES")
 a = ap.parse_args()
 
 import torch
@@ -26,7 +28,8 @@ N, K = a.points, a.nrhs
 kid = O.KERNEL_IDS[a.kernel]
 pts = np.random.default_rng(42).random((N, 3))
 t0 = time.time()
-tree = F.FmmTree(pts, a.order, F.KernelParams(F.KernelType(kid), base_range=a.base_range, total_sill=a.total_sill), True, True)
+tree = F.FmmTree(pts, a.order, F.KernelParams(F.KernelType(kid), base_range=a.base_range, total_sill=a.total_sill), True, True,
+               m2l_shared_basis=a.shared_basis, direct_small_w_leaves=a.direct_w_leaves)
 build = time.time() - t0
 dev = torch.device("cuda")
 w_h = np.random.default_rng(43).random((K, N))
