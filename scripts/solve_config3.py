@@ -24,6 +24,9 @@ ap.add_argument("--precon-order", type=int, default=0,
 ap.add_argument("--precon-shared-basis", action="store_true",
                 help="extension: the preconditioner's partial matvecs run on a second tree with BBFMM_FLAG_M2L_SHARED_BASIS "
                      "(FGMRES is flexible; the operator keeps the reference's arithmetic)")
+ap.add_argument("--shared-basis", action="store_true",
+                help="extension: ONE tree with BBFMM_FLAG_M2L_SHARED_BASIS for the operator and the preconditioner (the "
+                     "operator's products then carry the basis' truncation, about epsilon)")
 ap.add_argument("--clustered", action="store_true", help="points from a mixture of 12 Gaussian clusters instead of uniform")
 a = ap.parse_args()
 kid = {"LinearRbf": 0, "ThinPlateSplineRbf": 1, "CubicRbf": 2, "Spheroidal3Rbf": 3}[a.kernel]
@@ -36,7 +39,7 @@ if a.clustered:
     pts = np.unique(pts, axis=0); n = pts.shape[0]          # (clipping can duplicate points on the box faces)
 vals = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.5 * pts[:, 2] ** 2          # smooth test function
 t0 = time.time()
-tree = F.FmmTree(pts, a.order, F.KernelParams(F.KernelType(kid)), True, True)
+tree = F.FmmTree(pts, a.order, F.KernelParams(F.KernelType(kid)), True, True, m2l_shared_basis=a.shared_basis)
 t_tree = time.time() - t0
 st = InterpolantSettings(kid, 3, nugget=a.nugget)
 t0 = time.time()
@@ -56,7 +59,7 @@ x, hist = S.fgmres(op, rhs, pre, None, 20, 5, S.FittingAccuracy(a.tol), callback
 t_solve = time.time() - t0
 idx = rng.choice(n, 2000, replace=False)
 fit = op(x)[idx]
-print(json.dumps({"points": n, "kernel": a.kernel, "order": a.order, "precon_order": a.precon_order or a.order, "precon_shared_basis": bool(a.precon_shared_basis), "levels": pre.num_levels, "basis": st.basis_size,
+print(json.dumps({"points": n, "kernel": a.kernel, "order": a.order, "precon_order": a.precon_order or a.order, "precon_shared_basis": bool(a.precon_shared_basis), "shared_basis": bool(a.shared_basis), "levels": pre.num_levels, "basis": st.basis_size,
                   "fmm_tree_build_s": round(t_tree, 2), "ddm_build_and_factor_s": round(t_ddm, 2),
                   "solve_s": round(t_solve, 2), "iterations": len(hist),
                   "s_per_iteration": round(t_solve / max(len(hist), 1), 3),
