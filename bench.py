@@ -15,10 +15,13 @@ rank holds the whole tree and owns a contiguous Morton range of target leaves (s
 the total work is one matvec over all points); the owned potentials are exchanged with one RCCL
 all-gather over xGMI per step.
 
-Rank 0 prints ONE JSON line (see the prompt's contract) with `roofline` and `cpu_baseline`; at
-N = 1 the line also carries `configs`: the other single-GPU configurations of BASELINE.json
-(1M Spheroidal3 / multiquadric, the 10M thin-plate-spline p = 9 operator of config 3, 10M x 8 rhs)
-with their own step time, dominant-kernel roofline and sampled dense-row error.
+Rank 0 prints ONE JSON line (see the prompt's contract) with `roofline`, `phase_roofline` and -- at N = 1 --
+`cpu_baseline`; at every world size the line carries `dense_rows_rel_err` (32 rows of the dense sum computed
+in plain torch on rank 0 after the exchange) and `configs`: at N = 1 the other single-GPU configurations of
+BASELINE.json (1M Spheroidal3 / multiquadric, the 10M thin-plate-spline p = 9 operator of config 3, 10M x 8 rhs),
+at N > 1 config 5 (40M Spheroidal3, partitioned over the same ranks), each with its own step time, rooflines and
+sampled dense-row error.  `--configs` adds opt-in entries: `solve` = config 3 end to end (10M thin-plate spline +
+linear drift, FGMRES 20 x 5 + Schwarz), `extensions` = the labelled extensions beyond the reference's arithmetic.
 """
 from __future__ import annotations
 
@@ -27,7 +30,6 @@ import glob
 import hashlib
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -53,19 +55,32 @@ EXTRA_CONFIGS = [
      "base_range": 1.0, "total_sill": 1.0},
     {"name": "config3_operator_tps_10M_order9", "points": 10_000_000, "kernel": "ThinPlateSplineRbf", "order": 9,
      "nrhs": 1, "base_range": 1.0, "total_sill": 1.0},
-    # EXTENSION beyond the reference, never the headline: the headline workload with BBFMM_FLAG_M2L_SHARED_BASIS
-    # (M2L stages in one basis per level, cut at the operators' epsilon)
+]
+
+# EXTENSIONS beyond the reference (never the headline, never in the default line): `--configs extensions`
+EXTENSION_CONFIGS = [
+    # the headline workload with BBFMM_FLAG_M2L_SHARED_BASIS (M2L stages in one basis per level)
     {"name": "extension_shared_basis_linear_10M", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 1,
      "base_range": 1.0, "total_sill": 1.0, "m2l_shared_basis": True},
     {"name": "extension_shared_basis_linear_10M_8rhs", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 8,
      "base_range": 1.0, "total_sill": 1.0, "m2l_shared_basis": True},
-    # EXTENSION beyond the reference: config 2's workloads with BBFMM_FLAG_DIRECT_SMALL_W_LEAVES (W-list leaves with no
-    # more points than nodes are summed directly instead of through M2P / P2L)
+    # config 2's workloads with BBFMM_FLAG_DIRECT_SMALL_W_LEAVES (small W-list leaves summed directly)
     {"name": "extension_direct_w_leaves_spheroidal3_1M", "points": 1_000_000, "kernel": "Spheroidal3Rbf", "order": 7, "nrhs": 1,
      "base_range": 0.1, "total_sill": 0.1, "direct_small_w_leaves": True},
     {"name": "extension_direct_w_leaves_multiquadric_ext_1M", "points": 1_000_000, "kernel": "MultiquadricExt", "order": 7,
      "nrhs": 1, "base_range": 0.1, "total_sill": 0.1, "direct_small_w_leaves": True},
 ]
+
+# BASELINE.json config 5: rides on the N > 1 line, partitioned over the same ranks
+CONFIG5 = {"name": "config5_spheroidal3_40M", "points": 40_000_000, "kernel": "Spheroidal3Rbf", "order": 7, "nrhs": 1,
+           "base_range": 0.1, "total_sill": 0.1}
+
+# measured once at the full 10M points (scripts/cpu_port_full_size.py -> profiles/r02_cpu_port_full_10M.json)
+CPU_PORT_FULL_SIZE = {"value_full_size": 0.0213, "full_size_threads": 256, "full_size_from": "profiles/r02_cpu_port_full_10M.json"}
+
+# FP64 vector issue peak: 256 CUs x 4 SIMDs, one wave64 FP64 instruction per 4 cycles, at the 2.4 GHz AMD's
+# 78.6 TFLOP/s assumes (= 78.6e12 / 2 lane-FMAs per second)
+FP64_VALU_LANE_INSTR_PEAK = 78.6e12 / 2.0
 
 
 def parse():
@@ -81,8 +96,11 @@ def parse():
     ap.add_argument("--total-sill", type=float, default=1.0)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU sample (0: points/64)")
-    ap.add_argument("--configs", default="auto", choices=["auto", "off"],
-                    help="auto: at N = 1 with the default workload also time the other single-GPU configs")
+    ap.add_argument("--configs", default="auto",
+                    help="comma list of: auto (with the default workload: the other single-GPU configs at N = 1, "
+                         "config 5 = 40M Spheroidal3 at N > 1), off, solve (config 3 end to end: 10M thin-plate spline "
+                         "FGMRES + Schwarz, N = 1), extensions (the labelled extensions, N = 1)")
+    ap.add_argument("--config5-points", type=int, default=CONFIG5["points"], help="points of config 5 on the N > 1 line")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"],
                     help="gloo: CPU-staged exchange; ranks may then share a GPU (LOCAL_RANK modulo the device "
                          "count) -- for exercising the N > 1 path on a one-GPU box, never a scaling number")
@@ -92,28 +110,32 @@ def parse():
 # --------------------------------------------------------------------------- N > 1 without a launcher
 def launch_ranks(args) -> int:
     """Parent of a self-launched multi-rank run.  Touches neither torch nor the GPU: it only starts the
-    rank processes (fresh interpreters), relays rank 0's stdout and returns the worst exit code."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
+    rank processes (fresh interpreters), relays rank 0's stdout and returns the worst exit code.  The ranks meet
+    through a file store in a private temporary directory (no port to lose between picking and binding it); every
+    rank's stderr is kept, and the tail of a failing rank's is printed with its id."""
+    import tempfile
+    import threading
+    tmp = tempfile.mkdtemp(prefix="bbfmm_bench_")
+    rdzv = os.path.join(tmp, "rendezvous")
+    procs, errs = [], []
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus),
-                    "LOCAL_WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
+                    "LOCAL_WORLD_SIZE": str(args.gpus), "BBFMM_RDZV_FILE": rdzv,
                     "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        errs.append(open(os.path.join(tmp, f"rank{r}.stderr"), "w+b"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=errs[-1]))
     # relay rank 0's stdout; if any rank dies, stop the others (they would wait in the rendezvous for minutes)
-    import threading
     chunks = []
     reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
     reader.start()
-    rc = 0
+    rc, failed = 0, []
     while True:
         codes = [p.poll() for p in procs]
         if any(c not in (None, 0) for c in codes):
-            rc = max(abs(c) for c in codes if c not in (None, 0))
+            failed = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            rc = max(abs(c) for _, c in failed)
             for p in procs:
                 if p.poll() is None:
                     p.terminate()          # our own children, by handle
@@ -127,6 +149,17 @@ def launch_ranks(args) -> int:
         except subprocess.TimeoutExpired:
             p.kill()
     reader.join(timeout=10)
+    for r, f in enumerate(errs):
+        f.seek(0)
+        text = f.read().decode(errors="replace")
+        f.close()
+        if any(r == fr for fr, _ in failed):
+            sys.stderr.write(f"[bench] rank {r} exited with {dict(failed)[r]}; last lines of its stderr:\n")
+            sys.stderr.write("\n".join(text.splitlines()[-40:]) + "\n")
+        elif r == 0 and text:
+            sys.stderr.write(text)          # rank 0's warnings, as before
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
     sys.stdout.write(b"".join(c for c in chunks if c).decode())
     sys.stdout.flush()
     return rc
@@ -191,10 +224,9 @@ def cpu_baseline(args, kernel_id):
     which has the same leaf occupancy and list structure two levels shallower; the BBFMM matvec
     is O(N), so the rate is scaled by the point ratio.  The sample is run at the host's full thread
     count and at a half and a quarter of it (small problems do not always like every hardware thread);
-    the fastest is reported with its thread count.  Run once at the full 10M points the same code
-    measured 46.9 s per matvec = 0.021 matvecs/s on 256 threads
-    (scripts/cpu_port_full_size.py -> profiles/r02_cpu_port_full_10M.json): the scaled sample flatters the
-    CPU by about 2x (caches), which only makes the reported baseline conservative for the GPU."""
+    the fastest is reported with its thread count.  `value_full_size` is the same code measured once at the
+    full 10M points (46.9 s per matvec on 256 threads): the scaled sample flatters the CPU (caches), which only
+    makes `value` conservative for the GPU."""
     from oracle import bbfmm_oracle as O
     n_cpu = args.cpu_points or max(20000, args.points // 64)
     rng = np.random.default_rng(42)
@@ -221,20 +253,21 @@ def cpu_baseline(args, kernel_id):
     O.lib().oracle_set_num_threads(hw)
     t, threads, reps = best
     scale = n_cpu / float(args.points)
+    full = dict(CPU_PORT_FULL_SIZE) if (args.points, args.kernel, args.order, args.nrhs) == (10_000_000, "LinearRbf", 7, 1) else {}
     return {
         "value": (1.0 / t) * scale,
         "unit": "matvecs/s",
         "cores": threads,
         "kind": "port",
+        **full,
         "sample": (f"CPU restatement of the reference algorithm (not the Rust binary): median of "
                    f"{reps} matvecs on {n_cpu} uniform points ({t:.3f} s each on {threads} of {hw} threads, the "
                    f"fastest of full / half / quarter thread counts; same kernel/order/nrhs, same leaf occupancy as "
-                   f"the {args.points}-point workload), rate scaled by {n_cpu}/{args.points} (O(N) algorithm); "
-                   f"measured once at the full 10M points: 0.021 matvecs/s (profiles/r02_cpu_port_full_10M.json)"),
+                   f"the {args.points}-point workload), rate scaled by {n_cpu}/{args.points} (O(N) algorithm)"),
     }
 
 
-def roofline_of(stats, K, per_launch, world):
+def roofline_of(stats, K, per_launch, world, pair_frac=1.0):
     """Roofline entry of the dominant kernel (largest average launch among the M2L stages and P2P);
     algorithmic work per launch as DESIGN.md section 5 defines it."""
     m2l_stage_flops = stats.m2l_flops_k1 * K / 2.0          # each stage does 2*n*r per pair
@@ -258,17 +291,95 @@ def roofline_of(stats, K, per_launch, world):
     }
 
 
-def time_matvecs(torch, dist, tree, w, out, steps, warmup, world, xchg, stream):
+# Arithmetic of one kernel evaluation in the reference's pair loops (bbfmm.rs:1162-1251 with distance_sq
+# utils.rs:230-237 and the kernels of rbf_kernels.rs): d subtractions, d multiplies, d - 1 additions, the square
+# root, phi, and the multiply-add with the weight -- counted as flops, a transcendental as one.
+PAIR_FLOPS = {"LinearRbf": 3 * 3 - 1 + 1 + 1 + 2, "ThinPlateSplineRbf": 3 * 3 - 1 + 1 + 3 + 2, "CubicRbf": 3 * 3 - 1 + 1 + 2 + 2,
+              "Spheroidal3Rbf": 3 * 3 - 1 + 1 + 6 + 2, "MultiquadricExt": 3 * 3 - 1 + 1 + 2 + 2}
+
+
+def committed_pair_instructions():
+    """FP64 VALU instructions per kernel evaluation of the pair kernels, counted from the ISA of these very sources
+    (scripts/pair_instruction_counts.py -> profiles/r*_pair_instruction_counts.json, stamped with the source hash)."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pair_instruction_counts.json"))):
+        try:
+            with open(f) as fh:
+                j = json.load(fh)
+        except (OSError, ValueError):
+            continue
+        if j.get("source_hash") == source_hash():
+            best = j
+            best["file"] = os.path.relpath(f, ROOT)
+    return best
+
+
+def phase_roofline(stats, N, K, order, kernel, per_step_ms, sym_pairs):
+    """per phase the algorithmic bytes and flops of one matvec, the achieved GB/s and TFLOP/s, the
+    fractions of the HBM (8 TB/s) and FP64 (78.6 TFLOP/s) peaks, and which of the two binds the phase (the larger
+    of bytes / peak-bandwidth and flops / peak-rate).  Bytes: what the phase has to move once (tile traffic for the
+    pair phases, as the north-star defines it); flops: the reference's arithmetic (sum-factorised transfers for
+    M2M / L2L, 4 n r per V pair for M2L).  The pair phases also get their FP64 instruction-issue figure."""
+    n, C, d, p = stats.n_nodes, stats.n_cells, stats.d, order
+    leaves = stats.n_leaves
+    sum_r = stats.m2l_flops_k1 / (4.0 * n)                   # sum of the ranks over all V pairs
+    xfer = 2.0 * d * p ** (d + 1) * max(C - 1, 0) * K
+    pf = PAIR_FLOPS.get(kernel, 14)
+    work = {
+        "gather": (N * K * 16.0 + N * 4.0, 0.0),
+        "P2M": (N * (8.0 * d + 8 * K) + leaves * n * 8.0 * K, (2.0 + d) * N * n * K),
+        "M2M": (2.0 * C * n * 8 * K, xfer),
+        "M2L_stage1": ((C * n * 8.0 + sum_r * 8.0) * K, stats.m2l_flops_k1 * K / 2.0),
+        "M2L_stage2": ((sum_r * 8.0 + C * n * 8.0) * K, stats.m2l_flops_k1 * K / 2.0),
+        "P2L": (float(stats.wx_tile_bytes_k1) * K, float(stats.wx_pairs) * pf * K),
+        "L2L": (2.0 * C * n * 8 * K, xfer),
+        "P2P": (float(stats.p2p_tile_bytes_k1 + (K - 1) * 8 * (stats.p2p_tile_bytes_k1 // 32)), float(stats.p2p_pairs) * pf * K),
+        "M2P": (float(stats.wx_tile_bytes_k1) * K, float(stats.wx_pairs) * pf * K),
+        "L2P": (N * (8.0 * d + 8 * K) + leaves * n * 8.0 * K, (2.0 + d) * N * n * K),
+        "scatter": (N * K * 16.0 + N * 4.0, 0.0),
+    }
+    instr = committed_pair_instructions()
+    out = {}
+    for ph, (nbytes, flops) in work.items():
+        ms = per_step_ms.get(ph, 0.0)
+        if ms <= 0.0:
+            continue
+        if ph in ("P2L", "M2P") and stats.n_w == 0:
+            continue
+        sec = ms * 1e-3
+        t_hbm, t_fp = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (FP64_MFMA_PEAK_TFLOPS * 1e12)
+        e = {"ms": ms, "bytes": nbytes, "flops": flops, "gbps": nbytes / sec * 1e-9, "tflops": flops / sec * 1e-12,
+             "frac_hbm": nbytes / sec * 1e-9 / HBM_PEAK_GBPS, "frac_fp64": flops / sec * 1e-12 / FP64_MFMA_PEAK_TFLOPS,
+             "bound": "hbm" if t_hbm >= t_fp else ("mfma" if ph.startswith("M2L") else "fp64_valu")}
+        # FP64 instruction issue of the pair kernels: kernel evaluations actually executed (every unordered pair once
+        # in the symmetric kernels) x FP64 VALU instructions per evaluation (ISA count) against the issue peak
+        key = {"P2P": "p2p_sym" if sym_pairs else "p2p", "P2L": "wx_sym" if (sym_pairs and K == 1) else "p2l",
+               "M2P": "m2p"}.get(ph)
+        if key and instr and key in instr.get("kernels", {}).get(kernel, {}):
+            ipp = instr["kernels"][kernel][key]["fp64_valu_per_pair"]
+            if ph == "P2P":
+                evals = (stats.p2p_pairs + N) / 2.0 if sym_pairs else float(stats.p2p_pairs)
+            else:
+                evals = float(stats.wx_pairs)            # the fused kernel evaluates each (point, node) pair once for both
+            e["valu_issue"] = {"kernel_evaluations": evals * K, "fp64_valu_instr_per_evaluation": ipp,
+                               "achieved_lane_instr_per_s": evals * K * ipp / sec, "peak_lane_instr_per_s": FP64_VALU_LANE_INSTR_PEAK,
+                               "frac": evals * K * ipp / sec / FP64_VALU_LANE_INSTR_PEAK, "counted_from": instr["file"]}
+        out[ph] = e
+    return out
+
+
+def time_matvecs(torch, dist, tree, w, out, steps, warmup, world, pm, stream):
     """W untimed + exactly K timed steps between barrier + synchronize; returns (seconds, phases, counts)."""
     N, K = w.shape[1], w.shape[0]
 
     def step():
-        # hot path: gather, P2M, M2M, M2L, P2L, L2L, P2P, M2P, L2P, scatter -- all on the handle's stream
-        tree.matvec_device(w.data_ptr(), N, K, out.data_ptr(), N, sync=False)
         if world > 1:
-            # exchange step: owned potentials only (disjoint by construction) -> all-gather
-            with torch.cuda.stream(stream):
-                xchg.exchange(out)
+            # own share of the upward pass, all-reduce of the coarse multipoles, downward + leaf pass of the owned
+            # targets, all-gather of the owned potentials -- all queued on the handle's stream (distributed.py)
+            pm.step(w, out)
+        else:
+            # hot path: gather, P2M, M2M, M2L, P2L, L2L, P2P, M2P, L2P, scatter -- all on the handle's stream
+            tree.matvec_device(w.data_ptr(), N, K, out.data_ptr(), N, sync=False)
 
     def sync():
         torch.cuda.synchronize()
@@ -295,8 +406,19 @@ def time_matvecs(torch, dist, tree, w, out, steps, warmup, world, xchg, stream):
     return elapsed, phases, counts
 
 
-def run_extra_config(torch, F, dev, cfg, tree=None):
-    """One of EXTRA_CONFIGS on one GPU: step time, phases, dominant-kernel roofline, sampled dense rows."""
+def dense_rows_err(torch, dev, cfg_kernel, br, sill, pts, w, out, rows=32):
+    idx = np.random.default_rng(2).choice(pts.shape[0], rows, replace=False)
+    pts_d = torch.from_numpy(pts).to(dev)
+    yd = dense_rows_torch(torch, cfg_kernel, br, sill, pts_d[idx], pts_d, w)
+    del pts_d
+    if yd is None:
+        return None
+    return float((out[:, idx].T - yd).abs().max() / yd.abs().max())
+
+
+def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None):
+    """One configuration beside the headline: step time, phases, rooflines, sampled dense rows.  world > 1: the
+    same partitioned step as the headline (every rank calls this; rank 0 reports)."""
     N, K = cfg["points"], cfg["nrhs"]
     pts = np.random.default_rng(42).random((N, 3))
     t0 = time.time()
@@ -310,19 +432,25 @@ def run_extra_config(torch, F, dev, cfg, tree=None):
     w = torch.from_numpy(np.random.default_rng(43).random((K, N))).to(dev)
     out = torch.zeros((K, N), dtype=torch.float64, device=dev)
     stream = torch.cuda.ExternalStream(tree.stream(), device=dev)
+    pm = None
+    if world > 1:
+        from ferreus_rbf_rs_amd.distributed import PartitionedMatvec
+        tree.set_partition(rank, world)
+        pm = PartitionedMatvec(tree, N, K, dev)
+        assert pm.check_partition(), "partition does not cover the targets exactly once"
     steps = 5 if N * K <= 10_000_000 else 3
-    elapsed, phases, counts = time_matvecs(torch, None, tree, w, out, steps, 1, 1, None, stream)
+    elapsed, phases, counts = time_matvecs(torch, dist, tree, w, out, steps, 1, world, pm, stream)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if exchange == "rccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank != 0:
+        return None
     # a phase interval brackets all launches of the phase (rhs chunks, column chunks): per interval = per pass
     per_step = {k: (phases[k] / counts[k] if counts[k] else 0.0) for k in phases}
-    _, roof = roofline_of(stats, K, per_step, 1)
-    idx = np.random.default_rng(2).choice(N, 32, replace=False)
-    pts_d = torch.from_numpy(pts).to(dev)
-    err = None
-    yd = dense_rows_torch(torch, cfg["kernel"], cfg["base_range"], cfg["total_sill"], pts_d[idx], pts_d, w)
-    if yd is not None:
-        got = out[:, idx].T
-        err = float((got - yd).abs().max() / yd.abs().max())
-    del pts_d
+    per_step_total = {k: phases[k] / steps for k in phases}
+    _, roof = roofline_of(stats, K, per_step, world)
+    err = dense_rows_err(torch, dev, cfg["kernel"], cfg["base_range"], cfg["total_sill"], pts, w, out)
     ext = {}
     if cfg.get("direct_small_w_leaves"):
         ext = {"extension": "BBFMM_FLAG_DIRECT_SMALL_W_LEAVES (W-list leaves with no more points than nodes summed directly: "
@@ -330,15 +458,60 @@ def run_extra_config(torch, F, dev, cfg, tree=None):
     if cfg.get("m2l_shared_basis"):
         ext = {"extension": "BBFMM_FLAG_M2L_SHARED_BASIS (not the reference's M2L arithmetic; results within a few epsilon "
                             "of the default path)", "m2l_basis_rank": stats.m2l_basis_rank, "m2l_basis_len": stats.m2l_basis_len}
-    return {
+    res = {
         **ext,
         "workload": f"{N} uniform 3D points, {cfg['kernel']}, order {cfg['order']}, {K} rhs",
+        "n_gpus": world,
         "ms_per_step": elapsed / steps * 1e3, "matvecs_per_s": steps / elapsed, "steps": steps,
-        "roofline": roof, "phase_ms_per_step": per_step,
+        "roofline": roof, "phase_ms_per_step": per_step_total,
         "dense_rows_rel_err": err, "dense_rows": 32,
         "tree": {"depth": stats.depth, "cells": stats.n_cells, "leaves": stats.n_leaves, "v_pairs": stats.n_v,
                  "n_w": stats.n_w, "p2p_pairs": stats.p2p_pairs, "build_s": t_build},
     }
+    if world == 1 and not ext:
+        res["phase_roofline"] = phase_roofline(stats, N, K, cfg["order"], cfg["kernel"], per_step_total, sym_pairs=K == 1)
+    return res
+
+
+def run_config3_solve(F, points=10_000_000):
+    """BASELINE.json config 3 end to end (opt-in, `--configs solve`): thin-plate spline, order 9, linear drift, smooth
+    values, FGMRES 20 x 5 to 1e-6 relative, right-preconditioned by the multi-level Schwarz sweep -- with
+    DDMParams.for_points (the extension that keeps three fine levels; it converges) and with the reference's default
+    DDMParams (config.rs:60-69; it stagnates at this size, DESIGN.md section 9: the flag records that)."""
+    from ferreus_rbf_rs_amd import solvers as S
+    from ferreus_rbf_rs_amd.ddm import DDMParams, InterpolantSettings, SchwarzPreconditioner
+    n = points
+    rng = np.random.default_rng(42)
+    pts = rng.random((n, 3))
+    vals = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.5 * pts[:, 2] ** 2
+    t0 = time.time()
+    tree = F.FmmTree(pts, 9, F.KernelParams(F.KernelType["ThinPlateSplineRbf"]), True, True)
+    t_tree = time.time() - t0
+    st = InterpolantSettings(1, 3, nugget=0.0)
+    rhs = np.concatenate([vals, np.zeros(st.basis_size)])
+    out = {"workload": f"{n} uniform 3D points, ThinPlateSplineRbf, order 9, linear drift, FGMRES 20 x 5 + Schwarz, "
+                       "tolerance 1e-6 relative", "fmm_tree_build_s": t_tree}
+    for label, params, max_outer in (("for_points", DDMParams.for_points(n), 20), ("reference_defaults", DDMParams(), 4)):
+        t0 = time.time()
+        pre = SchwarzPreconditioner(tree, pts, st, params)
+        t_ddm = time.time() - t0
+        op = S.RbfSystemOperator(tree, st.basis_size, pre.monomial_matrix, 0.0)
+        t0 = time.time()
+        x, hist = S.fgmres(op, rhs, pre, None, max_outer, 5, S.FittingAccuracy(1e-6))
+        t_solve = time.time() - t0
+        res = [r for _, r in hist]
+        converged = bool(res and res[-1] <= 1e-6)
+        idx = rng.choice(n, 2000, replace=False)
+        fit = float(np.abs(op(x)[idx] - vals[idx]).max())
+        out[label] = {"ddm_params": {"leaf_threshold": params.leaf_threshold, "overlap_quota": params.overlap_quota,
+                                     "coarse_ratio": params.coarse_ratio, "coarse_threshold": params.coarse_threshold},
+                      "levels": pre.num_levels, "setup_s": t_ddm, "solve_s": t_solve, "iterations": len(hist),
+                      "converged": converged,
+                      "stagnated": bool(len(res) >= 10 and res[-1] > 0.5 * res[-6]),
+                      "max_outer_iterations": max_outer,
+                      "residual_history": [float("%.3e" % r) for r in res], "max_fit_error_on_sample": fit}
+        del pre, op
+    return out
 
 
 def main():
@@ -346,26 +519,33 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))        # nothing has touched the GPU in this process
 
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:  # every rank builds the whole tree: share the host cores instead of 8 x 64 setup threads
+        os.environ.setdefault("BBFMM_HOST_THREADS", str(max(4, (os.cpu_count() or 8) // world)))
+
+    import torch
+    import torch.distributed as dist
+
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # self-launched ranks meet through a file store; under torch.distributed.run the environment names the master
+        rdzv = os.environ.get("BBFMM_RDZV_FILE")
+        how = {"init_method": f"file://{rdzv}", "rank": rank, "world_size": world} if rdzv else {}
         if args.exchange == "gloo":
             torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **how)
         else:
             torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **how)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
     import ferreus_rbf_rs_amd as F
     kernel_id = int(F.KernelType[args.kernel])
+    want = {c.strip() for c in args.configs.split(",") if c.strip()}
 
     N, K = args.points, args.nrhs
     # synthetic inputs: i.i.d. uniform [0,1)^3 points, uniform [0,1) weights
@@ -375,20 +555,19 @@ def main():
                                                      total_sill=args.total_sill), True, True)
     t_build = time.time() - t0
     stats = tree.stats()
-    tree.set_partition(rank, world)
-    rows = tree.partition_rows()
 
     w = torch.from_numpy(np.random.default_rng(43).random((K, N))).to(dev)   # K x N, rhs-major
     out = torch.zeros((K, N), dtype=torch.float64, device=dev)
 
-    xchg = None
+    pm = None
     if world > 1:
-        from ferreus_rbf_rs_amd.distributed import OwnedRowsExchange
-        xchg = OwnedRowsExchange(rows, N, K, dev)     # owned rows are a disjoint cover: all-gather
-        assert xchg.check_partition(), "partition does not cover the targets exactly once"
+        from ferreus_rbf_rs_amd.distributed import PartitionedMatvec
+        tree.set_partition(rank, world)
+        pm = PartitionedMatvec(tree, N, K, dev)   # all-reduce of the coarse multipoles + all-gather of the owned rows
+        assert pm.check_partition(), "partition does not cover the targets exactly once"
 
     stream = torch.cuda.ExternalStream(tree.stream(), device=dev)
-    elapsed, phases, counts = time_matvecs(torch, dist, tree, w, out, args.steps, args.warmup, world, xchg, stream)
+    elapsed, phases, counts = time_matvecs(torch, dist, tree, w, out, args.steps, args.warmup, world, pm, stream)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.exchange == "rccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -396,7 +575,9 @@ def main():
 
     ms_per_step = elapsed / args.steps * 1e3
     value = args.steps / elapsed                     # whole-job matvecs/s (one matvec spans all ranks)
+    default_workload = (N, args.kernel, args.order, K) == (10_000_000, "LinearRbf", 7, 1)
 
+    line = None
     if rank == 0:
         per_launch = {k: (phases[k] / counts[k] if counts[k] else 0.0) for k in phases}
         n = stats.n_nodes
@@ -424,8 +605,9 @@ def main():
                                    f"{K} rhs, adaptive sparse tree, ACA eps=1e-{args.order}, "
                                    "set_weights + evaluate at the sources",
                        "points": N, "kernel": args.kernel, "order": args.order, "nrhs": K,
-                       "parallelism": (f"target-subtree partition x{world}, owned potentials all-gathered over "
-                                       f"{args.exchange}") if world > 1 else "single GPU"},
+                       "parallelism": (f"target-subtree partition x{world}: own-subtree upward pass + all-reduce of "
+                                       f"{pm.count * 8 * K / 1e6:.1f} MB of coarse multipoles, owned potentials all-gathered, "
+                                       f"over {args.exchange}") if world > 1 else "single GPU"},
             "roofline": roofline,
             "achieved_hbm_gbps_compulsory": compulsory_bytes / (elapsed / args.steps) * 1e-9,
             "phase_ms_per_step": {k: phases[k] / args.steps for k in phases},
@@ -435,37 +617,61 @@ def main():
             "source_hash": source_hash(),
         }
         if world == 1:
-            idx = np.random.default_rng(2).choice(N, 32, replace=False)
-            pts_d = torch.from_numpy(pts).to(dev)
-            yd = dense_rows_torch(torch, args.kernel, args.base_range, args.total_sill, pts_d[idx], pts_d, w)
-            if yd is not None:
-                line["dense_rows_rel_err"] = float((out[:, idx].T - yd).abs().max() / yd.abs().max())
-            del pts_d
+            line["phase_roofline"] = phase_roofline(stats, N, K, args.order, args.kernel, line["phase_ms_per_step"],
+                                                    sym_pairs=K == 1)
+        # the result every rank now holds, against 32 rows of the dense sum (plain torch on rank 0) -- at every world size
+        line["dense_rows_rel_err"] = dense_rows_err(torch, dev, args.kernel, args.base_range, args.total_sill, pts, w, out)
+        line["dense_rows"] = 32
+        if world == 1:
             try:
                 tf, errs = F.mfma_f64_selftest()
                 line["fp64_mfma_microbench_tflops"] = tf
             except Exception:  # noqa: BLE001
                 line["fp64_mfma_microbench_tflops"] = None
-            default_workload = (N, args.kernel, args.order, K) == (10_000_000, "LinearRbf", 7, 1)
-            if args.configs == "auto" and default_workload:
-                extra = {}
-                # configs on the headline tree first (more rhs), then the tree is released for the others
-                ordered = sorted(EXTRA_CONFIGS, key=lambda c: (c["points"], c["kernel"], c["order"]) != (N, args.kernel, args.order))
-                for cfg in ordered:
-                    reuse = tree if (cfg["points"], cfg["kernel"], cfg["order"]) == (N, args.kernel, args.order) and \
-                        not cfg["name"].startswith("extension_") else None
-                    if reuse is None and tree is not None:
-                        del tree, w, out, stream
-                        tree = w = out = stream = None
-                        torch.cuda.empty_cache()
-                    try:
-                        extra[cfg["name"]] = run_extra_config(torch, F, dev, cfg, reuse)
-                    except Exception as e:  # noqa: BLE001
-                        extra[cfg["name"]] = {"error": f"{type(e).__name__}: {e}"}
-                    torch.cuda.empty_cache()
-                line["configs"] = extra
-            if args.cpu_baseline != "off":
-                line["cpu_baseline"] = cpu_baseline(args, kernel_id)
+
+    extra = {}
+    if world == 1 and default_workload and want & {"auto", "extensions", "solve"}:
+        todo = (EXTRA_CONFIGS if "auto" in want else []) + (EXTENSION_CONFIGS if "extensions" in want else [])
+        # configs on the headline tree first (more rhs), then the tree is released for the others
+        ordered = sorted(todo, key=lambda c: (c["points"], c["kernel"], c["order"]) != (N, args.kernel, args.order))
+        for cfg in ordered:
+            reuse = tree if (cfg["points"], cfg["kernel"], cfg["order"]) == (N, args.kernel, args.order) and \
+                not cfg["name"].startswith("extension_") else None
+            if reuse is None and tree is not None:
+                del tree, w, out, stream
+                tree = w = out = stream = None
+                torch.cuda.empty_cache()
+            try:
+                extra[cfg["name"]] = run_config(torch, dist, F, dev, cfg, 1, 0, args.exchange, reuse)
+            except Exception as e:  # noqa: BLE001
+                extra[cfg["name"]] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+        if "solve" in want:
+            if tree is not None:
+                del tree, w, out, stream
+                tree = w = out = stream = None
+                torch.cuda.empty_cache()
+            try:
+                extra["config3_solve_tps_10M_fgmres_schwarz"] = run_config3_solve(F)
+            except Exception as e:  # noqa: BLE001
+                extra["config3_solve_tps_10M_fgmres_schwarz"] = {"error": f"{type(e).__name__}: {e}"}
+    elif world > 1 and default_workload and "auto" in want:
+        # config 5 (40M Spheroidal3) partitioned over the same ranks; every rank takes part
+        del tree, w, out, stream, pm
+        tree = w = out = stream = pm = None
+        torch.cuda.empty_cache()
+        cfg = dict(CONFIG5, points=args.config5_points)
+        try:
+            res = run_config(torch, dist, F, dev, cfg, world, rank, args.exchange)
+        except Exception as e:  # noqa: BLE001
+            res = {"error": f"{type(e).__name__}: {e}"}
+        if rank == 0:
+            extra[cfg["name"]] = res
+    if rank == 0:
+        if extra:
+            line["configs"] = extra
+        if world == 1 and args.cpu_baseline != "off":
+            line["cpu_baseline"] = cpu_baseline(args, kernel_id)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -16,6 +16,7 @@ OK, POINT_OUTSIDE_TREE, KERNEL_NO_GRADIENTS, BAD_ARGUMENT, DEVICE_ERROR, UNSUPPO
 FLAG_HOST_ONLY = 1
 FLAG_M2L_SHARED_BASIS = 2  # extension beyond the reference: M2L stages in one basis per level
 FLAG_DIRECT_SMALL_W_LEAVES = 4  # extension beyond the reference: small W-list leaves as near field
+FLAG_DETERMINISTIC = 8  # fixed summation order everywhere (no f64 atomics): bitwise reproducible results
 N_PHASES = 11
 PHASE_NAMES = ["gather", "P2M", "M2M", "M2L_stage1", "M2L_stage2", "P2L", "L2L", "P2P", "M2P",
                "L2P", "scatter"]
@@ -68,6 +69,10 @@ SIGNATURES = {
     "bbfmm_set_partition": (ctypes.c_int, [c_p, c_i32, c_i32]),
     "bbfmm_partition_row_count": (c_i64, [c_p]),
     "bbfmm_partition_rows": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_partition_coarse_count": (c_i64, [c_p]),
+    "bbfmm_matvec_partition_upward": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p]),
+    "bbfmm_matvec_partition_finish": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i32]),
+    "bbfmm_debug_partition_upward_counts": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     "bbfmm_get_tree_stats": (ctypes.c_int, [c_p, c_p]),
     "bbfmm_tree_built_on_device": (ctypes.c_int, [c_p]),
     "bbfmm_get_cells": (ctypes.c_int, [c_p, c_p, c_p]),

@@ -54,19 +54,35 @@ def _write_stamp(target: str, stamp: str, digest: str) -> None:
         f.write(digest + " " + _file_digest(target))
 
 
+_COMPILER_ID = None
+
+
+def _compiler_id(hipcc: str) -> str:
+    """`hipcc --version` (a toolchain upgrade invalidates the objects; the path of the checkout does not)."""
+    global _COMPILER_ID
+    if _COMPILER_ID is None:
+        try:
+            _COMPILER_ID = subprocess.run([hipcc, "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                          timeout=120).stdout.decode(errors="replace")
+        except (OSError, subprocess.SubprocessError):
+            _COMPILER_ID = "unknown"
+    return _COMPILER_ID
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
-    common = ["-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-I", os.path.join(ROOT, "include"),
-              "-Wall", "-Wno-unused-result"]
+    flags = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "--offload-arch=gfx950"]  # path-independent
+    common = flags[:-1] + ["-I", CSRC, "-I", os.path.join(ROOT, "include")]
+    flag_id = " ".join(flags) + "\n" + _compiler_id(hipcc)
     objs, digests, todo = [], [], []
     for src in HOST_SOURCES + HIP_SOURCES:
         path = os.path.join(CSRC, src)
         obj = os.path.join(OBJ, src + ".o")
         stamp = obj + ".sha256"
         cmd = [hipcc] + common + ["--offload-arch=gfx950", "-c", path, "-o", obj]
-        digest = _digest([path] + hdrs, " ".join(cmd[1:-3]))
+        digest = _digest([path] + hdrs, flag_id)  # file names + contents, flags, compiler: nothing about where the tree lies
         objs.append(obj)
         digests.append(digest)
         if force or _stale(obj, stamp, digest):

@@ -189,6 +189,23 @@ int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out) {
     return BBFMM_OK;
 }
 
+int64_t bbfmm_partition_coarse_count(const bbfmm_handle *h) { return h ? h->tree.partition_coarse_count() : -1; }
+
+int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse) {
+    GUARD(h) return h->tree.matvec_partition_upward(d_w, ldw, k, d_coarse);
+    END_GUARD(h)
+}
+
+int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync) {
+    GUARD(h) return h->tree.matvec_partition_finish(d_coarse, d_out, ldo, sync != 0);
+    END_GUARD(h)
+}
+
+int bbfmm_debug_partition_upward_counts(const bbfmm_handle *h, int64_t *counts_out, uint8_t *reads_out, int64_t *info_out) {
+    if (!h || !counts_out || !reads_out || !info_out) return BBFMM_BAD_ARGUMENT;
+    return h->tree.debug_partition_upward_counts(counts_out, reads_out, info_out);
+}
+
 int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out) {
     if (!h || !out) return BBFMM_BAD_ARGUMENT;
     h->tree.stats(out);

@@ -8,6 +8,7 @@
 #include <type_traits>
 
 #include "ddm_solver.hpp"
+#include "ferreus_bbfmm_hip.h"
 
 namespace bbfmm {
 namespace {
@@ -667,8 +668,10 @@ void launch_ddm_unpack_symmetric(const double *packed, int m, double *full, hipS
     if (m > 0) hipLaunchKernelGGL(unpack_symmetric_kernel, dim3(m), dim3(256), 0, s, packed, m, full);
 }
 
-void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s) {
-    if (lv.n_dom == 0) return;
+// Returns BBFMM_OK, or the error of the pivoted-LU fallback (rocSOLVER) -- the scatter is then skipped, so that an
+// unsolved right-hand side never reaches the correction.
+int launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s) {
+    if (lv.n_dom == 0) return BBFMM_OK;
     if (ddm_level_is_big(lv)) { // one large domain: work = [d_s | y] (n), z (m), gamma (m)
         const View v = make_view(lv);
         const int n = static_cast<int>(lv.n_entries), k = lv.k[0], m = n - k;
@@ -677,8 +680,10 @@ void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *
         hipLaunchKernelGGL(big_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, d_values, n);
         if (k) hipLaunchKernelGGL(big_rhs_kernel, dim3((m + 255) / 256), dim3(256), 0, s, v, k, m);
         if (lv.d_lu) { // not positive definite: pivoted LU of the full matrix (the reference's LBL^T role)
-            (void)hipMemcpyAsync(g, y, static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToDevice, s);
-            (void)big_lu_solve(lv, g, s);
+            if (hipMemcpyAsync(g, y, static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                return BBFMM_DEVICE_ERROR;
+            const int lrc = big_lu_solve(lv, g, s);
+            if (lrc != BBFMM_OK) return lrc;
         } else {
             for (int jb = 0; jb < m; jb += SB) {
                 const int rest = m - jb - std::min(SB, m - jb);
@@ -689,10 +694,11 @@ void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *
         }
         if (k) hipLaunchKernelGGL(big_special_kernel, dim3(k), dim3(256), 0, s, v, m, g);
         hipLaunchKernelGGL(big_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, n, k, g, d_out, all_points ? 1 : 0);
-        return;
+        return BBFMM_OK;
     }
     hipLaunchKernelGGL(ddm_solve_kernel, dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, make_view(lv), d_values,
                        d_out, all_points ? 1 : 0);
+    return BBFMM_OK;
 }
 
 } // namespace bbfmm

@@ -333,9 +333,15 @@ int big_lu_factor(DdmLevelSolver *lv, hipStream_t s) {
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_lu), static_cast<size_t>(m) * m * sizeof(double)));
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_ipiv), (static_cast<size_t>(m) + 1) * sizeof(int)));
     launch_ddm_unpack_symmetric(lv->d_fac, m, lv->d_lu, s);
-    if (api.create_handle(&lv->lu_handle) != 0 || api.set_stream(lv->lu_handle, s) != 0) return BBFMM_DEVICE_ERROR;
+    if (api.create_handle(&lv->lu_handle) != 0) {
+        lv->lu_handle = nullptr;
+        return BBFMM_DEVICE_ERROR;
+    }
     int *d_info = lv->d_ipiv + m;
-    if (api.dgetrf(lv->lu_handle, m, m, lv->d_lu, m, lv->d_ipiv, d_info) != 0) return BBFMM_DEVICE_ERROR;
+    if (api.set_stream(lv->lu_handle, s) != 0 || api.dgetrf(lv->lu_handle, m, m, lv->d_lu, m, lv->d_ipiv, d_info) != 0) {
+        big_lu_release(lv);
+        return BBFMM_DEVICE_ERROR;
+    }
     int info = 0;
     DHIP(hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, s));
     DHIP(hipStreamSynchronize(s));
@@ -500,7 +506,8 @@ void ddm_level_free(DdmLevelSolver *lv) {
 }
 
 int ddm_level_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s) {
-    launch_ddm_solve(lv, d_values, d_out, all_points, s);
+    const int rc = launch_ddm_solve(lv, d_values, d_out, all_points, s);
+    if (rc != BBFMM_OK) return rc;
     return hipGetLastError() == hipSuccess ? BBFMM_OK : BBFMM_DEVICE_ERROR;
 }
 

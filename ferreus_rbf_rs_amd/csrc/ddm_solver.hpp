@@ -74,7 +74,7 @@ int ddm_level_solve(const DdmLevelSolver &lv, const double *d_values, double *d_
 void launch_ddm_prep(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s);
 void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s);
 void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s);
-void launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s);
+int launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s);
 // packed lower triangle (column by column) -> full symmetric m x m column-major
 void launch_ddm_unpack_symmetric(const double *packed, int m, double *full, hipStream_t s);
 // gamma = (Q^T A Q)^-1 y through the LU factors of a large domain (y, gamma: m doubles on the device, in place)

@@ -11,6 +11,8 @@
 //   P2P/M2P/P2L     direct kernel evaluation, LDS-tiled sources, lanes = target x slice
 #include "device.hpp"
 
+#include <atomic>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -151,11 +153,13 @@ __device__ inline void cheb_S_reg(double x, const double *__restrict__ polyn, do
 // LDS slice; then lane q owns the node pairs (i1, i2) = q and keeps the P sums over i0 in
 // registers, so a point costs two private LDS reads plus P broadcast reads per lane.
 constexpr int P2M_WAVES = 4;
+// 3-D orders above 12 (they work, slowly: bbfmm.rs:77-104 takes any order): two waves per workgroup
+template <int P, int D> constexpr int p2m_waves() { return D == 3 && P > 12 ? 2 : P2M_WAVES; }
 constexpr int P2M_PTS = 64; // measured at 10M points, K = 1: 1.12 ms against 1.38 ms with 32
                             // (one batch covers a 38-point leaf) and 1.55 ms with two rhs slots
 
 template <int P, int D, int P2M_KB>
-__global__ __launch_bounds__(64 * P2M_WAVES) void p2m_kernel(const DevCheb *__restrict__ chp, int n_leaves, Xyz src,
+__global__ __launch_bounds__((64 * p2m_waves<P, D>())) void p2m_kernel(const DevCheb *__restrict__ chp, int n_leaves, Xyz src,
                                                              const double *__restrict__ ws, int64_t N, int K,
                                                              int64_t C, const int32_t *__restrict__ leaf_cells,
                                                              const int32_t *__restrict__ pt_begin,
@@ -167,11 +171,12 @@ __global__ __launch_bounds__(64 * P2M_WAVES) void p2m_kernel(const DevCheb *__re
     constexpr int NPASS = (NPAIR + 63) / 64;
     constexpr int SROW = 3 * P + P2M_KB; // per point: S0[P], S1[P], S2[P], w[KB]
     __shared__ double s_polyn[P * P];
-    __shared__ double s_pts[P2M_WAVES][P2M_PTS][SROW];
+    constexpr int WAVES = p2m_waves<P, D>();
+    __shared__ double s_pts[WAVES][P2M_PTS][SROW];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < P * P; i += 64 * P2M_WAVES) s_polyn[i] = chp->polyn[i];
+    for (int i = tid; i < P * P; i += 64 * WAVES) s_polyn[i] = chp->polyn[i];
     __syncthreads();
-    const int job = blockIdx.x * P2M_WAVES + wave;
+    const int job = blockIdx.x * WAVES + wave;
     if (job >= n_leaves) return; // whole wave; no block barrier below
     const int n_pad = chp->n_pad;
     const int cell = leaf_cells[job];
@@ -487,9 +492,10 @@ __global__ __launch_bounds__(512) void m2m3_kernel(const DevCheb *__restrict__ c
 // (dS scaled by 2/length, chebyshev.rs:862-869).  One wave per leaf, one lane per target; the
 // 1-D factors live in registers (order P is a template parameter), L_leaf is broadcast from LDS.
 constexpr int L2P_WAVES = 4;
+template <int P, int D> constexpr int l2p_waves() { return D == 3 && P > 12 ? (P > 14 ? 1 : 2) : L2P_WAVES; } // P^3 doubles of LDS per wave
 
 template <int P, int D, bool GRAD>
-__global__ __launch_bounds__(64 * L2P_WAVES) void l2p_kernel(const DevCheb *__restrict__ chp, int n_jobs,
+__global__ __launch_bounds__((64 * l2p_waves<P, D>())) void l2p_kernel(const DevCheb *__restrict__ chp, int n_jobs,
                                                              const int32_t *__restrict__ leaf_cells,
                                                              const int32_t *__restrict__ tgt_begin,
                                                              const int32_t *__restrict__ tgt_end,
@@ -500,11 +506,12 @@ __global__ __launch_bounds__(64 * L2P_WAVES) void l2p_kernel(const DevCheb *__re
                                                              double *__restrict__ out, double *__restrict__ grad) {
     constexpr int P1 = D > 1 ? P : 1, P2 = D > 2 ? P : 1, N = P * P1 * P2;
     __shared__ double s_polyn[P * P];
-    __shared__ double s_L[L2P_WAVES][N];
+    constexpr int WAVES = l2p_waves<P, D>();
+    __shared__ double s_L[WAVES][N];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < P * P; i += 64 * L2P_WAVES) s_polyn[i] = chp->polyn[i];
+    for (int i = tid; i < P * P; i += 64 * WAVES) s_polyn[i] = chp->polyn[i];
     __syncthreads();
-    const int job = blockIdx.x * L2P_WAVES + wave;
+    const int job = blockIdx.x * WAVES + wave;
     if (job >= n_jobs) return; // whole wave; no block barrier below
     const int n_pad = chp->n_pad;
     const int cell = leaf_cells[job];
@@ -1474,16 +1481,24 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
 // ------------------------------------------------------------------ launch helpers
 static Xyz make_xyz(const double *const *p) { return Xyz{p[0], p[1], p[2]}; }
 
+// Dynamic LDS above the 64 KB default needs the function attribute, per device (3-D orders 14-16 of the general
+// M2M / L2L kernels).  Called from launchers only; cheap when nothing is to do.
+static void allow_large_dynamic_lds(const void *fn, size_t bytes) {
+    if (bytes <= 64 * 1024) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
 template <int P, int D>
 static void p2m_launch_pd(const ChebRef &ch, Xyz src, const double *w_sorted, int64_t N, int K, int64_t C,
                           const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin, const int32_t *pt_end,
                           const double *centers, const double *lengths, double *M, hipStream_t s) {
-    const int blocks = (n_leaves + P2M_WAVES - 1) / P2M_WAVES;
-    if (K == 1)
-        hipLaunchKernelGGL((p2m_kernel<P, D, 1>), dim3(blocks), dim3(64 * P2M_WAVES), 0, s, ch.dev, n_leaves, src,
+    constexpr int WAVES = p2m_waves<P, D>();
+    const int blocks = (n_leaves + WAVES - 1) / WAVES;
+    if (K == 1 || (D == 3 && P > 12)) // (two rhs slots at orders above 12 would spill: one rhs per pass there)
+        hipLaunchKernelGGL((p2m_kernel<P, D, 1>), dim3(blocks), dim3(64 * WAVES), 0, s, ch.dev, n_leaves, src,
                            w_sorted, N, K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
     else
-        hipLaunchKernelGGL((p2m_kernel<P, D, 2>), dim3(blocks), dim3(64 * P2M_WAVES), 0, s, ch.dev, n_leaves, src,
+        hipLaunchKernelGGL((p2m_kernel<P, D, 2>), dim3(blocks), dim3(64 * WAVES), 0, s, ch.dev, n_leaves, src,
                            w_sorted, N, K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
 }
 
@@ -1495,9 +1510,8 @@ void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w
 #define P2M_CASE(PP)                                                                                               \
     case PP:                                                                                                       \
         if (ch.d == 3) {                                                                                           \
-            if constexpr (PP <= 12)                                                                                \
-                p2m_launch_pd<PP, 3>(ch, src, w_sorted, N, K, C, leaf_cells, n_leaves, pt_begin, pt_end, centers,  \
-                                     lengths, M, s);                                                               \
+            p2m_launch_pd<PP, 3>(ch, src, w_sorted, N, K, C, leaf_cells, n_leaves, pt_begin, pt_end, centers,      \
+                                 lengths, M, s);                                                                   \
         } else if (ch.d == 2) {                                                                                    \
             p2m_launch_pd<PP, 2>(ch, src, w_sorted, N, K, C, leaf_cells, n_leaves, pt_begin, pt_end, centers,      \
                                  lengths, M, s);                                                                   \
@@ -1529,6 +1543,7 @@ void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int
         }
 #undef M2M3_CASE
     const size_t lds = sizeof(double) * (3 * (size_t)ch.n + 2 * ch.p * ch.p);
+    allow_large_dynamic_lds(reinterpret_cast<const void *>(&m2m_kernel), lds);
     hipLaunchKernelGGL(m2m_kernel, dim3(n_parents), dim3(256), lds, s, ch.dev, K, C, parents, child_ptr, child_idx,
                        octant, M);
 }
@@ -1548,6 +1563,7 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
         }
 #undef L2L3_CASE
     const size_t lds = sizeof(double) * (2 * (size_t)ch.n + 2 * ch.p * ch.p);
+    allow_large_dynamic_lds(reinterpret_cast<const void *>(&l2l_kernel), lds);
     hipLaunchKernelGGL(l2l_kernel, dim3(n_cells), dim3(256), lds, s, ch.dev, K, C, cells, parent, octant, active, L);
 }
 
@@ -1556,13 +1572,14 @@ static void l2p_launch_pd(const ChebRef &ch, int n_jobs, const int32_t *leaf_cel
                           const int32_t *tgt_end, const double *centers, const double *lengths, Xyz tgt,
                           int64_t n_tgt, int K, int64_t C, const double *L, double *out_sorted, double *grad_sorted,
                           hipStream_t s) {
-    const int blocks = (n_jobs + L2P_WAVES - 1) / L2P_WAVES;
+    constexpr int WAVES = l2p_waves<P, D>();
+    const int blocks = (n_jobs + WAVES - 1) / WAVES;
     if (grad_sorted)
-        hipLaunchKernelGGL((l2p_kernel<P, D, true>), dim3(blocks), dim3(64 * L2P_WAVES), 0, s, ch.dev, n_jobs,
+        hipLaunchKernelGGL((l2p_kernel<P, D, true>), dim3(blocks), dim3(64 * WAVES), 0, s, ch.dev, n_jobs,
                            leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted,
                            grad_sorted);
     else
-        hipLaunchKernelGGL((l2p_kernel<P, D, false>), dim3(blocks), dim3(64 * L2P_WAVES), 0, s, ch.dev, n_jobs,
+        hipLaunchKernelGGL((l2p_kernel<P, D, false>), dim3(blocks), dim3(64 * WAVES), 0, s, ch.dev, n_jobs,
                            leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted,
                            grad_sorted);
 }
@@ -1572,8 +1589,7 @@ static void l2p_launch_p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cell
                          const int32_t *tgt_end, const double *centers, const double *lengths, Xyz tgt, int64_t n_tgt,
                          int K, int64_t C, const double *L, double *out_sorted, double *grad_sorted, hipStream_t s) {
     if (ch.d == 3) {
-        if constexpr (P <= 12) // P^3 doubles per wave must fit the static LDS budget
-            l2p_launch_pd<P, 3>(ch, n_jobs, leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted, grad_sorted, s);
+        l2p_launch_pd<P, 3>(ch, n_jobs, leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted, grad_sorted, s);
     } else if (ch.d == 2) {
         l2p_launch_pd<P, 2>(ch, n_jobs, leaf_cells, tgt_begin, tgt_end, centers, lengths, tgt, n_tgt, K, C, L, out_sorted, grad_sorted, s);
     } else {
@@ -1581,7 +1597,7 @@ static void l2p_launch_p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cell
     }
 }
 
-bool l2p_order_supported(int p, int d) { return p >= 2 && p <= kMaxOrder && (d < 3 || p <= 12); }
+bool l2p_order_supported(int p, int d) { return p >= 2 && p <= kMaxOrder && d >= 1 && d <= 3; }
 
 void launch_l2p(const ChebRef &ch, int n_jobs, const int32_t *leaf_cells, const int32_t *tgt_begin,
                 const int32_t *tgt_end, const double *centers, const double *lengths, const double *const *tgt_xyz,
@@ -1729,11 +1745,15 @@ static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, i
                             int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
                             int64_t out_len, const uint16_t *qlist, int slot_t, const int32_t *tile_idx, hipStream_t s) {
     const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 128 + 8 * 16 * slot_t) * 4 : 0); // + aux, cell and slot tables
-    static bool attr_set = false;
-    if (!attr_set) {
+    // function attributes are per device: one flag per (template instance, device), set from whichever thread
+    // launches there first (handles are bound to their device and may be used from any host thread)
+    static std::atomic<uint64_t> attr_set[4] = {{0}, {0}, {0}, {0}};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 256 || !((attr_set[dev >> 6].load(std::memory_order_acquire) >> (dev & 63)) & 1)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&m2l_gemm_k4<NG16, STAGE, MINW>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+        if (dev >= 0 && dev < 256) attr_set[dev >> 6].fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
     const int zdim = STAGE == 2 && slot_t > 1 ? n_colblocks * slot_t : n_colblocks; // stage 2: slot_t = parts of the contraction
     hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, zdim), dim3(512), lds, s, classes,
@@ -1819,14 +1839,17 @@ static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const
     }
 }
 
-static int device_cu_count() {
-    static const int n_cu = [] {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            return prop.multiProcessorCount;
-        return 256;
-    }();
+static int device_cu_count() { // of the current device (every entry point binds its thread to the handle's device)
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev >= 0 && dev < 64) {
+        const int c = cache[dev].load(std::memory_order_relaxed);
+        if (c > 0) return c;
+    }
+    int n_cu = 256;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    if (dev >= 0 && dev < 64) cache[dev].store(n_cu, std::memory_order_relaxed);
     return n_cu;
 }
 
@@ -1869,7 +1892,7 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len, const uint16_t *qlist,
-                       double *L, hipStream_t s) {
+                       double *L, hipStream_t s, bool allow_ksplit) {
     if (n_tiles == 0) return;
     // Two workgroups per tile, each with half of a 22-group chunk of the output nodes (gridDim.z = 2, 11 groups,
     // 78 KB of LDS: two fit a CU).  The halves of a tile read the same slot contents at about the same time (L2
@@ -1892,7 +1915,7 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
         const int v = e ? std::atoi(e) : 0;
         return v >= 1 && v <= 32 ? v : 0;
     }();
-    int ksplit = ks_env;
+    int ksplit = allow_ksplit ? ks_env : 1; // (the parts add atomically: not for BBFMM_FLAG_DETERMINISTIC handles)
     if (ksplit == 0) {
         const int n_cu = device_cu_count();
         const int64_t wgs = static_cast<int64_t>(n_tiles) * z * K;

@@ -265,10 +265,10 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
     if (order < 2 || order > kMaxOrder)
         return fail(BBFMM_BAD_ARGUMENT, "interpolation_order must be in [2, " + std::to_string(kMaxOrder) + "]");
     if (!(base_range > 0.0)) return fail(BBFMM_BAD_ARGUMENT, "base_range must be positive"); // kernel_helpers.rs:69
-    if (!l2p_order_supported(order, d))
-        return fail(BBFMM_UNSUPPORTED, "interpolation_order > 12 is not instantiated for 3-D trees");
+    if (!l2p_order_supported(order, d)) return fail(BBFMM_UNSUPPORTED, "interpolation_order is not instantiated on the device");
     host_only_ = (flags & BBFMM_FLAG_HOST_ONLY) != 0;
     shared_basis_ = (flags & BBFMM_FLAG_M2L_SHARED_BASIS) != 0;
+    deterministic_ = (flags & BBFMM_FLAG_DETERMINISTIC) != 0;
     if (shared_basis_ && host_only_) return fail(BBFMM_BAD_ARGUMENT, "BBFMM_FLAG_M2L_SHARED_BASIS needs a device");
     order_ = order;
     d_ = d;
@@ -1414,9 +1414,10 @@ int FmmTree::ensure_rhs_capacity(int k) {
 }
 
 // M2P jobs of one leaf: its W list cut into chunks so that a few big leaves still fill the chip.
+// (whole = BBFMM_FLAG_DETERMINISTIC: one job per leaf, so that no two jobs add to the same target)
 static void add_w_jobs(const HostTree &t, int32_t c, int32_t tb, int32_t te, std::vector<int32_t> *wtb,
-                       std::vector<int32_t> *wte, std::vector<int64_t> *wb, std::vector<int64_t> *we) {
-    constexpr int64_t kChunk = 8;
+                       std::vector<int32_t> *wte, std::vector<int64_t> *wb, std::vector<int64_t> *we, bool whole = false) {
+    const int64_t kChunk = whole ? std::max<int64_t>(t.w.ptr[c + 1] - t.w.ptr[c], 1) : 8;
     for (int64_t q = t.w.ptr[c]; q < t.w.ptr[c + 1]; q += kChunk) {
         wtb->push_back(tb);
         wte->push_back(te);
@@ -1438,7 +1439,7 @@ int FmmTree::build_source_target_set() {
         jc.push_back(c);
         tb.push_back(static_cast<int32_t>(t.pt_begin[c]));
         te.push_back(static_cast<int32_t>(t.pt_end[c]));
-        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
+        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we, deterministic_);
     }
     ts.n_jobs = static_cast<int>(jc.size());
     ts.n_w_jobs = static_cast<int>(wtb.size());
@@ -1652,7 +1653,7 @@ int FmmTree::build_target_set_device(const double *x, int64_t m, int64_t ldx, Ta
             HIPCHK(hipStreamSynchronize(stream_));
         }
         if (!t.w.idx.empty())
-            for (size_t j = 0; j < nj; ++j) add_w_jobs(t, jc[j], tb[j], te[j], &wtb, &wte, &wb, &we);
+            for (size_t j = 0; j < nj; ++j) add_w_jobs(t, jc[j], tb[j], te[j], &wtb, &wte, &wb, &we, deterministic_);
         if (leaves_out) leaves_out->swap(jc);
     }
     ts->n_w_jobs = static_cast<int>(wtb.size());
@@ -1689,7 +1690,7 @@ int FmmTree::build_target_set_host(const double *x, int64_t m, int64_t ldx, Targ
             jc.push_back(c);
             tb.push_back(static_cast<int32_t>(i));
             te.push_back(static_cast<int32_t>(e));
-            add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
+            add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we, deterministic_);
             i = e;
         }
     } else {
@@ -1705,7 +1706,7 @@ int FmmTree::build_target_set_host(const double *x, int64_t m, int64_t ldx, Targ
             tb.push_back(static_cast<int32_t>(cur));
             cur += cnt[c + 1];
             te.push_back(static_cast<int32_t>(cur));
-            add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
+            add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we, deterministic_);
         }
         for (int64_t i = 0; i < m; ++i) perm[start[cell[i]]++] = static_cast<int32_t>(i);
     }
@@ -1818,20 +1819,25 @@ int FmmTree::upward(int k, const DownwardPlan *dp) {
     const bool part = dp && dp->restrict_upward;
     // reset_multipole_coefficients (bbfmm.rs:619-624): M is zero-initialised once; P2M and M2M assign
     // every leaf with sources and every parent, the other entries are never written.  A partition computes
-    // only the multipoles its downward and leaf passes read (the others keep stale values nobody reads).
+    // only its share (see DownwardPlan): the coarse prefix is zeroed first because the coarse leaves other ranks
+    // own must enter the all-reduce as zeros; fine cells it does not need keep stale values nobody reads.
     phase_begin();
-    if (part)
+    if (part) {
+        for (int j = 0; j < k && dp->coarse_cells > 0; ++j)
+            HIPCHK(hipMemsetAsync(d_M_.p + static_cast<size_t>(j) * C * cheb_.n_pad, 0,
+                                  static_cast<size_t>(dp->coarse_cells) * cheb_.n_pad * sizeof(double), stream_));
         launch_p2m(cheb_, src_ptr_, d_w_sorted_.p, t.n_points, k, C, dp->d_up_leaves.p, static_cast<int>(dp->up_leaves_h.size()),
                    d_pt_begin_.p, d_pt_end_.p, d_centers_.p, d_lengths_.p, d_M_.p, stream_);
-    else
+    } else {
         launch_p2m(cheb_, src_ptr_, d_w_sorted_.p, t.n_points, k, C, d_src_leaves_.p, static_cast<int>(src_leaves_.size()),
                    d_pt_begin_.p, d_pt_end_.p, d_centers_.p, d_lengths_.p, d_M_.p, stream_);
+    }
     phase_end(kPhP2M);
     phase_begin();
     for (int level = t.depth - 1; level >= 1; --level) { // (1..depth).rev(), bbfmm.rs:675
         if (part)
             launch_m2m(cheb_, k, C, dp->d_up_parents[level].p, static_cast<int>(dp->up_parents_h[level].size()),
-                       d_child_ptr_.p, d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
+                       dp->d_part_child_ptr.p, dp->d_part_child_idx.p, d_octant_.p, d_M_.p, stream_);
         else
             launch_m2m(cheb_, k, C, d_m2m_parents_[level].p, static_cast<int>(m2m_parents_[level].size()), d_child_ptr_.p,
                        d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
@@ -1869,10 +1875,10 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     phase_begin();
     if (dp)
         launch_m2l_stage2(d_m2l_classes_.p, dp->d_tiles2.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles2_h.size()),
-                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, l_out, stream_);
+                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, l_out, stream_, !deterministic_);
     else
         launch_m2l_stage2(d_m2l_classes_.p, d_m2l_tiles2_.p, nullptr, static_cast<int>(m2l_tiles2_h_.size()),
-                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, l_out, stream_);
+                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, l_out, stream_, !deterministic_);
     if (shared_basis_) // back to the node values (every cell of level >= 2; cells above keep the zeros)
         launch_m2l_basis(d_basis_classes_.p, d_basis_tiles_e_.p, n_basis_tiles_, basis_pad_, cheb_.n_pad, k, C, d_Lc_.p, d_L_.p, stream_);
     phase_end(kPhM2L2);
@@ -1923,7 +1929,7 @@ int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStre
             return !e || std::atoi(e) != 0;
         }();
         if (timed) phase_begin();
-        if (ts.sym && sym_on && !with_grads && k == 1) // targets = sources, one rhs: every unordered pair once
+        if (ts.sym && sym_on && !deterministic_ && !with_grads && k == 1) // targets = sources, one rhs: every unordered pair once
             launch_p2p_sym(kernel_, ts.n_sym_jobs, ts.sym_tb.p, ts.sym_te.p, ts.sym_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_,
                            d_w_sorted_.p, ts.out.p, st);
         else
@@ -2078,7 +2084,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipEventRecord(ev_fork_, stream_));
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
         CHK(leaf_pass_near(ts, k, false, stream2_, 1));
-        CHK(upward(k, plan));
+        CHK(upward(k, nullptr));
         HIPCHK(hipEventRecord(ev_fork_, stream_));
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
         CHK(leaf_pass_near(ts, k, false, stream2_, 2));
@@ -2087,7 +2093,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
         CHK(leaf_pass_far(ts, k, false));
     } else if (overlap == 1) {
-        CHK(upward(k, plan));
+        CHK(upward(k, nullptr));
         // near field (FP64 VALU) on a second stream beside the far field (FP64 MFMA)
         HIPCHK(hipEventRecord(ev_fork_, stream_));
         HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
@@ -2102,13 +2108,76 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
             const char *e2 = std::getenv("BBFMM_P2P_SYM");
             return (!e || std::atoi(e) != 0) && (!e2 || std::atoi(e2) != 0);
         }();
-        const bool wx = wx_on && k == 1 && !have_part_ && ts.sym && ts.n_wx_jobs > 0;
-        CHK(upward(k, plan));
+        const bool wx = wx_on && !deterministic_ && k == 1 && !have_part_ && ts.sym && ts.n_wx_jobs > 0;
+        // (a partitioned handle called on its own, without the exchange of matvec_partition_upward / _finish,
+        // needs every multipole: the whole upward pass)
+        CHK(upward(k, nullptr));
         if (wx) HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(ts.m) * sizeof(double), stream_));
         CHK(downward(k, plan, wx ? &ts : nullptr));
         CHK(leaf_pass_near(ts, k, false, stream_, 3, wx));
         CHK(leaf_pass_far(ts, k, false));
     }
+    phase_begin();
+    launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);
+    phase_end(kPhScatter);
+    HIPCHK(hipGetLastError());
+    if (sync) HIPCHK(hipStreamSynchronize(stream_));
+    return BBFMM_OK;
+}
+
+// Doubles per right-hand side of the coarse multipoles a partition exchanges (0: nothing to exchange).
+int64_t FmmTree::partition_coarse_count() const {
+    return have_part_ || (host_only_ && part_world_ > 1) ? part_plan_.coarse_cells * static_cast<int64_t>(round_up(ops_.n, 32)) : 0;
+}
+
+// First half of the partitioned matvec: set_weights restricted to this rank's share of the upward pass
+// (bbfmm.rs:383-401, 666-772 split by subtree), partial coarse multipoles packed rhs-major into d_coarse.
+int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (!have_part_) return fail(BBFMM_BAD_ARGUMENT, "bbfmm_set_partition (world > 1) must be called first");
+    const int64_t N = tree_.n_points, C = tree_.n_cells();
+    const int64_t cnt = partition_coarse_count();
+    if (!d_w || k < 1 || ldw < N || (cnt > 0 && !d_coarse)) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
+    CHK(ensure_rhs_capacity(k));
+    nrhs_ = k;
+    have_locals_ = locals_requested_ = false;
+    phase_begin();
+    launch_gather_weights(d_w, ldw, k, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_end(kPhGather);
+    if (part_targets_.out.n < static_cast<size_t>(k) * part_targets_.m) {
+        dfree(&part_targets_.out);
+        CHK(dalloc(&part_targets_.out, static_cast<size_t>(k) * part_targets_.m));
+    }
+    CHK(upward(k, &part_plan_));
+    phase_begin();
+    for (int j = 0; j < k && cnt > 0; ++j)
+        HIPCHK(hipMemcpyAsync(d_coarse + static_cast<size_t>(j) * cnt, d_M_.p + static_cast<size_t>(j) * C * cheb_.n_pad,
+                              static_cast<size_t>(cnt) * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    phase_end(kPhM2M);
+    part_pending_k_ = k;
+    return BBFMM_OK;
+}
+
+// Second half: d_coarse holds the sum over all ranks of what matvec_partition_upward packed (an all-reduce on this
+// handle's stream, or any stream ordered with it); evaluate at the owned targets (bbfmm.rs:444-507 over this
+// rank's cells_with_targets), owned rows of d_out written, the others untouched.
+int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (!have_part_ || part_pending_k_ < 1) return fail(BBFMM_BAD_ARGUMENT, "bbfmm_matvec_partition_upward must be called first");
+    const int64_t N = tree_.n_points, C = tree_.n_cells();
+    const int64_t cnt = partition_coarse_count();
+    const int k = part_pending_k_;
+    if (!d_out || ldo < N || (cnt > 0 && !d_coarse)) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
+    part_pending_k_ = 0;
+    phase_begin();
+    for (int j = 0; j < k && cnt > 0; ++j)
+        HIPCHK(hipMemcpyAsync(d_M_.p + static_cast<size_t>(j) * C * cheb_.n_pad, d_coarse + static_cast<size_t>(j) * cnt,
+                              static_cast<size_t>(cnt) * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    phase_end(kPhM2M);
+    const TargetSet &ts = part_targets_;
+    CHK(downward(k, &part_plan_));
+    CHK(leaf_pass_near(ts, k, false, stream_, 3));
+    CHK(leaf_pass_far(ts, k, false));
     phase_begin();
     launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);
     phase_end(kPhScatter);
@@ -2240,7 +2309,8 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
 // bbfmm.rs:468-480): M2L stage 2 on the tiles that hold such a cell, stage 1 on compact tiles (lists
 // of class positions, 128 per tile) of the cells that are a V-list source of one, P2L on such cells.
 // The host part also runs on BBFMM_FLAG_HOST_ONLY handles.
-int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp, bool restrict_upward) {
+int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp, bool restrict_upward,
+                                 int64_t own_b, int64_t own_e) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
     dp->active.assign(static_cast<size_t>(C), 0);
@@ -2409,26 +2479,72 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
     dp->restrict_upward = restrict_upward;
     dp->up_leaves_h.clear();
     dp->up_parents_h.assign(static_cast<size_t>(t.depth) + 1, {});
+    dp->coarse_level = 0;
+    dp->coarse_cells = 0;
+    dp->part_child_ptr_h.clear();
+    dp->part_child_idx_h.clear();
     if (restrict_upward) {
-        // multipoles read: V-list sources of the active cells (stage 1), W-list cells of the target leaves (M2P);
-        // computing one needs every cell below it.  Cells are numbered by (level, key): parents come first.
-        std::vector<uint8_t> up(needed);
+        // Coarse level: the deepest level whose prefix of M (levels 0..Lc, per rhs) stays under 32 MB -- level 4 of
+        // a uniform tree at orders 7 and 9 (4,681 cells: 13 / 28 MB); one more level is eight times that.
+        // BBFMM_PART_COARSE_LEVEL overrides (0: no exchange, every needed multipole is recomputed).
+        int Lc = 0;
+        {
+            const char *e = std::getenv("BBFMM_PART_COARSE_LEVEL");
+            const int64_t n_pad = round_up(ops_.n, 32);
+            if (e) {
+                Lc = std::max(0, std::min(std::atoi(e), t.depth - 1));
+            } else {
+                for (int l = 1; l <= t.depth - 1; ++l)
+                    if (t.level_ptr[static_cast<size_t>(l) + 1] * n_pad * 8 <= (int64_t(32) << 20)) Lc = l;
+            }
+            if (t.depth < 2) Lc = 0;
+        }
+        dp->coarse_level = Lc;
+        dp->coarse_cells = Lc > 0 ? t.level_ptr[static_cast<size_t>(Lc) + 1] : 0;
+        auto owned = [&](int64_t c) { return t.pt_end[c] > t.pt_begin[c] && t.pt_begin[c] >= own_b && t.pt_begin[c] < own_e; };
+        // complete multipoles above the coarse level: V-list sources of the active cells (stage 1), W-list cells of
+        // the target leaves (M2P), the cells of level Lc + 1 this rank owns (the rank that holds a cell's first
+        // point; they feed the partial sums), and everything below them.  Cells are numbered by (level, key):
+        // parents come first.
+        std::vector<uint8_t> up(static_cast<size_t>(C), 0);
+        for (int64_t c = 0; c < C; ++c)
+            if (needed[c] && t.level[c] > Lc) up[c] = 1;
         for (int32_t leaf : target_leaves)
-            for (int64_t q = t.w.ptr[leaf]; q < t.w.ptr[leaf + 1]; ++q) up[t.w.idx[q]] = 1;
+            for (int64_t q = t.w.ptr[leaf]; q < t.w.ptr[leaf + 1]; ++q)
+                if (t.level[t.w.idx[q]] > Lc) up[t.w.idx[q]] = 1;
+        if (Lc > 0 && Lc + 1 <= t.depth)
+            for (int64_t c = t.level_ptr[static_cast<size_t>(Lc) + 1]; c < t.level_ptr[static_cast<size_t>(Lc) + 2]; ++c)
+                if (owned(c)) up[c] = 1;
         for (int64_t c = 0; c < C; ++c)
             if (up[c])
                 for (int64_t q = t.children.ptr[c]; q < t.children.ptr[c + 1]; ++q) up[t.children.idx[q]] = 1;
         for (int32_t c : src_leaves_)
-            if (up[c]) dp->up_leaves_h.push_back(c);
+            if (up[c] || (t.level[c] <= Lc && owned(c))) dp->up_leaves_h.push_back(c);
         for (int level = 1; level < t.depth; ++level)
             for (int32_t c : m2m_parents_[level])
-                if (up[c]) dp->up_parents_h[level].push_back(c);
+                if (level <= Lc || up[c]) dp->up_parents_h[level].push_back(c); // coarse parents: all (partial sums, maybe zero)
+        dp->reads_h = needed;
+        for (int32_t leaf : target_leaves)
+            for (int64_t q = t.w.ptr[leaf]; q < t.w.ptr[leaf + 1]; ++q) dp->reads_h[t.w.idx[q]] = 1;
+        // children lists: the parents of level Lc sum the children they own only
+        dp->part_child_ptr_h.assign(static_cast<size_t>(C) + 1, 0);
+        dp->part_child_idx_h.reserve(t.children.idx.size());
+        for (int64_t c = 0; c < C; ++c) {
+            for (int64_t q = t.children.ptr[c]; q < t.children.ptr[c + 1]; ++q) {
+                const int32_t ch = t.children.idx[q];
+                if (Lc > 0 && t.level[c] == Lc && !owned(ch)) continue;
+                dp->part_child_idx_h.push_back(ch);
+            }
+            dp->part_child_ptr_h[static_cast<size_t>(c) + 1] = static_cast<int64_t>(dp->part_child_idx_h.size());
+        }
     }
     if (host_only_) return BBFMM_OK;
     if (restrict_upward) {
         CHK(tupload(&dp->d_up_leaves, dp->up_leaves_h));
         dp->d_up_parents.resize(dp->up_parents_h.size());
         for (size_t l = 0; l < dp->up_parents_h.size(); ++l) CHK(tupload(&dp->d_up_parents[l], dp->up_parents_h[l]));
+        CHK(tupload(&dp->d_part_child_ptr, dp->part_child_ptr_h));
+        CHK(tupload(&dp->d_part_child_idx, dp->part_child_idx_h));
     }
     CHK(tupload(&dp->d_active, dp->active));
     CHK(tupload(&dp->d_tiles2, dp->tiles2_h));
@@ -2444,6 +2560,8 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
 void FmmTree::free_downward_plan(DownwardPlan *dp) {
     dfree(&dp->d_up_leaves);
     for (auto &b : dp->d_up_parents) dfree(&b);
+    dfree(&dp->d_part_child_ptr);
+    dfree(&dp->d_part_child_idx);
     dfree(&dp->d_active);
     dfree(&dp->d_tiles2);
     dfree(&dp->d_tiles1);
@@ -2592,9 +2710,10 @@ int FmmTree::set_partition(int rank, int world) {
     part_world_ = world;
     if (have_part_) {
         free_target_set(&part_targets_);
-        free_downward_plan(&part_plan_);
         have_part_ = false;
     }
+    free_downward_plan(&part_plan_);
+    part_pending_k_ = 0;
     part_rows_.clear();
     if (world == 1) return BBFMM_OK;
     // balance the leaf-pass + M2L work proxy: P2P pair count + a per-point share of the far field
@@ -2620,10 +2739,10 @@ int FmmTree::set_partition(int rank, int world) {
     const size_t lb = rank == 0 ? 0 : cut(rank), le = rank == world - 1 ? nl : cut(rank + 1);
     std::vector<int32_t> owned_leaves(src_leaves_.begin() + static_cast<std::ptrdiff_t>(lb),
                                       src_leaves_.begin() + static_cast<std::ptrdiff_t>(le));
-    CHK(build_downward_plan(owned_leaves, &part_plan_, true));
     // owned targets: one contiguous range of the sorted sources
     const int64_t pb = lb < le ? t.pt_begin[src_leaves_[lb]] : 0;
     const int64_t pe = lb < le ? t.pt_end[src_leaves_[le - 1]] : 0;
+    CHK(build_downward_plan(owned_leaves, &part_plan_, true, pb, pe));
     part_rows_.resize(static_cast<size_t>(pe - pb));
     for (int64_t i = 0; i < pe - pb; ++i) part_rows_[i] = t.order[pb + i];
     part_empty_ = pe == pb;
@@ -2640,7 +2759,7 @@ int FmmTree::set_partition(int rank, int world) {
         jc.push_back(c);
         tb.push_back(static_cast<int32_t>(t.pt_begin[c] - pb));
         te.push_back(static_cast<int32_t>(t.pt_end[c] - pb));
-        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we);
+        add_w_jobs(t, c, tb.back(), te.back(), &wtb, &wte, &wb, &we, deterministic_);
     }
     ts.n_jobs = static_cast<int>(jc.size());
     ts.n_w_jobs = static_cast<int>(wtb.size());
@@ -2704,6 +2823,35 @@ int FmmTree::debug_get_coefficients(char which, int k, double *out) {
     HIPCHK(hipStreamSynchronize(stream_));
     HIPCHK(hipMemcpy2D(out, n * sizeof(double), src, n_pad * sizeof(double), n * sizeof(double),
                        static_cast<size_t>(k) * C, hipMemcpyDeviceToHost));
+    return BBFMM_OK;
+}
+
+// Test hook: the partition's upward plan walked with point counts in place of multipoles (see the header).
+int FmmTree::debug_partition_upward_counts(int64_t *counts_out, uint8_t *reads_out, int64_t *info_out) const {
+    const HostTree &t = tree_;
+    const DownwardPlan &dp = part_plan_;
+    if (part_world_ < 2 || !dp.restrict_upward) return BBFMM_BAD_ARGUMENT;
+    const int64_t C = t.n_cells();
+    std::fill(counts_out, counts_out + C, int64_t(-1));
+    std::fill(counts_out, counts_out + dp.coarse_cells, int64_t(0)); // the memset of the coarse prefix
+    for (int32_t c : dp.up_leaves_h) counts_out[c] = t.pt_end[c] - t.pt_begin[c];
+    int64_t n_parents = 0;
+    for (int level = t.depth - 1; level >= 1; --level)
+        for (int32_t c : dp.up_parents_h[static_cast<size_t>(level)]) {
+            int64_t sum = 0;
+            for (int64_t q = dp.part_child_ptr_h[static_cast<size_t>(c)]; q < dp.part_child_ptr_h[static_cast<size_t>(c) + 1]; ++q) {
+                const int64_t v = counts_out[dp.part_child_idx_h[static_cast<size_t>(q)]];
+                if (v < 0) return BBFMM_UNSUPPORTED; // a child that was never computed: the plan is broken
+                sum += v;
+            }
+            counts_out[c] = sum;
+            ++n_parents;
+        }
+    std::copy(dp.reads_h.begin(), dp.reads_h.end(), reads_out);
+    info_out[0] = dp.coarse_level;
+    info_out[1] = dp.coarse_cells;
+    info_out[2] = static_cast<int64_t>(dp.up_leaves_h.size());
+    info_out[3] = n_parents;
     return BBFMM_OK;
 }
 

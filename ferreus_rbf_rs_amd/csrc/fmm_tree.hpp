@@ -80,13 +80,25 @@ struct DownwardPlan {
     std::vector<int32_t> tile_idx_h;        // class positions of the cells of both tile lists
     std::vector<uint16_t> qlist_h;          // active contraction steps of the stage-2 tiles
     int n_x_jobs = 0;
-    // a partition also restricts the upward pass to the cells whose multipoles it reads (V-list sources and
-    // W-list cells of its targets, and everything below them)
+    // A partition also splits the upward pass (bbfmm.rs:666-772).  Levels <= coarse_level: every rank sums the
+    // multipoles of the sources it owns only (P2M of its own coarse leaves, M2M over the children it owns at
+    // level coarse_level + 1, over all children above), and one all-reduce (sum) of that prefix of M -- cells are
+    // numbered by level, so it is contiguous -- gives every rank the complete coarse multipoles (M2M is linear).
+    // Levels > coarse_level: the rank computes, complete, the cells it owns at level coarse_level + 1, the V-list
+    // sources of its active cells and the W-list cells of its target leaves, with everything below them (a halo
+    // of three cells per level around its subtree).
     bool restrict_upward = false;
+    int coarse_level = 0;          // 0: nothing to exchange (every multipole the rank reads is computed locally)
+    int64_t coarse_cells = 0;      // cells of levels 0..coarse_level = level_ptr[coarse_level + 1]
     std::vector<int32_t> up_leaves_h;
     std::vector<std::vector<int32_t>> up_parents_h; // per level
+    std::vector<int64_t> part_child_ptr_h;          // children CSR with the rows of level coarse_level cut to the
+    std::vector<int32_t> part_child_idx_h;          // children this rank owns
+    std::vector<uint8_t> reads_h;                   // cells whose multipoles the rank's downward / leaf pass reads
     DevBuf<int32_t> d_up_leaves;
     std::vector<DevBuf<int32_t>> d_up_parents;
+    DevBuf<int64_t> d_part_child_ptr;
+    DevBuf<int32_t> d_part_child_idx;
     DevBuf<uint8_t> d_active;
     DevBuf<M2lTileDesc> d_tiles2, d_tiles1;
     DevBuf<int32_t> d_tile_idx, d_x_cells, d_x_runs;
@@ -125,6 +137,12 @@ class FmmTree {
                                    int64_t n_target_indices, const double *poly, int64_t ldp, double nugget,
                                    double *result);                                     // rbf.rs:1338-1379
     int matvec_device(const double *d_w, int64_t ldw, int k, double *d_out, int64_t ldo, bool sync);
+    // The partitioned matvec in two calls around the exchange of the coarse multipoles:
+    // upward: gather + own P2M / M2M, packs k x partition_coarse_count() partial multipoles into d_coarse;
+    // finish: takes their sum over the ranks, runs the downward and leaf passes of the owned targets.
+    int64_t partition_coarse_count() const;
+    int matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse);
+    int matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync);
     int register_subset(const int64_t *idx, int64_t n_idx, int *id_out);
     int matvec_subset_device(int id, const double *d_w, double *d_y, bool sync);
     int set_partition(int rank, int world);
@@ -165,6 +183,7 @@ class FmmTree {
     // M, L: n_cells x n (cell-major, one rhs).  L is accumulated into.
     int debug_apply_m2l_tables_host(const double *M, double *L) const;
     int debug_get_coefficients(char which, int k, double *out);
+    int debug_partition_upward_counts(int64_t *counts_out, uint8_t *reads_out, int64_t *info_out) const;
 
   private:
     int fail(int code, const std::string &msg);
@@ -200,6 +219,7 @@ class FmmTree {
     // ---- host state
     std::string err_;
     bool host_only_ = false;
+    bool deterministic_ = false; // BBFMM_FLAG_DETERMINISTIC: no f64 atomics anywhere (ordered-pair kernels, one M2P job per leaf)
     bool tree_built_on_device_ = false;
     DevTreePoints dev_points_; // left by the device tree build until upload() has gathered the sorted sources
     int order_ = 0, d_ = 0;
@@ -239,7 +259,10 @@ class FmmTree {
     DownwardPlan part_plan_;                     // partition: restricted downward pass
     std::vector<std::unique_ptr<SubsetPlan>> subset_plans_; // partial matvecs, least recently used evicted
     uint64_t subset_clock_ = 0;
-    int build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp, bool restrict_upward = false);
+    // restrict_upward: the plan of a partition that owns the sorted sources [own_b, own_e)
+    int build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp, bool restrict_upward = false,
+                            int64_t own_b = 0, int64_t own_e = 0);
+    int part_pending_k_ = 0; // rhs count of a matvec_partition_upward that still waits for its finish
     void free_downward_plan(DownwardPlan *dp);
     int subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out);
     int fill_subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan *sp);

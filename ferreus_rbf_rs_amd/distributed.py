@@ -1,11 +1,16 @@
-"""Multi-GPU exchange step of the partitioned matvec.
+"""Multi-GPU exchange steps of the partitioned matvec.
 
-Every rank holds the whole tree and evaluates the potentials of the targets it owns (a
-contiguous Morton range of leaves, `FmmTree.set_partition`).  Owned rows are disjoint by
-construction, so one all-gather of the owned values (padded to the largest share) completes the
-matvec on every rank; with backend "nccl" this is RCCL over xGMI (`all_gather_into_tensor` on
-preallocated device buffers: one collective, one gather pass before it and one scatter pass after
-it per step).  With a "gloo" group the same bookkeeping runs on CPU tensors (tests), or -- for
+Every rank holds the whole tree and all weights, and owns a contiguous Morton range of leaves
+(`FmmTree.set_partition`).  Two collectives per matvec, both on preallocated device buffers:
+
+* upward pass: every rank anterpolates its own sources (plus the three-cell halo its V / W lists read at the fine
+  levels); the partial multipoles of the coarse levels -- a contiguous 13 MB prefix of M at order 7 -- are summed
+  with ONE all-reduce (`PartitionedMatvec`; M2M is linear, so the sum is the whole upward pass of bbfmm.rs:666-772);
+* potentials: owned rows are disjoint by construction, so one all-gather of the owned values (padded to the largest
+  share) completes the matvec on every rank (`OwnedRowsExchange`: one gather pass before and one scatter pass after
+  the collective per step).
+
+With backend "nccl" both are RCCL over xGMI.  With a "gloo" group the same bookkeeping runs on CPU tensors (tests), or -- for
 device tensors -- stages the owned values through pinned host buffers, which lets two ranks share
 one GPU (a functional check of the N > 1 path on a one-GPU box, never a scaling number).
 """
@@ -73,3 +78,52 @@ class OwnedRowsExchange:
             dist.all_gather_into_tensor(self.recv.view(-1), self.send.view(-1), group=self.group)
         out.view(-1).index_copy_(0, self.dst_idx, self.recv.view(-1).index_select(0, self.src_idx))
         return out
+
+
+class PartitionedMatvec:
+    """One matvec of a partitioned handle: upward (own share) -> all-reduce of the coarse multipoles -> downward and
+    leaf pass of the owned targets -> all-gather of the owned potentials.  Everything is queued on the handle's HIP
+    stream (wrapped as a torch ExternalStream so that RCCL orders itself with the kernels); nothing synchronises the
+    host except the gloo staging path."""
+
+    def __init__(self, tree, n_total: int, k: int, device, group=None):
+        self.tree, self.group, self.k, self.n = tree, group, k, n_total
+        device = torch.device(device)
+        self.world = dist.get_world_size(group)
+        self.xchg = OwnedRowsExchange(tree.partition_rows(), n_total, k, device, group)
+        self.count = tree.partition_coarse_count() if self.world > 1 else 0
+        self.staged = self.xchg.staged
+        self.coarse = torch.zeros((k, max(self.count, 1)), dtype=torch.float64, device=device)
+        if self.staged:
+            self.h_coarse = torch.zeros((k, max(self.count, 1)), dtype=torch.float64).pin_memory()
+        self.stream = torch.cuda.ExternalStream(tree.stream(), device=device) if device.type == "cuda" else None
+
+    def check_partition(self) -> bool:
+        return self.xchg.check_partition()
+
+    def all_reduce_coarse(self):
+        if self.count == 0 or self.world == 1:
+            return
+        if self.staged:
+            self.h_coarse.copy_(self.coarse)                             # device -> pinned host (synchronises)
+            dist.all_reduce(self.h_coarse, group=self.group)
+            self.coarse.copy_(self.h_coarse)
+        else:
+            dist.all_reduce(self.coarse, group=self.group)
+
+    def step(self, w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """w: K x N weights (device, contiguous, the same on every rank); out: K x N, complete on return."""
+        if self.world == 1:
+            self.tree.matvec_device(w.data_ptr(), self.n, self.k, out.data_ptr(), self.n, sync=False)
+            return out
+        self.tree.matvec_partition_upward(w.data_ptr(), self.n, self.k, self.coarse.data_ptr())
+        with torch.cuda.stream(self.stream):
+            self.all_reduce_coarse()
+        self.tree.matvec_partition_finish(self.coarse.data_ptr(), out.data_ptr(), self.n, sync=False)
+        with torch.cuda.stream(self.stream):
+            self.xchg.exchange(out)
+        return out
+
+    def synchronize(self):
+        if self.stream is not None:
+            self.stream.synchronize()

@@ -141,11 +141,13 @@ class FmmTree:
     def __init__(self, source_points, interpolation_order: int, kernel_params: KernelParams,
                  adaptive_tree: bool, sparse: bool, *, extents=None,
                  params: Optional[FmmParams] = None, host_only: bool = False,
-                 m2l_shared_basis: bool = False, direct_small_w_leaves: bool = False):
+                 m2l_shared_basis: bool = False, direct_small_w_leaves: bool = False, deterministic: bool = False):
         """m2l_shared_basis: BBFMM_FLAG_M2L_SHARED_BASIS, an extension beyond the reference (off by default):
         the M2L stages run in one orthonormal basis per level, cut at params.epsilon.
         direct_small_w_leaves: BBFMM_FLAG_DIRECT_SMALL_W_LEAVES, likewise an extension: W-list leaves with no
-        more points than nodes are summed directly instead of through M2P / P2L."""
+        more points than nodes are summed directly instead of through M2P / P2L.
+        deterministic: BBFMM_FLAG_DETERMINISTIC -- fixed summation order everywhere (no f64 atomics), bitwise
+        reproducible results from run to run like the reference's."""
         lib = L.load()
         pts = _as_f64_2d(source_points, "source_points")
         n, d = pts.shape
@@ -162,7 +164,8 @@ class FmmTree:
                               ctypes.byref(cpar) if cpar is not None else None,
                               (L.FLAG_HOST_ONLY if host_only else 0) |
                               (L.FLAG_M2L_SHARED_BASIS if m2l_shared_basis else 0) |
-                              (L.FLAG_DIRECT_SMALL_W_LEAVES if direct_small_w_leaves else 0), ctypes.byref(h))
+                              (L.FLAG_DIRECT_SMALL_W_LEAVES if direct_small_w_leaves else 0) |
+                              (L.FLAG_DETERMINISTIC if deterministic else 0), ctypes.byref(h))
         self._h = h
         self._lib = lib
         if rc != L.OK:
@@ -296,6 +299,29 @@ class FmmTree:
         rows = np.zeros(n, dtype=np.int64)
         self._raise(self._lib.bbfmm_partition_rows(self._h, rows.ctypes.data))
         return rows
+
+    def partition_coarse_count(self) -> int:
+        """Doubles per right-hand side of the coarse multipoles a partition exchanges (0: none)."""
+        return int(self._lib.bbfmm_partition_coarse_count(self._h))
+
+    def matvec_partition_upward(self, d_w: int, ldw: int, k: int, d_coarse: int):
+        """First half of the partitioned matvec (device pointers): this rank's share of the upward pass; packs
+        k x partition_coarse_count() partial coarse multipoles into d_coarse for the all-reduce."""
+        self._raise(self._lib.bbfmm_matvec_partition_upward(self._h, d_w, ldw, k, d_coarse or None))
+
+    def matvec_partition_finish(self, d_coarse: int, d_out: int, ldo: int, sync: bool = True):
+        """Second half: d_coarse summed over the ranks; downward + leaf pass of the owned targets."""
+        self._raise(self._lib.bbfmm_matvec_partition_finish(self._h, d_coarse or None, d_out, ldo, int(sync)))
+
+    def debug_partition_upward_counts(self):
+        """(counts, reads, info): the rank's upward plan walked with point counts (see the header)."""
+        c = self.stats().n_cells
+        counts = np.zeros(c, dtype=np.int64)
+        reads = np.zeros(c, dtype=np.uint8)
+        info = np.zeros(4, dtype=np.int64)
+        self._raise(self._lib.bbfmm_debug_partition_upward_counts(self._h, counts.ctypes.data, reads.ctypes.data,
+                                                                 info.ctypes.data))
+        return counts, reads, info
 
     def set_profiling(self, on: bool):
         self._lib.bbfmm_set_profiling(self._h, int(on))

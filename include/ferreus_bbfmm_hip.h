@@ -98,6 +98,16 @@ typedef struct bbfmm_handle bbfmm_handle;
                                         * approximates, so results move by the reference's own M2P / P2L error (about
                                         * epsilon); on mixed-level trees of moderate size these two passes dominate the
                                         * matvec (1M uniform points, Spheroidal3: 9 of 14 ms). */
+#define BBFMM_FLAG_DETERMINISTIC 8u /* bitwise reproducible results from run to run, as the reference's fixed-order
+                                    * per-target sums are.  The default one-rhs matvec accumulates through hardware f64
+                                    * atomics in three places (column sums of the unordered-pair near field, L and the
+                                    * potentials of the fused M2P + P2L pass, the contraction split of M2L stage 2 on
+                                    * small trees) and M2P adds the chunks of a leaf's W list atomically: the last bits
+                                    * of a result depend on the scheduling (differences <= 1e-12 relative; an FGMRES run
+                                    * near its tolerance may take one iteration more or less).  With this flag the handle
+                                    * uses the ordered-pair kernels, one M2P job per leaf and plain stores in stage 2:
+                                    * every sum has a fixed order (about 1.1x slower at 10M points, 1.5x on mixed-level
+                                    * trees).  Same arithmetic as the reference either way. */
 
 /*
  * FmmTree::new (ferreus_rbf_utils/src/utils.rs:392-421 -> ferreus_bbfmm/src/bbfmm.rs:272-353).
@@ -217,6 +227,31 @@ void *bbfmm_stream(bbfmm_handle *h);
 int bbfmm_set_partition(bbfmm_handle *h, int32_t rank, int32_t world);
 int64_t bbfmm_partition_row_count(const bbfmm_handle *h);
 int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out);
+
+/* The partitioned matvec in two calls, around the one exchange the upward pass needs (the passes
+ * being split are ferreus_bbfmm/src/bbfmm.rs:666-772 and 444-507).  Every rank holds all weights but anterpolates
+ * only its share: above a coarse level (4 for a uniform 10M-point tree) the cells it owns and the three-cell halo
+ * its V / W lists read, complete; at and below it the partial sums over the sources it owns.  M2M is linear, so
+ * one all-reduce (sum) of those partial coarse multipoles -- a contiguous prefix of M, 13 MB per right-hand side at
+ * order 7 -- completes them on every rank.
+ *   bbfmm_partition_coarse_count   doubles per right-hand side of that prefix (0: nothing to exchange, e.g. depth < 2)
+ *   bbfmm_matvec_partition_upward  gather + this rank's P2M / M2M on the handle's stream; packs k x count partial
+ *                                  multipoles rhs-major into d_coarse (device memory of the caller)
+ *   -- caller: all-reduce (sum) d_coarse over the ranks, ordered after the handle's stream (RCCL on that stream, or
+ *      any stream that waits for it) --
+ *   bbfmm_matvec_partition_finish  takes the summed d_coarse, runs the downward and leaf passes of the owned
+ *                                  targets, writes the owned rows of d_out (ld ldo) like bbfmm_matvec_device.
+ * bbfmm_matvec_device on a partitioned handle still works on its own (it then runs the whole upward pass). */
+int64_t bbfmm_partition_coarse_count(const bbfmm_handle *h);
+int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse);
+int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync);
+/* Test hook (host side, also on BBFMM_FLAG_HOST_ONLY handles): walks this rank's upward plan with point COUNTS in
+ * place of multipoles (P2M -> points of the leaf, M2M -> sum over the plan's children).  counts_out[c] (n_cells):
+ * what the plan leaves in cell c before the exchange (-1: never written); reads_out[c] = 1 where the rank's downward
+ * or leaf pass reads M_c.  info_out[0..3] = coarse level, coarse cells, leaves anterpolated, parents translated.
+ * Summed over the ranks the coarse prefix must equal the true point counts, and every cell a rank reads above the
+ * coarse level must hold its true count already. */
+int bbfmm_debug_partition_upward_counts(const bbfmm_handle *h, int64_t *counts_out, uint8_t *reads_out, int64_t *info_out);
 
 /* ---- introspection (tests, bench statistics; host side, no device needed) ---- */
 typedef struct {

@@ -93,10 +93,14 @@ fn kernel_id(k: KernelType) -> i32 {
 pub const BBFMM_FLAG_M2L_SHARED_BASIS: u32 = 2;
 /// `BBFMM_FLAG_DIRECT_SMALL_W_LEAVES`: the other extension (`FERREUS_BBFMM_DIRECT_SMALL_W_LEAVES=1`).
 pub const BBFMM_FLAG_DIRECT_SMALL_W_LEAVES: u32 = 4;
+/// `BBFMM_FLAG_DETERMINISTIC` (`FERREUS_BBFMM_DETERMINISTIC=1`): fixed summation order everywhere (no f64 atomics), so
+/// that two runs give bitwise equal results, as the reference's per-target sums do.
+pub const BBFMM_FLAG_DETERMINISTIC: u32 = 8;
 fn creation_flags() -> u32 {
     let on = |name: &str| matches!(std::env::var(name), Ok(v) if v == "1");
     (if on("FERREUS_BBFMM_M2L_SHARED_BASIS") { BBFMM_FLAG_M2L_SHARED_BASIS } else { 0 })
         | (if on("FERREUS_BBFMM_DIRECT_SMALL_W_LEAVES") { BBFMM_FLAG_DIRECT_SMALL_W_LEAVES } else { 0 })
+        | (if on("FERREUS_BBFMM_DETERMINISTIC") { BBFMM_FLAG_DETERMINISTIC } else { 0 })
 }
 
 impl FmmTree {

@@ -17,7 +17,7 @@ def pytest_configure(config):
 def _built():
     """Build the HIP library (cross-compiles without a GPU) and the oracle's C passes once."""
     from ferreus_rbf_rs_amd import build as b
-    b.build()                        # mtime-aware: a no-op when the library is newer than every source
+    b.build()                        # content-hashed: a no-op when the in-tree objects belong to the sources
     from oracle import bbfmm_oracle as O
     O.build_passes()
     return True

@@ -1,0 +1,34 @@
+"""Child process of tests/test_gpu_switches.py: one mixed-level cloud through the matvec entry point and a
+two-rhs evaluate at arbitrary targets, with whatever BBFMM_* switches the parent put in the environment (they
+are read once per process).  Saves the results to the .npz named on the command line."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    out_path, flags = sys.argv[1], sys.argv[2:]
+    import ferreus_rbf_rs_amd as F
+    rng = np.random.default_rng(2024)
+    n = 260000
+    pts = np.vstack([rng.random((200000, 3)), np.clip(rng.normal(size=(60000, 3)) * 0.03 + 0.4, 0.0, 0.999)])
+    w = rng.standard_normal((n, 2))
+    tree = F.FmmTree(pts, 6, F.KernelParams(F.FmmKernelType.LinearRbf), True, True,
+                     deterministic="deterministic" in flags)
+    st = tree.stats()
+    y = tree.fast_matrix_vector_product(w[:, 0].copy())
+    y_again = tree.fast_matrix_vector_product(w[:, 0].copy())
+    x = rng.random((5000, 3))
+    tree.set_weights(w)
+    z = tree.evaluate(w, x)
+    nv, nc = tree.debug_m2l_variants()
+    np.savez(out_path, y=y, y_again=y_again, z=z, n_w=st.n_w, depth=st.depth, on_device=int(tree.tree_built_on_device()),
+             n_variants=nv)
+
+
+if __name__ == "__main__":
+    main()

@@ -50,10 +50,29 @@ def test_committed_counters_are_only_quoted_for_the_sources_they_were_taken_on(t
 
 
 def test_extra_configs_name_baseline_json_configs():
-    names = [c["name"] for c in bench.EXTRA_CONFIGS]
-    assert len(names) == len(set(names)) == 8
+    """The default line carries the reference's arithmetic only: configs 2 (x2), 3, 4 at N = 1, config 5 at N > 1;
+    the extensions are opt-in and say what they are."""
     flagged = lambda c: bool(c.get("m2l_shared_basis") or c.get("direct_small_w_leaves"))
-    assert sum(1 for c in bench.EXTRA_CONFIGS if not flagged(c)) == 4                   # configs 2 (x2), 3, 4
-    assert all(c["name"].startswith("extension_") == flagged(c) for c in bench.EXTRA_CONFIGS)   # extensions say so
-    for c in bench.EXTRA_CONFIGS:
+    names = [c["name"] for c in bench.EXTRA_CONFIGS + bench.EXTENSION_CONFIGS + [bench.CONFIG5]]
+    assert len(names) == len(set(names)) == 9
+    assert len(bench.EXTRA_CONFIGS) == 4 and not any(flagged(c) for c in bench.EXTRA_CONFIGS + [bench.CONFIG5])
+    assert all(flagged(c) and c["name"].startswith("extension_") for c in bench.EXTENSION_CONFIGS)
+    assert (bench.CONFIG5["points"], bench.CONFIG5["kernel"]) == (40_000_000, "Spheroidal3Rbf")
+    for c in bench.EXTRA_CONFIGS + bench.EXTENSION_CONFIGS + [bench.CONFIG5]:
         assert c["total_sill"] <= c["base_range"]      # KernelParamsBuilder::build asserts this (kernel_helpers.rs:69-70)
+
+
+def test_phase_roofline_accounts_every_phase_and_names_the_bound():
+    class S:  # the fields of bbfmm_tree_stats the function reads (10M-point headline values)
+        n_nodes, n_cells, d, n_leaves, n_w = 343, 298905, 3, 261542, 9216
+        m2l_flops_k1, wx_tile_bytes_k1, wx_pairs = 1.7298e12, 5.0e8, 1.2e8
+        p2p_tile_bytes_k1, p2p_pairs = 9.99e9, 1.008e10
+    ms = {"gather": 0.05, "P2M": 1.06, "M2M": 0.43, "M2L_stage1": 17.3, "M2L_stage2": 15.8, "P2L": 0.2, "L2L": 0.3,
+          "P2P": 5.5, "M2P": 0.0, "L2P": 0.95, "scatter": 0.05}
+    pr = bench.phase_roofline(S, 10_000_000, 1, 7, "LinearRbf", ms, sym_pairs=True)
+    assert set(pr) == set(ms) - {"M2P"}                                   # phases that took no time are left out
+    assert pr["M2L_stage1"]["bound"] == "mfma" and abs(pr["M2L_stage1"]["frac_fp64"] - 0.636) < 0.01
+    assert pr["P2P"]["bound"] == "fp64_valu" and abs(pr["P2P"]["frac_hbm"] - 0.227) < 0.01
+    assert pr["gather"]["bound"] == "hbm" and pr["gather"]["flops"] == 0.0
+    for e in pr.values():
+        assert e["gbps"] > 0 and 0 <= e["frac_hbm"] < 1.5 and 0 <= e["frac_fp64"] < 1.0

@@ -298,8 +298,9 @@ def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs):
 def test_config5_forty_million_points_eight_way_partition():
     """BASELINE.json configs[4] at full size on one GPU: 40M points, Spheroidal3, the matvec
     partitioned by target subtree into 8 shares that are run one after another and reassembled from their owned
-    rows -- everything of the 8-GPU run except the RCCL all-gather itself (tests/test_gpu_two_ranks.py runs the
-    exchange with two real processes)."""
+    rows -- everything of the 8-GPU run (own-subtree upward pass, summed coarse multipoles, restricted downward and
+    leaf passes) except the two RCCL collectives themselves (tests/test_gpu_two_ranks.py runs those with two real
+    processes)."""
     import torch
     n, br, sill = 40_000_000, 0.1, 0.1
     pts = np.random.default_rng(42).random((n, 3))
@@ -312,12 +313,24 @@ def test_config5_forty_million_points_eight_way_partition():
     acc = torch.full((1, n), float("nan"), dtype=torch.float64, device="cuda")
     tmp = torch.zeros_like(w)
     owned = 0
+    # the split upward pass: every share anterpolates its own subtree (+ halo); the sum of the partial coarse
+    # multipoles is what the all-reduce delivers
+    total = None
+    for rank in range(8):
+        t.set_partition(rank, 8)
+        c = torch.zeros((1, t.partition_coarse_count()), dtype=torch.float64, device="cuda")
+        t.matvec_partition_upward(w.data_ptr(), n, 1, c.data_ptr())
+        torch.cuda.synchronize()
+        total = c if total is None else total + c
+    assert total.numel() == 4681 * 352                                  # levels 0..4 of the uniform tree, n_pad = 352
+    scratch = torch.zeros_like(total)
     for rank in range(8):
         t.set_partition(rank, 8)
         rows = torch.from_numpy(t.partition_rows()).cuda()
         assert 0.08 * n < rows.numel() < 0.18 * n                       # balanced shares
         tmp.zero_()
-        t.matvec_device(w.data_ptr(), n, 1, tmp.data_ptr(), n, True)
+        t.matvec_partition_upward(w.data_ptr(), n, 1, scratch.data_ptr())
+        t.matvec_partition_finish(total.data_ptr(), tmp.data_ptr(), n, True)
         acc[:, rows] = tmp[:, rows]
         owned += rows.numel()
         del rows

@@ -53,5 +53,33 @@ def test_single_rank_rccl_exchange_matches_unpartitioned():
             idx = torch.as_tensor(rws, device=dev)
             full[:, idx] = o[:, idx]
         assert (full - ref).abs().max() / ref.abs().max() < 1e-12
+        # the split upward pass: every rank's partial coarse multipoles summed (what the all-reduce does), then
+        # every rank's downward + leaf pass on the sum -- ranks run in turn on the one GPU, worlds 2 and 5
+        for world in (2, 5):
+            partial = []
+            for r in range(world):
+                tree.set_partition(r, world)
+                cnt = tree.partition_coarse_count()
+                assert cnt > 0
+                c = torch.zeros((K, cnt), dtype=torch.float64, device=dev)
+                tree.matvec_partition_upward(w.data_ptr(), n, K, c.data_ptr())
+                torch.cuda.synchronize()
+                stream.synchronize()
+                partial.append(c)
+            total = torch.stack(partial).sum(0).contiguous()
+            dist.all_reduce(total)                                   # one-rank RCCL group: the collective itself runs
+            torch.cuda.synchronize()
+            full = torch.full_like(w, float("nan"))
+            for r in range(world):
+                tree.set_partition(r, world)
+                scratch = torch.zeros_like(total)
+                tree.matvec_partition_upward(w.data_ptr(), n, K, scratch.data_ptr())   # this rank's fine levels again
+                o = torch.zeros_like(w)
+                tree.matvec_partition_finish(total.data_ptr(), o.data_ptr(), n, True)
+                idx = torch.as_tensor(tree.partition_rows(), device=dev)
+                full[:, idx] = o[:, idx]
+            assert not torch.isnan(full).any()
+            assert (full - ref).abs().max() / ref.abs().max() < 1e-12, world
+        tree.set_partition(0, 1)
     finally:
         dist.destroy_process_group()

@@ -20,15 +20,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.timeout(900)
-def test_two_processes_partitioned_matvec_and_exchange_equal_the_single_rank_product():
+def _run_two_ranks(backend):
     n, k, world = 130000, 2, 2
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(n), str(k)],
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "two_rank_worker.py"), str(n), str(k), backend],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE))
     res = []
     for p in procs:
@@ -39,7 +38,23 @@ def test_two_processes_partitioned_matvec_and_exchange_equal_the_single_rank_pro
     assert all(r["cover"] and not r["nan_left"] for r in res), res
     assert sum(r["owned"] for r in res) == n and all(0 < r["owned"] < n for r in res), res
     assert all(r["n_w"] > 0 for r in res)                      # mixed-level tree: M2P / P2L run partitioned too
+    assert all(r["coarse_count"] > 0 for r in res)             # the upward pass really was split and exchanged
     assert all(r["err"] < 1e-12 for r in res), res
+
+
+@pytest.mark.timeout(900)
+def test_two_processes_partitioned_matvec_and_exchange_equal_the_single_rank_product():
+    _run_two_ranks("gloo")
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_over_rccl_one_gpu_each():
+    """The same two-rank product with the collectives on RCCL (all-reduce of the coarse multipoles, all-gather of the
+    owned rows), one GPU per rank: runs on the first box that has two GPUs."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL refuses two ranks on one device)")
+    _run_two_ranks("nccl")
 
 
 @pytest.mark.timeout(900)
