@@ -37,7 +37,9 @@ class TreeStats(ctypes.Structure):
                 ("n_u", c_i64), ("n_v", c_i64), ("n_w", c_i64), ("n_x", c_i64),
                 ("p2p_pairs", c_i64), ("p2p_tile_bytes_k1", c_i64), ("m2l_flops_k1", c_f64),
                 ("center", c_f64 * 3), ("radius", c_f64), ("wx_pairs", c_i64), ("wx_tile_bytes_k1", c_i64),
-                ("m2l_basis_rank", c_i32), ("m2l_basis_len", c_i32)]
+                ("m2l_basis_rank", c_i32), ("m2l_basis_len", c_i32),
+                ("m2l_batches", c_i32), ("m2l_rhs_per_pass", c_i32), ("m2l_slots_bytes_per_rhs", c_i64),
+                ("m2l_intermediate_bytes", c_i64)]
 
 
 # every symbol include/ferreus_bbfmm_hip.h declares: name -> (restype, argtypes)

@@ -1925,6 +1925,23 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
     m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, z, K, C, cbuf, cbuf_len, L, 0, qlist, ksplit > 1 ? ksplit : 0, tile_idx, s);
 }
 
+// Slot segments of absent pairs: 16 lanes per segment, 16 bytes per lane and round.
+__global__ __launch_bounds__(256) void m2l_zero_segments_kernel(const int32_t *__restrict__ segs, int64_t n_segs,
+                                                                double *__restrict__ cbuf, int64_t cbuf_len) {
+    const int64_t sg = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 4;
+    const int l = threadIdx.x & 15;
+    if (sg >= n_segs) return;
+    const int2 e = reinterpret_cast<const int2 *>(segs)[sg];
+    double2 *dst = reinterpret_cast<double2 *>(cbuf + static_cast<int64_t>(blockIdx.y) * cbuf_len) + e.x;
+    for (int i = l; i < e.y; i += 16) dst[i] = make_double2(0.0, 0.0);
+}
+
+void launch_m2l_zero_segments(const int32_t *segs, int64_t n_segs, int K, double *cbuf, int64_t cbuf_len, hipStream_t s) {
+    if (n_segs <= 0) return;
+    hipLaunchKernelGGL(m2l_zero_segments_kernel, dim3(static_cast<unsigned>((n_segs * 16 + 255) / 256), K), dim3(256), 0, s, segs,
+                       n_segs, cbuf, cbuf_len);
+}
+
 // Shared-basis extension: change of basis of every cell of a level (stage 3 of the GEMM kernel), OUT[cell][0..out_ld) =
 // sum_k IN[cell][k] * OP_level[k][0..out_ld).  classes[].cells / u_all: the level's cells and its in_ld x out_ld operator.
 void launch_m2l_basis(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int in_ld, int out_ld, int K,
@@ -2023,10 +2040,11 @@ void launch_m2l_assemble(const M2lAssembleClass &c, int n, int n_pad, bool compr
     (void)hipMemsetAsync(vt_all, 0, static_cast<size_t>(n_pad) * c.r_pad16 * sizeof(double), s);
     (void)hipMemsetAsync(u_all, 0, static_cast<size_t>(c.k_pad) * n_pad * sizeof(double), s);
     if (c.n_src > 0)
-        hipLaunchKernelGGL(assemble_vt_kernel, dim3(grid_for(static_cast<int64_t>(c.n_src) * n, 256)), dim3(256), 0, s, c, n, n_pad,
+        // (one thread per entry, no grid-stride loop: the exact block count, not grid_for's capped one)
+        hipLaunchKernelGGL(assemble_vt_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(c.n_src) * n + 255) / 256)), dim3(256), 0, s, c, n, n_pad,
                            compressed ? 1 : 0, ops, invperm, vt_all);
     if (c.n_tgt > 0 && c.max_rank > 0)
-        hipLaunchKernelGGL(assemble_u_kernel, dim3(grid_for(static_cast<int64_t>(c.max_rank) * n, 256), c.n_tgt), dim3(256), 0, s, c,
+        hipLaunchKernelGGL(assemble_u_kernel, dim3(static_cast<unsigned>((static_cast<int64_t>(c.max_rank) * n + 255) / 256), c.n_tgt), dim3(256), 0, s, c,
                            n, n_pad, ops, invperm, u_all);
 }
 

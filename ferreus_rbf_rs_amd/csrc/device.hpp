@@ -94,6 +94,8 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
                        const uint16_t *qlist, double *L, hipStream_t s, bool allow_ksplit = true);
+// Zeroes the slot segments of absent V pairs of a batch: segs = (slot / 2, length / 2) pairs, K buffers of cbuf_len.
+void launch_m2l_zero_segments(const int32_t *segs, int64_t n_segs, int K, double *cbuf, int64_t cbuf_len, hipStream_t s);
 // shared-basis extension: per-cell change of basis (OUT[cell] = IN[cell] * OP_level), setup-time dense product
 void launch_m2l_basis(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int in_ld, int out_ld, int K,
                       int64_t C, const double *in, double *out, hipStream_t s);

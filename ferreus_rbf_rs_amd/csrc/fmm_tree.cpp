@@ -536,10 +536,18 @@ int FmmTree::build_m2l_tables() {
     m2l_classes_h_.clear();
     m2l_tiles_h_.clear();
     m2l_qlist_h_.clear();
-    cbuf_len_ = 0;
+    m2l_batches_.clear();
+    m2l_batch_of_class_.clear();
+    m2l_group_ops_.clear();
+    cbuf_batch_len_ = 0;
+    cbuf_total_len_ = 0;
     m2l_flops_k1_ = 0;
     m2l_flops_level_.clear();
     if (t.depth < 2) return BBFMM_OK;
+    if (const char *e = std::getenv("BBFMM_M2L_CBUF_MB")) { // read per handle (tests vary it inside one process)
+        const double mb = std::atof(e); // fractions allowed (the CPU tests cut small trees into groups)
+        if (mb > 0) m2l_budget_bytes_ = static_cast<int64_t>(mb * 1048576.0);
+    }
 
     auto comp = [&](int tv, int a) { return ops_.all_vecs[static_cast<size_t>(tv) * d + a]; };
     auto far = [&](int tv) {
@@ -578,22 +586,82 @@ int FmmTree::build_m2l_tables() {
     };
 
     std::vector<int32_t> pos_in_class(t.n_cells(), -1);
-    int64_t cbuf_cursor = 0;
     int64_t bad_pairs = 0;
-    for (int level = 2; level <= t.depth; ++level) {
+    // slot layout of a target of class o at `level`: one segment per admissible transfer vector
+    auto slot_layout = [&](int level, std::vector<std::vector<int>> *off_tgt, std::vector<int> *k_pad) {
         const auto &lops = ops_.m2l[level];
-        auto rank_of = [&](int tv) { return lops[ops_.ref_lookup[tv]].rank; };
-        // slot layout of a target of class o
-        std::vector<std::vector<int>> off_tgt(ncls);
-        std::vector<int> k_pad(ncls, 0);
+        off_tgt->assign(ncls, {});
+        k_pad->assign(ncls, 0);
         for (int o = 0; o < ncls; ++o) {
             int off = 0;
             for (int tv : tgt_list[o]) {
-                off_tgt[o].push_back(off);
-                off += round_up(rank_of(tv), 2); // 16-byte aligned segments
+                (*off_tgt)[o].push_back(off);
+                off += round_up(lops[ops_.ref_lookup[tv]].rank, 2); // 16-byte aligned segments
             }
-            k_pad[o] = round_up(std::max(off, 16), 16);
+            (*k_pad)[o] = round_up(std::max(off, 16), 16);
         }
+    };
+    // ---- batches.  The slots of all targets (one per cell, sum_t r_t doubles: 37 KB at order 7) are what the two
+    // stages exchange -- 10.9 GB per right-hand side at 10M points, 76 GB for the finest level of an 80M-point tree.
+    // They go through one buffer of at most m2l_budget_bytes_: consecutive levels share a batch while they fit; a
+    // level that does not fit alone is cut into 2, 4 or 8 groups of target classes, and the sources of that level
+    // get one stacked stage-1 operator per group (the transfer vectors that end in the group's classes: the same
+    // tables over fewer transfer vectors, like the boundary variants below).
+    std::vector<int> level_groups(static_cast<size_t>(t.depth) + 1, 1);
+    std::vector<std::vector<int>> batch_of(static_cast<size_t>(t.depth) + 1, std::vector<int>(ncls, -1));
+    {
+        const int64_t budget = std::max<int64_t>(m2l_budget_bytes_ / 8 - 128, 1);
+        std::vector<std::vector<int64_t>> class_len(static_cast<size_t>(t.depth) + 1, std::vector<int64_t>(ncls, 0));
+        for (int level = 2; level <= t.depth; ++level) {
+            std::vector<std::vector<int>> off_tgt;
+            std::vector<int> k_pad;
+            slot_layout(level, &off_tgt, &k_pad);
+            for (int64_t c = t.level_ptr[level]; c < t.level_ptr[level + 1]; ++c) class_len[level][t.octant[c]] += k_pad[t.octant[c]];
+        }
+        int64_t cur_len = 0;
+        for (int level = 2; level <= t.depth; ++level) {
+            int64_t len = 0;
+            for (int64_t v : class_len[level]) len += v;
+            cbuf_total_len_ += len;
+            int G = 1;
+            if (len > budget)
+                for (G = 2; G < ncls; G *= 2) {
+                    int64_t worst = 0;
+                    for (int g = 0; g < G; ++g) {
+                        int64_t gl = 0;
+                        for (int o = g * ncls / G; o < (g + 1) * ncls / G; ++o) gl += class_len[level][o];
+                        worst = std::max(worst, gl);
+                    }
+                    if (worst <= budget) break;
+                }
+            G = std::min(G, ncls);
+            level_groups[level] = G;
+            if (G == 1 && !m2l_batches_.empty() && m2l_batches_.back().groups == 1 && cur_len + len <= budget) {
+                m2l_batches_.back().level_hi = level; // shares the batch of the level above
+                cur_len += len;
+                for (int o = 0; o < ncls; ++o) batch_of[level][o] = static_cast<int>(m2l_batches_.size()) - 1;
+                continue;
+            }
+            for (int g = 0; g < G; ++g) {
+                M2lBatch b;
+                b.level_lo = b.level_hi = level;
+                b.groups = G;
+                b.group = g;
+                for (int o = g * ncls / G; o < (g + 1) * ncls / G; ++o) batch_of[level][o] = static_cast<int>(m2l_batches_.size());
+                m2l_batches_.push_back(b);
+            }
+            cur_len = len;
+        }
+    }
+    std::vector<std::vector<M2lTileDesc>> tiles1_of_batch(m2l_batches_.size());
+    std::vector<int32_t> variant_batch; // batch of every entry of m2l_variants_
+    std::vector<std::vector<int32_t>> zero_of_batch(m2l_batches_.size()); // (slot / 2, length / 2) of the absent pairs' segments
+    for (int level = 2; level <= t.depth; ++level) {
+        const auto &lops = ops_.m2l[level];
+        auto rank_of = [&](int tv) { return lops[ops_.ref_lookup[tv]].rank; };
+        std::vector<std::vector<int>> off_tgt;
+        std::vector<int> k_pad;
+        slot_layout(level, &off_tgt, &k_pad);
         const size_t first_class = m2l_host_.size();
         // Stage-1 row tables of a class-o operator stacked over the transfer vectors `tvs` (the whole admissible
         // list for the class itself, the present ones for a boundary variant): every transfer vector's rows
@@ -645,6 +713,7 @@ int FmmTree::build_m2l_tables() {
             return true;
         };
         m2l_host_.resize(first_class + ncls);
+        m2l_group_ops_.resize(first_class + ncls);
         for (int64_t c = t.level_ptr[level]; c < t.level_ptr[level + 1]; ++c)
             m2l_host_[first_class + t.octant[c]].cells.push_back(static_cast<int32_t>(c));
         // Order the cells of a class by their V-list pattern (complete lists first, equal patterns
@@ -687,9 +756,10 @@ int FmmTree::build_m2l_tables() {
             hc.tgt_off = off_tgt[o];
             if (host_only_) fill_m2l_operator_arrays(hc, &hc.vt_all, &hc.u_all);
             hc.cbase.resize(hc.cells.size());
+            int64_t &cursor = m2l_batches_[static_cast<size_t>(batch_of[level][o])].len; // slot addresses are relative to the batch
             for (size_t i = 0; i < hc.cells.size(); ++i) {
-                hc.cbase[i] = cbuf_cursor;
-                cbuf_cursor += hc.k_pad;
+                hc.cbase[i] = cursor;
+                cursor += hc.k_pad;
             }
             hc.cslot.resize(hc.cells.size() * static_cast<size_t>(hc.n_t));
             {
@@ -737,6 +807,29 @@ int FmmTree::build_m2l_tables() {
             m2l_flops_level_[static_cast<size_t>(level)] = level_flops;
             for (int64_t b : bad_part) bad_pairs += b;
         }
+        // Batches share one buffer, so a slot segment whose pair does not exist (domain boundary, coarser neighbour)
+        // holds another batch's values when stage 2 reads it: such segments are zeroed before every pass
+        // (launch_m2l_zero_segments).  A single batch keeps the zeros the buffer was allocated with.
+        if (m2l_batches_.size() > 1)
+            for (int o = 0; o < ncls; ++o) {
+                const HostM2lClass &hc = m2l_host_[first_class + o];
+                std::vector<int32_t> &zs = zero_of_batch[static_cast<size_t>(batch_of[level][o])];
+                std::vector<uint8_t> present(tgt_list[o].size());
+                for (size_t i = 0; i < hc.cells.size(); ++i) {
+                    const int64_t B = hc.cells[i];
+                    std::fill(present.begin(), present.end(), uint8_t(0));
+                    for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
+                        const int tv = t.v_tidx[q];
+                        const int pos = tv >= 0 && tv < nvec ? tpos_tgt[o][tv] : -1;
+                        if (pos >= 0) present[static_cast<size_t>(pos)] = 1;
+                    }
+                    for (size_t pos = 0; pos < present.size(); ++pos)
+                        if (!present[pos]) {
+                            zs.push_back(static_cast<int32_t>((hc.cbase[i] + off_tgt[o][pos]) / 2));
+                            zs.push_back(round_up(rank_of(tgt_list[o][pos]), 2) / 2);
+                        }
+                }
+            }
         for (int o = 0; o < ncls; ++o) {
             const HostM2lClass &hc = m2l_host_[first_class + o];
             const int nq = hc.k_pad / 16;
@@ -785,12 +878,64 @@ int FmmTree::build_m2l_tables() {
             const char *e = std::getenv("BBFMM_M2L_VARIANTS");
             return e ? std::atoi(e) : 4;
         }();
-        const bool variants_on = variant_min_tiles > 0;
-        for (int o = 0; o < ncls; ++o) {
+        const int G = level_groups[level];
+        const bool variants_on = variant_min_tiles > 0 && G == 1;
+        // A level cut into groups of target classes: per (group, source class) one stacked operator over the transfer
+        // vectors whose targets lie in the group, all cells of the class as its tiles.
+        for (int g = 0; g < G && G > 1; ++g) {
+            const int o_lo = g * ncls / G, o_hi = (g + 1) * ncls / G;
+            for (int o = 0; o < ncls; ++o) {
+                const HostM2lClass &hc = m2l_host_[first_class + o];
+                const size_t nc = hc.cells.size();
+                if (nc == 0) continue;
+                const int nt = hc.n_t;
+                std::vector<int> tvs, keep;
+                for (int ps = 0; ps < nt; ++ps) {
+                    const int oc = target_class(o, hc.src_tv[ps]);
+                    if (oc >= o_lo && oc < o_hi) {
+                        tvs.push_back(hc.src_tv[ps]);
+                        keep.push_back(ps);
+                    }
+                }
+                if (tvs.empty()) continue;
+                HostM2lClass v;
+                v.level = level;
+                v.octant = o;
+                v.k_pad = 16;
+                if (!stage1_rows(o, tvs, &v)) return fail(BBFMM_BAD_ARGUMENT, "M2L slot too long for the packed row table");
+                v.cells = hc.cells;
+                v.cslot.resize(nc * tvs.size());
+                {
+                    int32_t *dst = v.cslot.data();
+                    const int32_t *src = hc.cslot.data();
+                    const size_t nk = keep.size();
+                    parallel_for_chunks(static_cast<int64_t>(nc), 4096, [&](int64_t lo, int64_t hi) {
+                        for (int64_t k = lo; k < hi; ++k)
+                            for (size_t q = 0; q < nk; ++q) dst[static_cast<size_t>(k) * nk + q] = src[static_cast<size_t>(k) * nt + keep[q]];
+                    });
+                }
+                const int bidx = batch_of[level][o_lo];
+                for (size_t f = 0; f < nc; f += kM2lTile) {
+                    M2lTileDesc td;
+                    std::memset(&td, 0, sizeof td);
+                    td.level_class = -1 - static_cast<int32_t>(m2l_variants_.size()); // fixed up below
+                    td.first = static_cast<int32_t>(f);
+                    td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, nc - f));
+                    td.pad = 0;
+                    tiles1_of_batch[static_cast<size_t>(bidx)].push_back(td);
+                }
+                if (host_only_) fill_m2l_operator_arrays(v, &v.vt_all, &v.u_all);
+                m2l_group_ops_[first_class + o].push_back(static_cast<int32_t>(m2l_variants_.size()));
+                variant_batch.push_back(bidx);
+                m2l_variants_.push_back(std::move(v));
+            }
+        }
+        for (int o = 0; o < ncls && G == 1; ++o) {
             const HostM2lClass &hc = m2l_host_[first_class + o];
             const size_t nc = hc.cells.size();
             if (nc == 0) continue;
             const int nt = hc.n_t;
+            std::vector<M2lTileDesc> &tiles1_out = tiles1_of_batch[static_cast<size_t>(batch_of[level][o])];
             // pattern signature per cell (which targets exist)
             std::vector<uint64_t> sig(nc);
             parallel_for(static_cast<int64_t>(nc), 256, [&](int64_t i) {
@@ -850,9 +995,10 @@ int FmmTree::build_m2l_tables() {
                             td.first = static_cast<int32_t>(f);
                             td.count = kM2lTile;
                             td.pad = 0;
-                            m2l_tiles1_h_.push_back(td);
+                            tiles1_out.push_back(td);
                         }
                         if (host_only_) fill_m2l_operator_arrays(v, &v.vt_all, &v.u_all);
+                        variant_batch.push_back(batch_of[level][o]);
                         m2l_variants_.push_back(std::move(v));
                     }
                 }
@@ -866,7 +1012,7 @@ int FmmTree::build_m2l_tables() {
                 td.first = static_cast<int32_t>(m2l_tile_idx1_h_.size() + f);
                 td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, rest.size() - f));
                 td.pad = 1; // first indexes the position list
-                m2l_tiles1_h_.push_back(td);
+                tiles1_out.push_back(td);
             }
             m2l_tile_idx1_h_.insert(m2l_tile_idx1_h_.end(), rest.begin(), rest.end());
         }
@@ -874,10 +1020,44 @@ int FmmTree::build_m2l_tables() {
     if (bad_pairs > 0)
         return fail(BBFMM_UNSUPPORTED,
                     "V-list pairs outside the admissible transfer-vector set (source points outside the root box?)");
-    for (M2lTileDesc &td : m2l_tiles1_h_) // variant classes follow the level classes in the device table
-        if (td.level_class < 0) td.level_class = static_cast<int32_t>(m2l_host_.size()) + (-1 - td.level_class);
-    cbuf_len_ = cbuf_cursor + 128; // + dump area for the branch-free stage-1 scatter (never read)
-    if (cbuf_len_ / 2 >= (int64_t(1) << 31)) return fail(BBFMM_UNSUPPORTED, "M2L intermediate buffer too large");
+    // device class table: level classes, then variants / group operators; every entry works for one batch
+    m2l_batch_of_class_.assign(m2l_host_.size() + m2l_variants_.size(), 0);
+    for (size_t lc = 0; lc < m2l_host_.size(); ++lc)
+        m2l_batch_of_class_[lc] = batch_of[static_cast<size_t>(m2l_host_[lc].level)][static_cast<size_t>(m2l_host_[lc].octant)];
+    for (size_t v = 0; v < m2l_variants_.size(); ++v) m2l_batch_of_class_[m2l_host_.size() + v] = variant_batch[v];
+    // launch lists, batch by batch: stage 1 from the per-batch lists, stage 2 = the class tiles (classes of a batch
+    // are consecutive) with the tail of every batch split
+    m2l_tiles2_h_.clear();
+    {
+        size_t next = 0;
+        for (size_t b = 0; b < m2l_batches_.size(); ++b) {
+            M2lBatch &mb = m2l_batches_[b];
+            mb.t1_first = static_cast<int32_t>(m2l_tiles1_h_.size());
+            for (M2lTileDesc td : tiles1_of_batch[b]) {
+                if (td.level_class < 0) td.level_class = static_cast<int32_t>(m2l_host_.size()) + (-1 - td.level_class);
+                m2l_tiles1_h_.push_back(td);
+            }
+            mb.t1_count = static_cast<int32_t>(m2l_tiles1_h_.size()) - mb.t1_first;
+            std::vector<M2lTileDesc> part;
+            while (next < m2l_tiles_h_.size() && m2l_batch_of_class_[static_cast<size_t>(m2l_tiles_h_[next].level_class)] == static_cast<int32_t>(b))
+                part.push_back(m2l_tiles_h_[next++]);
+            split_tile_tail(&part, n_cu_);
+            mb.t2_first = static_cast<int32_t>(m2l_tiles2_h_.size());
+            mb.t2_count = static_cast<int32_t>(part.size());
+            m2l_tiles2_h_.insert(m2l_tiles2_h_.end(), part.begin(), part.end());
+            cbuf_batch_len_ = std::max(cbuf_batch_len_, mb.len);
+        }
+        if (next != m2l_tiles_h_.size()) return fail(BBFMM_DEVICE_ERROR, "internal: M2L tiles out of batch order");
+    }
+    m2l_zero_h_.clear();
+    m2l_zero_ptr_.assign(m2l_batches_.size() + 1, 0);
+    for (size_t b = 0; b < m2l_batches_.size(); ++b) {
+        m2l_zero_h_.insert(m2l_zero_h_.end(), zero_of_batch[b].begin(), zero_of_batch[b].end());
+        m2l_zero_ptr_[b + 1] = static_cast<int64_t>(m2l_zero_h_.size() / 2);
+    }
+    cbuf_batch_len_ += 128; // + dump area for the branch-free stage-1 scatter (never read)
+    if (cbuf_batch_len_ / 2 >= (int64_t(1) << 31))
+        return fail(BBFMM_UNSUPPORTED, "M2L intermediate buffer of one batch too large (raise the number of groups: lower BBFMM_M2L_CBUF_MB)");
     return BBFMM_OK;
 }
 
@@ -1099,9 +1279,9 @@ int FmmTree::upload() {
     CHK(dupload(&d_m2l_tiles_, m2l_tiles_h_));
     CHK(dupload(&d_m2l_tiles1_, m2l_tiles1_h_));
     CHK(dupload(&d_tile_idx1_, m2l_tile_idx1_h_));
-    m2l_tiles2_h_ = m2l_tiles_h_;
-    split_tile_tail(&m2l_tiles2_h_, n_cu_);
     CHK(dupload(&d_m2l_tiles2_, m2l_tiles2_h_));
+    CHK(dupload(&d_m2l_zero_, m2l_zero_h_));
+    decltype(m2l_zero_h_)().swap(m2l_zero_h_);
     CHK(dupload(&d_m2l_qlist_, m2l_qlist_h_));
     std::vector<uint8_t> act(static_cast<size_t>(C), 1);
     CHK(dupload(&d_active_, act));
@@ -1406,7 +1586,9 @@ int FmmTree::ensure_rhs_capacity(int k) {
         CHK(dalloc(&d_Mc_, static_cast<size_t>(k) * C * basis_pad_, true));
         CHK(dalloc(&d_Lc_, static_cast<size_t>(k) * C * basis_pad_, true));
     }
-    CHK(dalloc(&d_cbuf_, static_cast<size_t>(k) * std::max<int64_t>(cbuf_len_, 1), true)); // absent pairs stay 0
+    // the M2L intermediate: as many right-hand sides per pass as fit the budget (at least one); absent pairs stay 0
+    m2l_rhs_chunk_ = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(k, m2l_budget_bytes_ / 8 / std::max<int64_t>(cbuf_batch_len_, 1))));
+    CHK(dalloc(&d_cbuf_, static_cast<size_t>(m2l_rhs_chunk_) * std::max<int64_t>(cbuf_batch_len_, 1), true));
     CHK(dalloc(&d_out_, static_cast<size_t>(k) * N));
     CHK(dalloc(&src_targets_.out, static_cast<size_t>(k) * N));
     k_cap_ = k;
@@ -1860,28 +2042,51 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     const int m2l_len = shared_basis_ ? basis_pad_ : cheb_.n_pad;
     const double *m_in = shared_basis_ ? d_Mc_.p : d_M_.p;
     double *l_out = shared_basis_ ? d_Lc_.p : d_L_.p;
-    phase_begin();
     if (shared_basis_) { // coordinates of every multipole in its level's basis; stage 2 leaves untouched tiles at 0
+        phase_begin();
         launch_m2l_basis(d_basis_classes_.p, d_basis_tiles_c_.p, n_basis_tiles_, cheb_.n_pad, basis_pad_, k, C, d_M_.p, d_Mc_.p, stream_);
         HIPCHK(hipMemsetAsync(d_Lc_.p, 0, static_cast<size_t>(k) * C * basis_pad_ * sizeof(double), stream_));
+        phase_end(kPhM2L1);
     }
-    if (dp)
-        launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles1_h.size()),
-                          m2l_len, m2l_slot_t_, k, C, m_in, d_cbuf_.p, cbuf_len_, stream_, dp->tiles1_own_blocks);
-    else
-        launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p, d_tile_idx1_.p, static_cast<int>(m2l_tiles1_h_.size()), m2l_len,
-                          m2l_slot_t_, k, C, m_in, d_cbuf_.p, cbuf_len_, stream_);
-    phase_end(kPhM2L1);
-    phase_begin();
-    if (dp)
-        launch_m2l_stage2(d_m2l_classes_.p, dp->d_tiles2.p, dp->d_tile_idx.p, static_cast<int>(dp->tiles2_h.size()),
-                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, dp->d_qlist.p, l_out, stream_, !deterministic_);
-    else
-        launch_m2l_stage2(d_m2l_classes_.p, d_m2l_tiles2_.p, nullptr, static_cast<int>(m2l_tiles2_h_.size()),
-                          m2l_len, k, C, d_cbuf_.p, cbuf_len_, d_m2l_qlist_.p, l_out, stream_, !deterministic_);
-    if (shared_basis_) // back to the node values (every cell of level >= 2; cells above keep the zeros)
+    // The batches go through the bounded intermediate one after another (stage 1 fills the slots of the batch's
+    // targets, stage 2 contracts them into L), m2l_rhs_chunk_ right-hand sides per pass.
+    const int nb = static_cast<int>(m2l_batches_.size());
+    for (int k0 = 0; k0 < k; k0 += m2l_rhs_chunk_) {
+        const int kb = std::min(m2l_rhs_chunk_, k - k0);
+        const double *m_chunk = m_in + static_cast<size_t>(k0) * C * m2l_len;
+        double *l_chunk = l_out + static_cast<size_t>(k0) * C * m2l_len;
+        for (int b = 0; b < nb; ++b) {
+            const M2lBatch &mb = m2l_batches_[static_cast<size_t>(b)];
+            const int t1_first = dp ? dp->batch_t1[2 * b] : mb.t1_first, t1_count = dp ? dp->batch_t1[2 * b + 1] : mb.t1_count;
+            const int t2_first = dp ? dp->batch_t2[2 * b] : mb.t2_first, t2_count = dp ? dp->batch_t2[2 * b + 1] : mb.t2_count;
+            if (t2_count == 0) continue; // no target of this batch is active: nobody reads its slots
+            phase_begin();
+            if (nb > 1)
+                launch_m2l_zero_segments(d_m2l_zero_.p + 2 * m2l_zero_ptr_[static_cast<size_t>(b)],
+                                         m2l_zero_ptr_[static_cast<size_t>(b) + 1] - m2l_zero_ptr_[static_cast<size_t>(b)], kb, d_cbuf_.p,
+                                         cbuf_batch_len_, stream_);
+            if (dp)
+                launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p + t1_first, dp->d_tile_idx.p, t1_count, m2l_len, m2l_slot_t_, kb,
+                                  C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, dp->tiles1_own_blocks);
+            else
+                launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p + t1_first, d_tile_idx1_.p, t1_count, m2l_len, m2l_slot_t_, kb, C,
+                                  m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_);
+            phase_end(kPhM2L1);
+            phase_begin();
+            if (dp)
+                launch_m2l_stage2(d_m2l_classes_.p, dp->d_tiles2.p + t2_first, dp->d_tile_idx.p, t2_count, m2l_len, kb, C, d_cbuf_.p,
+                                  cbuf_batch_len_, dp->d_qlist.p, l_chunk, stream_, !deterministic_);
+            else
+                launch_m2l_stage2(d_m2l_classes_.p, d_m2l_tiles2_.p + t2_first, nullptr, t2_count, m2l_len, kb, C, d_cbuf_.p,
+                                  cbuf_batch_len_, d_m2l_qlist_.p, l_chunk, stream_, !deterministic_);
+            phase_end(kPhM2L2);
+        }
+    }
+    if (shared_basis_) { // back to the node values (every cell of level >= 2; cells above keep the zeros)
+        phase_begin();
         launch_m2l_basis(d_basis_classes_.p, d_basis_tiles_e_.p, n_basis_tiles_, basis_pad_, cheb_.n_pad, k, C, d_Lc_.p, d_L_.p, stream_);
-    phase_end(kPhM2L2);
+        phase_end(kPhM2L2);
+    }
     phase_begin();
     if (t.adaptive && wx) { // targets = all sources, one rhs: P2L and M2P share their kernel evaluations (X = W^T)
         launch_wx_sym(kernel_, cheb_, wx->n_wx_jobs, wx->wx_tb.p, wx->wx_te.p, wx->wx_range.p, d_w_idx_.p, d_centers_.p,
@@ -2322,48 +2527,89 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         }
     }
     const std::vector<uint8_t> &active = dp->active;
+    // class and position of every cell with M2L work; group of its class inside its level's batches
+    std::vector<int32_t> cls_of(static_cast<size_t>(C), -1), pos_of(static_cast<size_t>(C), -1);
+    for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+        const HostM2lClass &hc = m2l_host_[lc];
+        for (size_t i = 0; i < hc.cells.size(); ++i) {
+            cls_of[hc.cells[i]] = static_cast<int32_t>(lc);
+            pos_of[hc.cells[i]] = static_cast<int32_t>(i);
+        }
+    }
+    auto group_of_class = [&](int32_t lc) { return m2l_batches_[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(lc)])].group; };
+    // needed[V]: V is a V-list source of an active cell; bit g: of an active cell whose class lies in group g of the level
     std::vector<uint8_t> needed(static_cast<size_t>(C), 0);
     auto flag = [](uint8_t *p) { __atomic_store_n(p, uint8_t(1), __ATOMIC_RELAXED); }; // threads may set the same flag
     parallel_for_chunks(C, 4096, [&](int64_t lo, int64_t hi) {
         for (int64_t B = lo; B < hi; ++B) {
-            if (!active[B] || t.level[B] < 2) continue;
-            for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) flag(&needed[t.v.idx[q]]);
+            if (!active[B] || t.level[B] < 2 || cls_of[B] < 0) continue;
+            const uint8_t bit = static_cast<uint8_t>(1u << group_of_class(cls_of[B]));
+            for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) __atomic_fetch_or(&needed[t.v.idx[q]], bit, __ATOMIC_RELAXED);
         }
     });
     dp->tiles2_h.clear();
     dp->tiles1_h.clear();
     dp->tile_idx_h.clear();
     dp->qlist_h.clear();
+    const size_t nb = m2l_batches_.size();
+    std::vector<std::vector<M2lTileDesc>> t1b(nb), t2b(nb);
+    // stage-1 source operators a plan uses: the class operator, or -- on a level cut into groups -- the group operators
+    struct SrcOp {
+        int32_t dev_class;
+        const HostM2lClass *h;
+        uint8_t bit;
+    };
+    std::vector<SrcOp> sops;
+    std::vector<std::vector<int32_t>> sops_of_class(m2l_host_.size());
+    for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+        if (m2l_host_[lc].cells.empty()) continue;
+        if (m2l_group_ops_[lc].empty()) {
+            sops_of_class[lc].push_back(static_cast<int32_t>(sops.size()));
+            sops.push_back(SrcOp{static_cast<int32_t>(lc), &m2l_host_[lc], uint8_t(0xff)});
+        } else {
+            // (a class whose transfer vectors miss a group has no operator for it: index by the operator's group)
+            sops_of_class[lc].assign(8, -1);
+            for (int32_t v : m2l_group_ops_[lc]) {
+                const int32_t dev = static_cast<int32_t>(m2l_host_.size()) + v;
+                const int g = m2l_batches_[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(dev)])].group;
+                sops_of_class[lc][static_cast<size_t>(g)] = static_cast<int32_t>(sops.size());
+                sops.push_back(SrcOp{dev, &m2l_variants_[static_cast<size_t>(v)], static_cast<uint8_t>(1u << g)});
+            }
+        }
+    }
+    auto add_tiles = [&](const std::vector<uint8_t> &flags, uint8_t bit, int32_t dev_class, const std::vector<int32_t> &cells,
+                         std::vector<M2lTileDesc> *tiles) {
+        const size_t start = dp->tile_idx_h.size();
+        for (size_t i = 0; i < cells.size(); ++i)
+            if (flags[cells[i]] & bit) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
+        for (size_t f = start; f < dp->tile_idx_h.size(); f += kM2lTile) {
+            M2lTileDesc td;
+            std::memset(&td, 0, sizeof td);
+            td.level_class = dev_class;
+            td.first = static_cast<int32_t>(f);
+            td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - f));
+            td.pad = 1; // first indexes tile_idx (class positions)
+            tiles->push_back(td);
+        }
+    };
+    for (const SrcOp &so : sops)
+        add_tiles(needed, so.bit, so.dev_class, so.h->cells, &t1b[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(so.dev_class)])]);
     std::vector<int> tpos_of(static_cast<size_t>(ops_.n_vec));
     for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
         const HostM2lClass &hc = m2l_host_[lc];
         if (hc.cells.empty()) continue;
-        auto add_tiles = [&](const std::vector<uint8_t> &flag, std::vector<M2lTileDesc> *tiles) {
-            const size_t start = dp->tile_idx_h.size();
-            for (size_t i = 0; i < hc.cells.size(); ++i)
-                if (flag[hc.cells[i]]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
-            for (size_t f = start; f < dp->tile_idx_h.size(); f += kM2lTile) {
-                M2lTileDesc td;
-                std::memset(&td, 0, sizeof td);
-                td.level_class = static_cast<int32_t>(lc);
-                td.first = static_cast<int32_t>(f);
-                td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - f));
-                td.pad = 1; // first indexes tile_idx (class positions)
-                tiles->push_back(td);
-            }
-        };
-        add_tiles(needed, &dp->tiles1_h);
-        const size_t t2 = dp->tiles2_h.size();
-        add_tiles(active, &dp->tiles2_h);
+        std::vector<M2lTileDesc> &tiles2 = t2b[static_cast<size_t>(m2l_batch_of_class_[lc])];
+        const size_t t2 = tiles2.size();
+        add_tiles(active, uint8_t(0xff), static_cast<int32_t>(lc), hc.cells, &tiles2);
         // contraction steps (16 slot entries each) that hold a V-list entry of some cell of the tile
         std::fill(tpos_of.begin(), tpos_of.end(), -1);
         for (size_t pos = 0; pos < hc.tgt_tv.size(); ++pos) tpos_of[hc.tgt_tv[pos]] = static_cast<int>(pos);
         const auto &lops = ops_.m2l[hc.level];
         const int nq = hc.k_pad / 16;
-        const int64_t n_t2 = static_cast<int64_t>(dp->tiles2_h.size() - t2);
+        const int64_t n_t2 = static_cast<int64_t>(tiles2.size() - t2);
         std::vector<std::vector<uint16_t>> tile_q(static_cast<size_t>(n_t2));
         parallel_for(n_t2, 4, [&](int64_t k) {
-            const M2lTileDesc &td = dp->tiles2_h[t2 + static_cast<size_t>(k)];
+            const M2lTileDesc &td = tiles2[t2 + static_cast<size_t>(k)];
             std::vector<uint8_t> act_k(static_cast<size_t>(nq), 0);
             for (int32_t i = 0; i < td.count; ++i) {
                 const int64_t B = hc.cells[dp->tile_idx_h[td.first + i]];
@@ -2379,59 +2625,56 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
                 if (act_k[sq]) tile_q[static_cast<size_t>(k)].push_back(static_cast<uint16_t>(sq));
         });
         for (int64_t k = 0; k < n_t2; ++k) {
-            M2lTileDesc &td = dp->tiles2_h[t2 + static_cast<size_t>(k)];
+            M2lTileDesc &td = tiles2[t2 + static_cast<size_t>(k)];
             td.q_first = static_cast<int32_t>(dp->qlist_h.size());
             dp->qlist_h.insert(dp->qlist_h.end(), tile_q[static_cast<size_t>(k)].begin(), tile_q[static_cast<size_t>(k)].end());
             td.q_count = static_cast<int32_t>(dp->qlist_h.size()) - td.q_first;
         }
     }
-    split_tile_tail(&dp->tiles2_h, n_cu_);
+    for (auto &tl : t2b) split_tile_tail(&tl, n_cu_);
     // Sparse target sets: a needed source cell still needs only the column blocks (kM2lS1Block stacked
     // rows = a few transfer vectors) that hold a transfer vector towards an ACTIVE target.  When that is
     // well under the whole operator, stage 1 runs one tile per (column block, the sources it needs).
     int64_t n_active = 0;
     for (uint8_t a : active) n_active += a;
+    dp->tiles1_own_blocks = false;
     if (n_active * 2 < C) { // (denser sets need nearly every block of every source: skip the analysis)
-        std::vector<int32_t> cls_of(static_cast<size_t>(C), -1), pos_of(static_cast<size_t>(C), -1);
-        std::vector<int64_t> bm_off(m2l_host_.size() + 1, 0); // per class: n_blk x n_cells flags
-        for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
-            const HostM2lClass &hc = m2l_host_[lc];
-            for (size_t i = 0; i < hc.cells.size(); ++i) {
-                cls_of[hc.cells[i]] = static_cast<int32_t>(lc);
-                pos_of[hc.cells[i]] = static_cast<int32_t>(i);
-            }
-            bm_off[lc + 1] = bm_off[lc] + static_cast<int64_t>(hc.r_pad16 / kM2lS1Block) * static_cast<int64_t>(hc.cells.size());
-        }
+        std::vector<int64_t> bm_off(sops.size() + 1, 0); // per source operator: n_blk x n_cells flags
+        for (size_t si = 0; si < sops.size(); ++si)
+            bm_off[si + 1] = bm_off[si] + static_cast<int64_t>(sops[si].h->r_pad16 / kM2lS1Block) * static_cast<int64_t>(sops[si].h->cells.size());
         std::vector<uint8_t> bm(static_cast<size_t>(bm_off.back()), 0);
-        std::vector<std::vector<int32_t>> spos(m2l_host_.size());
-        for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
-            spos[lc].assign(static_cast<size_t>(ops_.n_vec), -1);
-            for (size_t pos = 0; pos < m2l_host_[lc].src_tv.size(); ++pos) spos[lc][m2l_host_[lc].src_tv[pos]] = static_cast<int32_t>(pos);
+        std::vector<std::vector<int32_t>> spos(sops.size());
+        for (size_t si = 0; si < sops.size(); ++si) {
+            spos[si].assign(static_cast<size_t>(ops_.n_vec), -1);
+            for (size_t pos = 0; pos < sops[si].h->src_tv.size(); ++pos) spos[si][sops[si].h->src_tv[pos]] = static_cast<int32_t>(pos);
         }
         parallel_for_chunks(C, 4096, [&](int64_t lo, int64_t hi) {
             for (int64_t B = lo; B < hi; ++B) {
-                if (!active[B] || t.level[B] < 2) continue;
+                if (!active[B] || t.level[B] < 2 || cls_of[B] < 0) continue;
+                const int gB = group_of_class(cls_of[B]);
                 for (int64_t q = t.v.ptr[B]; q < t.v.ptr[B + 1]; ++q) {
                     const int32_t S = t.v.idx[q];
                     const int tv = t.v_tidx[q];
                     const int32_t lc = cls_of[S];
                     if (lc < 0 || tv < 0 || tv >= ops_.n_vec) continue;
-                    const int32_t sp = spos[lc][tv];
+                    const auto &cand = sops_of_class[static_cast<size_t>(lc)];
+                    const int32_t si = cand.size() == 1 ? cand[0] : cand[static_cast<size_t>(gB)];
+                    if (si < 0) continue;
+                    const int32_t sp = spos[static_cast<size_t>(si)][tv];
                     if (sp < 0) continue;
-                    const HostM2lClass &hc = m2l_host_[lc];
-                    if (hc.src_row1[sp] <= hc.src_row0[sp]) continue;
-                    const int64_t nc = static_cast<int64_t>(hc.cells.size());
-                    for (int zb = hc.src_row0[sp] / kM2lS1Block; zb <= (hc.src_row1[sp] - 1) / kM2lS1Block; ++zb)
-                        flag(&bm[static_cast<size_t>(bm_off[lc] + zb * nc + pos_of[S])]);
+                    const HostM2lClass &hs = *sops[static_cast<size_t>(si)].h;
+                    if (hs.src_row1[sp] <= hs.src_row0[sp]) continue;
+                    const int64_t nc = static_cast<int64_t>(hs.cells.size());
+                    for (int zb = hs.src_row0[sp] / kM2lS1Block; zb <= (hs.src_row1[sp] - 1) / kM2lS1Block; ++zb)
+                        flag(&bm[static_cast<size_t>(bm_off[static_cast<size_t>(si)] + zb * nc + pos_of[S])]);
                 }
             }
         });
         int64_t whole = 0, part = 0; // cell-blocks of work: needed cells x all blocks, against the flagged ones
-        for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
-            const HostM2lClass &hc = m2l_host_[lc];
+        for (const SrcOp &so : sops) {
             int64_t nn = 0;
-            for (int32_t c : hc.cells) nn += needed[c];
-            whole += nn * (hc.r_pad16 / kM2lS1Block);
+            for (int32_t c : so.h->cells) nn += (needed[c] & so.bit) ? 1 : 0;
+            whole += nn * (so.h->r_pad16 / kM2lS1Block);
         }
         for (uint8_t f : bm) part += f;
         static const double max_ratio = [] {
@@ -2440,29 +2683,40 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         }();
         dp->tiles1_own_blocks = whole > 0 && static_cast<double>(part) < max_ratio * static_cast<double>(whole);
         if (dp->tiles1_own_blocks) {
-            dp->tiles1_h.clear();
-            for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
-                const HostM2lClass &hc = m2l_host_[lc];
-                const int64_t nc = static_cast<int64_t>(hc.cells.size());
-                for (int zb = 0; zb < hc.r_pad16 / kM2lS1Block; ++zb) {
+            for (auto &tl : t1b) tl.clear();
+            for (size_t si = 0; si < sops.size(); ++si) {
+                const HostM2lClass &hs = *sops[si].h;
+                const int64_t nc = static_cast<int64_t>(hs.cells.size());
+                std::vector<M2lTileDesc> &out = t1b[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(sops[si].dev_class)])];
+                for (int zb = 0; zb < hs.r_pad16 / kM2lS1Block; ++zb) {
                     const size_t start = dp->tile_idx_h.size();
-                    const uint8_t *f = &bm[static_cast<size_t>(bm_off[lc] + zb * nc)];
+                    const uint8_t *f = &bm[static_cast<size_t>(bm_off[si] + zb * nc)];
                     for (int64_t i = 0; i < nc; ++i)
                         if (f[i]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
                     for (size_t fst = start; fst < dp->tile_idx_h.size(); fst += kM2lTile) {
                         M2lTileDesc td;
                         std::memset(&td, 0, sizeof td);
-                        td.level_class = static_cast<int32_t>(lc);
+                        td.level_class = sops[si].dev_class;
                         td.first = static_cast<int32_t>(fst);
                         td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - fst));
                         td.q_first = zb;
                         td.q_count = 1;
                         td.pad = 2;
-                        dp->tiles1_h.push_back(td);
+                        out.push_back(td);
                     }
                 }
             }
         }
+    }
+    dp->batch_t1.assign(2 * nb, 0);
+    dp->batch_t2.assign(2 * nb, 0);
+    for (size_t b = 0; b < nb; ++b) {
+        dp->batch_t1[2 * b] = static_cast<int32_t>(dp->tiles1_h.size());
+        dp->batch_t1[2 * b + 1] = static_cast<int32_t>(t1b[b].size());
+        dp->tiles1_h.insert(dp->tiles1_h.end(), t1b[b].begin(), t1b[b].end());
+        dp->batch_t2[2 * b] = static_cast<int32_t>(dp->tiles2_h.size());
+        dp->batch_t2[2 * b + 1] = static_cast<int32_t>(t2b[b].size());
+        dp->tiles2_h.insert(dp->tiles2_h.end(), t2b[b].begin(), t2b[b].end());
     }
     std::vector<int32_t> xc, xruns;
     std::vector<int64_t> xptr(1, 0);
@@ -2523,7 +2777,8 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         for (int level = 1; level < t.depth; ++level)
             for (int32_t c : m2m_parents_[level])
                 if (level <= Lc || up[c]) dp->up_parents_h[level].push_back(c); // coarse parents: all (partial sums, maybe zero)
-        dp->reads_h = needed;
+        dp->reads_h.assign(static_cast<size_t>(C), 0);
+        for (int64_t c = 0; c < C; ++c) dp->reads_h[static_cast<size_t>(c)] = needed[static_cast<size_t>(c)] ? 1 : 0;
         for (int32_t leaf : target_leaves)
             for (int64_t q = t.w.ptr[leaf]; q < t.w.ptr[leaf + 1]; ++q) dp->reads_h[t.w.idx[q]] = 1;
         // children lists: the parents of level Lc sum the children they own only
@@ -2810,6 +3065,10 @@ void FmmTree::stats(bbfmm_tree_stats *out) const {
     out->m2l_flops_k1 = m2l_flops_k1_;
     for (int r : basis_rank_) out->m2l_basis_rank = std::max<int32_t>(out->m2l_basis_rank, r);
     out->m2l_basis_len = shared_basis_ ? basis_pad_ : 0;
+    out->m2l_batches = static_cast<int32_t>(m2l_batches_.size());
+    out->m2l_rhs_per_pass = m2l_rhs_chunk_;
+    out->m2l_slots_bytes_per_rhs = cbuf_total_len_ * 8;
+    out->m2l_intermediate_bytes = static_cast<int64_t>(d_cbuf_.n) * 8;
     for (int a = 0; a < d_; ++a) out->center[a] = t.center[a];
     out->radius = t.radius;
 }
@@ -2859,42 +3118,60 @@ int FmmTree::debug_partition_upward_counts(int64_t *counts_out, uint8_t *reads_o
 // construction without a GPU; never reached from a compute entry point.
 int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
     const int n = ops_.n, n_pad = round_up(n, 32);
-    std::vector<double> cbuf(static_cast<size_t>(std::max<int64_t>(cbuf_len_, 1)), 0.0);
-    // stage 1 exactly as the unrestricted device launch walks it: the tile list with the boundary variants
-    std::vector<uint8_t> seen(static_cast<size_t>(tree_.n_cells()), 0);
-    for (const M2lTileDesc &td : m2l_tiles1_h_) {
-        const bool variant = static_cast<size_t>(td.level_class) >= m2l_host_.size();
-        const HostM2lClass &hc = variant ? m2l_variants_[static_cast<size_t>(td.level_class) - m2l_host_.size()]
-                                         : m2l_host_[static_cast<size_t>(td.level_class)];
-        if (hc.vt_all.empty()) return BBFMM_UNSUPPORTED; // tables were released after upload
-        for (int32_t q = 0; q < td.count; ++q) {
-            const size_t pos = static_cast<size_t>(td.pad ? m2l_tile_idx1_h_[static_cast<size_t>(td.first + q)] : td.first + q);
-            if (seen[hc.cells[pos]]++) return BBFMM_BAD_ARGUMENT; // every source cell belongs to exactly one tile
-            const double *Mv = M + static_cast<size_t>(hc.cells[pos]) * n;
-            for (int row = 0; row < hc.n_rows; ++row) {
-                if (hc.row_tpos[row] < 0) continue; // padding row
-                const int32_t slot = hc.cslot[pos * hc.n_t + hc.row_tpos[row]];
-                if (slot < 0) continue;
-                double s = 0.0;
-                for (int m = 0; m < n; ++m) s += hc.vt_all[static_cast<size_t>(m) * hc.r_pad16 + row] * Mv[m];
-                cbuf[static_cast<size_t>(slot) * 2 + hc.row_off[row]] = s;
+    // exactly as the unrestricted device launches walk them: batch by batch through ONE buffer of the largest
+    // batch's length (slot addresses are relative to the batch), stage 1 over the batch's tile list (boundary
+    // variants, group operators), stage 2 over the classes of the batch.  The buffer is NOT cleared between batches:
+    // what the zero-fill lists do not reset is left as the previous batch wrote it, like on the device.
+    std::vector<double> cbuf(static_cast<size_t>(std::max<int64_t>(cbuf_batch_len_, 1)), 0.0);
+    std::vector<int32_t> seen(static_cast<size_t>(tree_.n_cells()), 0);
+    const bool have_zero_lists = m2l_batches_.size() > 1 && !m2l_zero_h_.empty();
+    for (size_t b = 0; b < m2l_batches_.size(); ++b) {
+        const M2lBatch &mb = m2l_batches_[b];
+        if (have_zero_lists)
+            for (int64_t z = m2l_zero_ptr_[b]; z < m2l_zero_ptr_[b + 1]; ++z)
+                std::fill(cbuf.begin() + 2 * static_cast<int64_t>(m2l_zero_h_[static_cast<size_t>(2 * z)]),
+                          cbuf.begin() + 2 * (static_cast<int64_t>(m2l_zero_h_[static_cast<size_t>(2 * z)]) + m2l_zero_h_[static_cast<size_t>(2 * z + 1)]), 0.0);
+        for (int32_t ti = mb.t1_first; ti < mb.t1_first + mb.t1_count; ++ti) {
+            const M2lTileDesc &td = m2l_tiles1_h_[static_cast<size_t>(ti)];
+            const bool variant = static_cast<size_t>(td.level_class) >= m2l_host_.size();
+            const HostM2lClass &hc = variant ? m2l_variants_[static_cast<size_t>(td.level_class) - m2l_host_.size()]
+                                             : m2l_host_[static_cast<size_t>(td.level_class)];
+            if (hc.vt_all.empty()) return BBFMM_UNSUPPORTED; // tables were released after upload
+            if (m2l_batch_of_class_[static_cast<size_t>(td.level_class)] != static_cast<int32_t>(b)) return BBFMM_BAD_ARGUMENT;
+            for (int32_t q = 0; q < td.count; ++q) {
+                const size_t pos = static_cast<size_t>(td.pad ? m2l_tile_idx1_h_[static_cast<size_t>(td.first + q)] : td.first + q);
+                ++seen[hc.cells[pos]];
+                const double *Mv = M + static_cast<size_t>(hc.cells[pos]) * n;
+                for (int row = 0; row < hc.n_rows; ++row) {
+                    if (hc.row_tpos[row] < 0) continue; // padding row
+                    const int32_t slot = hc.cslot[pos * hc.n_t + hc.row_tpos[row]];
+                    if (slot < 0) continue;
+                    double s = 0.0;
+                    for (int m = 0; m < n; ++m) s += hc.vt_all[static_cast<size_t>(m) * hc.r_pad16 + row] * Mv[m];
+                    cbuf[static_cast<size_t>(slot) * 2 + hc.row_off[row]] = s;
+                }
+            }
+        }
+        for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
+            if (m2l_batch_of_class_[lc] != static_cast<int32_t>(b)) continue;
+            const HostM2lClass &hc = m2l_host_[lc];
+            for (size_t pos = 0; pos < hc.cells.size(); ++pos) {
+                double *Lb = L + static_cast<size_t>(hc.cells[pos]) * n;
+                const double *cc = &cbuf[static_cast<size_t>(hc.cbase[pos])];
+                for (int i = 0; i < n; ++i) {
+                    double s = 0.0;
+                    for (int k = 0; k < hc.k_pad; ++k) s += hc.u_all[static_cast<size_t>(k) * n_pad + i] * cc[k];
+                    Lb[i] += s;
+                }
             }
         }
     }
-    for (const HostM2lClass &hc : m2l_host_) // ... and no cell of a level with M2L work was left out
-        for (int32_t c : hc.cells)
-            if (!seen[c]) return BBFMM_BAD_ARGUMENT;
-    for (const HostM2lClass &hc : m2l_host_) {
-        for (size_t pos = 0; pos < hc.cells.size(); ++pos) {
-            double *Lb = L + static_cast<size_t>(hc.cells[pos]) * n;
-            const double *cc = &cbuf[static_cast<size_t>(hc.cbase[pos])];
-            for (int i = 0; i < n; ++i) {
-                double s = 0.0;
-                for (int k = 0; k < hc.k_pad; ++k) s += hc.u_all[static_cast<size_t>(k) * n_pad + i] * cc[k];
-                Lb[i] += s;
-            }
+    // every source cell of a level with M2L work belongs to exactly one stage-1 tile per batch of its level
+    for (const HostM2lClass &hc : m2l_host_)
+        for (int32_t c : hc.cells) {
+            const M2lBatch &mb = m2l_batches_[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(&hc - m2l_host_.data())])];
+            if (seen[c] != mb.groups) return BBFMM_BAD_ARGUMENT;
         }
-    }
     return BBFMM_OK;
 }
 

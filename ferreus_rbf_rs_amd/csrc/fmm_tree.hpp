@@ -45,6 +45,17 @@ struct HostM2lClass {
     std::vector<int64_t> cbase;
 };
 
+// One pass of stage 1 + stage 2 through the bounded intermediate buffer (cbuf): whole levels, or -- for a level
+// whose slots alone exceed the budget -- a group of its target classes.  Slot addresses (HostM2lClass::cbase,
+// cslot) are relative to the batch, so the buffer is as long as the largest batch, whatever the tree.
+struct M2lBatch {
+    int level_lo = 0, level_hi = 0;      // levels of the batch (level_lo == level_hi when groups > 1)
+    int groups = 1, group = 0;           // the level is cut into `groups` ranges of target classes; this is range `group`
+    int64_t len = 0;                     // doubles of its slots (without the dump area)
+    int32_t t1_first = 0, t1_count = 0;  // its tiles in the unrestricted stage-1 / stage-2 launch lists
+    int32_t t2_first = 0, t2_count = 0;
+};
+
 struct TargetSet { // targets sorted by leaf, resident on the device
     int64_t m = 0;
     DevBuf<double> xyz[3];
@@ -74,8 +85,9 @@ struct TargetSet { // targets sorted by leaf, resident on the device
 // target subset of a partial matvec): cells that carry targets, the M2L tiles and P2L jobs for them.
 struct DownwardPlan {
     std::vector<uint8_t> active;            // cells with targets (leaves and their ancestors)
-    std::vector<M2lTileDesc> tiles2_h;      // compact stage-2 tiles over the active cells (tail split)
-    std::vector<M2lTileDesc> tiles1_h;      // compact stage-1 tiles over the V-list sources of active cells
+    std::vector<M2lTileDesc> tiles2_h;      // compact stage-2 tiles over the active cells (tail split), batch by batch
+    std::vector<M2lTileDesc> tiles1_h;      // compact stage-1 tiles over the V-list sources of active cells, batch by batch
+    std::vector<int32_t> batch_t1, batch_t2; // 2 per batch: first tile and count in the two lists
     bool tiles1_own_blocks = false;         // sparse plan: a stage-1 tile per (column block, sources that block needs)
     std::vector<int32_t> tile_idx_h;        // class positions of the cells of both tile lists
     std::vector<uint16_t> qlist_h;          // active contraction steps of the stage-2 tiles
@@ -246,11 +258,23 @@ class FmmTree {
     std::vector<M2lClass> m2l_classes_h_;
     std::vector<M2lTileDesc> m2l_tiles_h_;
     std::vector<uint16_t> m2l_qlist_h_;
-    int64_t cbuf_len_ = 0;
+    // cbuf: bounded intermediate of the two M2L stages.  The batches run one after another through one buffer of
+    // cbuf_batch_len_ doubles per right-hand side (the largest batch + the dump area); m2l_rhs_chunk_ right-hand sides
+    // go through it per pass.  Budget: BBFMM_M2L_CBUF_MB (default 16384).
+    std::vector<M2lBatch> m2l_batches_;
+    std::vector<int32_t> m2l_batch_of_class_;          // per device class (level classes, then variants / group operators)
+    std::vector<std::vector<int32_t>> m2l_group_ops_;  // per level class: its stage-1 group operators (indices into
+                                                       // m2l_variants_, one per batch of the level), empty when groups == 1
+    std::vector<int32_t> m2l_zero_h_;                  // (slot / 2, length / 2) of the slot segments of absent pairs, batch by batch
+    std::vector<int64_t> m2l_zero_ptr_;                // per batch: range of its segments (only filled with more than one batch)
+    int64_t cbuf_batch_len_ = 0;
+    int64_t cbuf_total_len_ = 0;                       // sum of all slots (what one unbounded buffer would hold)
+    int64_t m2l_budget_bytes_ = int64_t(16384) << 20;
+    int m2l_rhs_chunk_ = 1;
     double m2l_flops_k1_ = 0;
     int n_cu_ = 256;      // compute units of the device (tail splitting of the tile lists)
     int device_ = -1;     // the HIP device that was current in create(): every entry point binds its thread to it
-    std::vector<M2lTileDesc> m2l_tiles2_h_; // stage-2 launch list: m2l_tiles_h_ with a split tail
+    std::vector<M2lTileDesc> m2l_tiles2_h_; // stage-2 launch list: m2l_tiles_h_ with the tail of every batch split
     int m2l_slot_t_ = 1; // most transfer vectors any stage-1 column block touches
     // partition
     int part_rank_ = 0, part_world_ = 1;
@@ -321,6 +345,7 @@ class FmmTree {
     DevBuf<M2lClass> d_m2l_classes_;
     DevBuf<M2lTileDesc> d_m2l_tiles_, d_m2l_tiles2_, d_m2l_tiles1_;
     DevBuf<int32_t> d_tile_idx1_;
+    DevBuf<int32_t> d_m2l_zero_;
     DevBuf<uint16_t> d_m2l_qlist_;
 
     DevBuf<uint8_t> d_active_;

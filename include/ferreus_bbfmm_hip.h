@@ -268,6 +268,14 @@ typedef struct {
     int32_t m2l_basis_rank;                  /* BBFMM_FLAG_M2L_SHARED_BASIS: largest rank of a level's basis (0: flag not set); */
     int32_t m2l_basis_len;                   /* coordinates kept per cell (rank padded to the kernel's column groups);      */
                                              /* m2l_flops_k1 then counts the stages in the basis + both changes of basis      */
+    /* The intermediate of the two M2L stages (one slot of sum_t rank_t doubles per target cell; the reference holds
+     * none, bbfmm.rs:864-986 multiplies pair by pair) is bounded: the levels -- or, for a level that alone exceeds the
+     * budget, 2 / 4 / 8 groups of its target classes -- go through one buffer in `m2l_batches` passes, a few
+     * right-hand sides at a time.  Budget: BBFMM_M2L_CBUF_MB (default 16384). */
+    int32_t m2l_batches;                     /* passes through the buffer per right-hand-side chunk                        */
+    int32_t m2l_rhs_per_pass;                /* right-hand sides per pass (0 until weights were set)                        */
+    int64_t m2l_slots_bytes_per_rhs;         /* all slots of one right-hand side (what an unbounded buffer would hold)      */
+    int64_t m2l_intermediate_bytes;          /* bytes of the buffer actually allocated (0 until weights were set)           */
 } bbfmm_tree_stats;
 
 int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out);

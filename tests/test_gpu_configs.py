@@ -340,3 +340,39 @@ def test_config5_forty_million_points_eight_way_partition():
     idx = np.random.default_rng(6).choice(n, 16, replace=False)
     yd = O.dense_sum(3, br, sill, pts[idx], pts, w.cpu().numpy().T.copy())
     assert relerr(ref.cpu().numpy().T[idx], yd) < 5e-6
+
+
+@pytest.mark.timeout(1800)
+def test_eighty_million_points_depth_seven_tree():
+    """A size the unbounded intermediate could not hold: 80M uniform points give a depth-7 tree whose finest level
+    alone has 77 GB of M2L slots per right-hand side (and slot indices beyond 2^31 in one buffer).  Bounded, the
+    level goes through the buffer in 8 groups of target classes.  Checked through dense rows, linearity and the
+    symmetry of the kernel matrix (size-independent properties; the oracle does not reach this size in seconds)."""
+    import torch
+    n = 80_000_000
+    pts = np.random.default_rng(42).random((n, 3))
+    t = F.FmmTree(pts, 7, F.KernelParams(F.KernelType.LinearRbf), True, True)
+    st = t.stats()
+    assert st.depth == 7 and t.tree_built_on_device()
+    assert st.m2l_slots_bytes_per_rhs > 80e9 and st.m2l_batches >= 9
+    g = torch.Generator(device="cuda").manual_seed(8)
+    w = torch.rand((2, n), dtype=torch.float64, device="cuda", generator=g) - 0.5
+    y = torch.zeros_like(w)
+    t.matvec_device(w.data_ptr(), n, 1, y[0].data_ptr(), n, True)
+    assert t.stats().m2l_intermediate_bytes < 17.2e9                       # the budget (16 GiB), not 87 GB
+    t.matvec_device(w[1].data_ptr(), n, 1, y[1].data_ptr(), n, True)
+    a, b = 0.75, -1.25
+    wc = (a * w[0] + b * w[1]).contiguous()
+    yc = torch.zeros_like(wc)
+    t.matvec_device(wc.data_ptr(), n, 1, yc.data_ptr(), n, True)
+    assert float((yc - (a * y[0] + b * y[1])).abs().max() / yc.abs().max()) < 1e-11          # linearity
+    sym = abs(float(torch.dot(w[1], y[0]) - torch.dot(w[0], y[1]))) / abs(float(torch.dot(w[1], y[0])))
+    assert sym < 1e-6                                                                      # K = K^T up to the far field
+    idx = np.random.default_rng(9).choice(n, 32, replace=False)
+    pd = torch.from_numpy(pts).cuda()
+    r2 = torch.zeros((32, n), dtype=torch.float64, device="cuda")
+    for ax in range(3):
+        r2 += (pd[idx, ax, None] - pd[None, :, ax]) ** 2
+    yd = -(torch.sqrt(r2) * w[0]).sum(1)
+    got = y[0][torch.from_numpy(idx).cuda()]
+    assert float((got - yd).abs().max() / yd.abs().max()) < 1e-6

@@ -228,3 +228,43 @@ def test_tree_statistics_definitions():
                 for c in range(r.C) for t_ in r.v_tidx[r.v_ptr[c]:r.v_ptr[c + 1]])
     assert s.m2l_flops_k1 == pytest.approx(flops, rel=1e-12)
     assert s.n_v == len(r.v_idx) and s.n_u == len(r.u_idx) and s.n_w == len(r.w_idx) and s.n_x == len(r.x_idx)
+
+
+@pytest.mark.parametrize("budget_mb,order,n,leaf", [(None, 4, 6000, 40), (3.0, 4, 6000, 40), (0.8, 4, 6000, 40), (0.25, 4, 6000, 40),
+                                                    (0.1, 3, 5000, 30), (0.4, 5, 3000, 30)])
+def test_bounded_m2l_intermediate_batches_reproduce_m2l(monkeypatch, budget_mb, order, n, leaf):
+    """The slots of the two M2L stages go through ONE buffer of bounded length (BBFMM_M2L_CBUF_MB): whole levels
+    while they fit, else 2 / 4 / 8 groups of a level's target classes with one stacked stage-1 operator per (group,
+    source class).  The host walk of the very tables and tile lists the device launches use -- one buffer, batch
+    after batch, zero-fill lists for the absent pairs -- must reproduce the reference's M2L (bbfmm.rs:864-986)
+    whatever the cut, on a mixed-level clustered tree (boundary cells, absent pairs everywhere)."""
+    rng = np.random.default_rng(23)
+    pts = np.vstack([rng.random((n, 3)), clustered_points(rng, n // 2, 3)])
+    if budget_mb is None:
+        monkeypatch.delenv("BBFMM_M2L_CBUF_MB", raising=False)
+    else:
+        monkeypatch.setenv("BBFMM_M2L_CBUF_MB", str(budget_mb))
+    params = (leaf, 2, 1e-5, 1024)
+    t, r = both(pts, order=order, params=params)
+    st = t.stats()
+    if budget_mb is None:
+        assert st.m2l_batches == 1
+    else:
+        assert st.m2l_batches > 1
+        if budget_mb <= 0.25:
+            assert st.m2l_batches > st.depth - 1                 # some level was cut into groups of classes
+    inject_product_operators(t, r)
+    r.set_weights(rng.random((pts.shape[0], 1)))
+    M = r.M[0].copy()
+    Lp = t.debug_apply_m2l_tables_host(M)
+    r.L = np.zeros_like(r.M)
+    lib = O.lib()
+    for level in range(2, r.depth + 1):
+        cells = np.ascontiguousarray(r.level_cells[level])
+        buf, u_off, vt_off, rank = r.opbuf[level]
+        lib.oracle_m2l(O.I32(r.ops.n), O.I64(r.C), O.I32(1), O._p(cells), O.I64(len(cells)), O._p(r.v_ptr),
+                       O._p(r.v_idx), O._p(r.v_tidx), O.I32(len(rank)), O._p(u_off), O._p(vt_off), O._p(rank),
+                       O._p(buf), O.I32(1), O._p(r.ops.perm), O._p(r.ops.invperm),
+                       O._p(r.ops.perm_lookup), O._p(r.ops.ref_lookup), O._p(r.M), O._p(r.L))
+    assert relerr(Lp, r.L[0]) < 1e-12
+    assert st.m2l_slots_bytes_per_rhs > 0
