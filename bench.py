@@ -346,6 +346,8 @@ def phase_roofline(stats, N, K, order, kernel, per_step_ms, sym_pairs):
             continue
         if ph in ("P2L", "M2P") and stats.n_w == 0:
             continue
+        if ph == "M2P" and sym_pairs and K == 1:
+            continue                                     # fused with P2L into one kernel (timed under P2L)
         sec = ms * 1e-3
         t_hbm, t_fp = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (FP64_MFMA_PEAK_TFLOPS * 1e12)
         e = {"ms": ms, "bytes": nbytes, "flops": flops, "gbps": nbytes / sec * 1e-9, "tflops": flops / sec * 1e-12,
@@ -628,6 +630,15 @@ def main():
                 line["fp64_mfma_microbench_tflops"] = tf
             except Exception:  # noqa: BLE001
                 line["fp64_mfma_microbench_tflops"] = None
+            try:  # what the vector pipe sustains on this device (the pair kernels' issue roofline) and at which clock
+                vtf, vmhz = F.fp64_valu_selftest()
+                line["fp64_valu_microbench"] = {"tflops": vtf, "clock_mhz": vmhz,
+                                                "lane_instr_per_s": vtf * 1e12 / 2.0}
+                for e in line.get("phase_roofline", {}).values():
+                    if "valu_issue" in e:
+                        e["valu_issue"]["frac_of_measured_fma_rate"] = e["valu_issue"]["achieved_lane_instr_per_s"] / (vtf * 1e12 / 2.0)
+            except Exception:  # noqa: BLE001
+                line["fp64_valu_microbench"] = None
 
     extra = {}
     if world == 1 and default_workload and want & {"auto", "extensions", "solve"}:

@@ -89,6 +89,7 @@ SIGNATURES = {
     "bbfmm_get_phase_ms": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_reset_phase_ms": (ctypes.c_int, [c_p]),
     "bbfmm_mfma_f64_selftest": (ctypes.c_int, [c_p, c_p, c_p]),
+    "bbfmm_fp64_valu_selftest": (ctypes.c_int, [c_p, c_p]),
     "bbfmm_debug_dense_m2m": (ctypes.c_int, [c_p, c_i32, c_p]),
     "bbfmm_debug_apply_m2l_tables_host": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_debug_m2l_variants": (ctypes.c_int, [c_p, c_p, c_p]),

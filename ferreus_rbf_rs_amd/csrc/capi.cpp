@@ -336,6 +336,13 @@ int bbfmm_reset_phase_ms(bbfmm_handle *h) {
     return BBFMM_OK;
 }
 
+int bbfmm_fp64_valu_selftest(double *tflops, double *clock_mhz) {
+    int ndev = 0;
+    if (!tflops || !clock_mhz) return BBFMM_BAD_ARGUMENT;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return BBFMM_DEVICE_ERROR;
+    return bbfmm::valu_f64_selftest(tflops, clock_mhz) == 0 ? BBFMM_OK : BBFMM_DEVICE_ERROR;
+}
+
 int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors, double *info6) {
     double tf = 0;
     int errs = -1;

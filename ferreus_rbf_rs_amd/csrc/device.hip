@@ -881,6 +881,140 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
     }
 }
 
+// ---- the same unordered-pair sums, one WAVE per job (round 3).  The workgroup version above spends a third of its
+// busy cycles around the pair arithmetic (three workgroup barriers per tile, one wave building the segment table while
+// seven wait, column sums through LDS atomics, six-row reductions per wave) and leaves the vector ALU idle a quarter of
+// the time.  Here a wave owns a whole leaf (up to SYM2_MAX_ROWS rows):
+//   * the columns of a tile (SYM2_CG x 64 sources: coordinates, weight, output index) live in REGISTERS -- lane l
+//     owns columns l, l + 64, ... -- loaded once per tile through the wave's own segment table (wave-private LDS
+//     slice, in-order LDS: no barrier anywhere in the kernel);
+//   * the rows go by in chunks of SYM2_R whose coordinates and weights are wave-uniform (scalar loads, SGPR
+//     operands); the SYM2_R pair chains of a column are independent and branch-free (rows past the leaf are clamped
+//     copies with weight 0), so the compiler interleaves them;
+//   * column sums stay in registers over all rows of the leaf and leave with one atomic per source and tile; row sums
+//     are reduced per (tile, chunk) through a 4 KB wave-private transpose (8 ds_write_b64, 4 ds_read_b128, 3 DPP
+//     steps) and one atomic per row.
+constexpr int SYM2_R = 8;
+constexpr int SYM2_CG = 4;
+constexpr int SYM2_WAVES = 4;
+constexpr int SYM2_MAX_ROWS = 256;
+
+struct Sym2Wave { // wave-private
+    double red[SYM2_R][64];
+    int32_t seg_src[64], seg_off[64], seg_two[64];
+};
+
+template <int KID>
+__global__ __launch_bounds__(64 * SYM2_WAVES) void p2p_sym2_kernel(KernelSpec ks, SymJobs jobs, Xyz src,
+                                                                  const double *__restrict__ ws,
+                                                                  double *__restrict__ out) {
+    __shared__ Sym2Wave lds[SYM2_WAVES];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int job = blockIdx.x * SYM2_WAVES + wave;
+    if (job >= jobs.n_jobs) return; // whole wave; no workgroup barrier below
+    Sym2Wave &W = lds[wave];
+    const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
+    int64_t q = jobs.run_range[2 * job];
+    const int64_t q1 = jobs.run_range[2 * job + 1];
+    int pos = 0; // points of run q already taken
+    constexpr int TILE = 64 * SYM2_CG;
+    while (q < q1) {
+        // segment table of the tile: up to 64 runs packed back to back until TILE columns are full
+        int fill, nseg;
+        {
+            const int64_t r = q + lane;
+            const bool valid = r < q1;
+            int b = valid ? jobs.runs[3 * r] : 0;
+            const int e = valid ? jobs.runs[3 * r + 1] : 0;
+            const int two = valid ? jobs.runs[3 * r + 2] : 0;
+            if (lane == 0) b += pos;
+            const int len = e - b;
+            int incl = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            const int excl = incl - len;
+            const int take = min(len, max(TILE - excl, 0));
+            W.seg_src[lane] = b;
+            W.seg_off[lane] = excl;
+            W.seg_two[lane] = two;
+            nseg = __popcll(__ballot(take > 0));
+            const int last = max(nseg - 1, 0);
+            fill = __builtin_amdgcn_readlane(excl + take, last);
+            const int take_l = __builtin_amdgcn_readlane(take, last), len_l = __builtin_amdgcn_readlane(len, last);
+            const bool full = take_l == len_l;
+            const int pos_now = pos;
+            q = q + last + (full ? 1 : 0);
+            pos = full ? 0 : ((last == 0 ? pos_now : 0) + take_l);
+            if (nseg == 0) break; // (empty runs only: cannot happen with the host's lists; never spin)
+        }
+        // the tile's columns into registers
+        double cx[SYM2_CG], cy[SYM2_CG], cz[SYM2_CG], cw[SYM2_CG], csum[SYM2_CG];
+        int cidx[SYM2_CG];
+#pragma unroll
+        for (int cg = 0; cg < SYM2_CG; ++cg) {
+            const int j = cg * 64 + lane;
+            cx[cg] = cy[cg] = cz[cg] = cw[cg] = 0.0; // a padding column: weight 0, its sums are dropped
+            cidx[cg] = -1;
+            csum[cg] = 0.0;
+            if (j < fill) {
+                int lo = 0, hi = nseg;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (W.seg_off[mid] <= j) lo = mid;
+                    else hi = mid;
+                }
+                const int g = W.seg_src[lo] + (j - W.seg_off[lo]);
+                cx[cg] = src.x[g];
+                cy[cg] = src.y[g];
+                cz[cg] = src.z[g];
+                cw[cg] = ws[g];
+                cidx[cg] = W.seg_two[lo] ? g - jobs.tgt_off : -1;
+            }
+        }
+        const int ncg = (fill + 63) >> 6; // wave-uniform
+        for (int rb = t0; rb < t1; rb += SYM2_R) {
+            double tx[SYM2_R], ty[SYM2_R], tz[SYM2_R], tw[SYM2_R], racc[SYM2_R];
+#pragma unroll
+            for (int r = 0; r < SYM2_R; ++r) {
+                const int g = jobs.tgt_off + min(rb + r, t1 - 1); // wave-uniform: scalar loads
+                tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
+                tw[r] = rb + r < t1 ? ws[g] : 0.0;
+                racc[r] = 0.0;
+            }
+#pragma unroll
+            for (int cg = 0; cg < SYM2_CG; ++cg) {
+                if (cg < ncg) {
+#pragma unroll
+                    for (int r = 0; r < SYM2_R; ++r) {
+                        const double dx = tx[r] - cx[cg], dy = ty[r] - cy[cg], dz = tz[r] - cz[cg];
+                        const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
+                        racc[r] += v * cw[cg];
+                        csum[cg] += v * tw[r];
+                    }
+                }
+            }
+            // row sums: transpose through the wave's slice, lane l adds 8 of the 64 partial sums of row l >> 3
+#pragma unroll
+            for (int r = 0; r < SYM2_R; ++r) W.red[r][lane] = racc[r];
+            const double2 *pr = reinterpret_cast<const double2 *>(&W.red[lane >> 3][(lane & 7) * 8]);
+            const double2 a0 = pr[0], a1 = pr[1], a2 = pr[2], a3 = pr[3];
+            double sum = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            const int row = rb + (lane >> 3);
+            if ((lane & 7) == 0 && row < t1) unsafeAtomicAdd(&out[row], sum);
+        }
+#pragma unroll
+        for (int cg = 0; cg < SYM2_CG; ++cg)
+            if (cg < ncg && cidx[cg] >= 0) unsafeAtomicAdd(&out[cidx[cg]], csum[cg]);
+    }
+}
+
 // Stage the Chebyshev nodes of `cell` (scale_cheb_nodes_to_cell, chebyshev.rs:951-968) and
 // its coefficients as a source tile (n <= DIRECT_TILE assumed per chunk).
 template <int KB>
@@ -1673,18 +1807,38 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
 }
 
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                    const int64_t *run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
+                    const int64_t *run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
+                    const int64_t *w_run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
                     const double *w_sorted, double *out_sorted, hipStream_t s) {
-    if (n_jobs == 0) return;
-    const SymJobs jobs{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
-        hipLaunchKernelGGL((p2p_sym_kernel<ID>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, make_xyz(src_xyz),
-                           w_sorted, out_sorted);
+        if (n_wave_jobs > 0) {
+            const SymJobs jobs{n_wave_jobs, w_tgt_begin, w_tgt_end, w_run_range, runs3, tgt_off};
+            hipLaunchKernelGGL((p2p_sym2_kernel<ID>), dim3((n_wave_jobs + SYM2_WAVES - 1) / SYM2_WAVES), dim3(64 * SYM2_WAVES), 0, s,
+                               ks, jobs, make_xyz(src_xyz), w_sorted, out_sorted);
+        }
+        if (n_jobs > 0) {
+            const SymJobs jobs{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
+            hipLaunchKernelGGL((p2p_sym_kernel<ID>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, make_xyz(src_xyz),
+                               w_sorted, out_sorted);
+        }
     });
 }
 
+// Leaves of at most this many rows are one job of the wave-per-job kernel (BBFMM_P2P_SYM_WAVE=<rows>, 0: none).
+// Measured on MI355X: 38-point leaves (10M uniform points) 5.55 -> 4.46 ms with the wave kernel; 153- and 238-point
+// leaves (40M, 1M points) are faster in the workgroup kernel (89.7 against 103 ms, 2.5 against 4.7 ms).
+int p2p_sym_wave_rows() {
+    static const int rows = [] {
+        const char *e = std::getenv("BBFMM_P2P_SYM_WAVE");
+        const int v = e ? std::atoi(e) : 64;
+        return v < 0 ? 0 : (v > SYM2_MAX_ROWS ? SYM2_MAX_ROWS : v);
+    }();
+    return rows;
+}
+
 int p2p_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
+int wx_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
 
 void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
                    const int64_t *w_range, const int32_t *w_cells, const double *centers, const double *lengths,
@@ -2155,6 +2309,63 @@ int mfma_f64_selftest(double *tflops, int *layout_errors, double *info) {
     (void)hipFree(dA);
     (void)hipFree(dB);
     (void)hipFree(dD);
+    return 0;
+}
+
+// ------------------------------------------------------------------ FP64 vector-ALU peak (the pair kernels' roofline)
+// Eight independent v_fma_f64 chains per lane: what the vector pipe sustains chip-wide, and at which clock (the
+// FP64 load pulls the shader clock well under the 2.4 GHz of AMD's 78.6 TFLOP/s).
+__global__ __launch_bounds__(256) void valu_peak_kernel(double *sink, int iters, unsigned long long *stamps) {
+    double a = 1.0 + threadIdx.x * 1e-9;
+    const double b = 1.0 - 1e-9;
+    double c[8] = {0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8};
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c[q] = fma(c[q], b, a);
+    }
+    double sum = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) sum += c[q];
+    if (sum == 12345.678) sink[0] = sum;
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && (threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+        stamps[2 * w] = t1 - t0;
+        stamps[2 * w + 1] = r1 - r0;
+    }
+}
+
+// tflops: FMA flops per second chip-wide (2 per lane and instruction); mhz: the shader clock during the run.
+int valu_f64_selftest(double *tflops, double *mhz) {
+    const int iters = 8192, blocks = 4096;
+    double *sink = nullptr;
+    unsigned long long *dS = nullptr;
+    if (hipMalloc(&sink, 64) != hipSuccess) return 1;
+    if (hipMalloc(&dS, sizeof(unsigned long long) * 2 * 4 * blocks) != hipSuccess) return 1;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 64, nullptr); // warm-up
+    (void)hipEventRecord(e0, 0);
+    hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, dS);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    std::vector<unsigned long long> hS(2 * 4 * blocks);
+    (void)hipMemcpy(hS.data(), dS, sizeof(unsigned long long) * hS.size(), hipMemcpyDeviceToHost);
+    double sc = 0, sr = 0;
+    for (size_t w = 0; w < (size_t)4 * blocks; ++w) {
+        sc += (double)hS[2 * w];
+        sr += (double)hS[2 * w + 1];
+    }
+    *tflops = (double)blocks * 256 * iters * 8.0 * 2.0 / (ms * 1e-3) / 1e12;
+    *mhz = sr > 0 ? sc / sr * 100.0 : 0.0;
+    (void)hipFree(sink);
+    (void)hipFree(dS);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
 }
 

@@ -137,10 +137,16 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
 // = (begin, end, two_sided) triples of sorted source ranges: two-sided runs also receive the column sums (they
 // must lie inside the target range and after the leaf), one-sided runs only feed the job's rows.  out_sorted
 // (n_tgt values, zeroed by the caller) is accumulated with f64 atomics.
+// Two job lists over the same runs: (n_jobs, tgt_begin, tgt_end, run_range) row chunks of big leaves for the
+// workgroup-per-job kernel, (n_wave_jobs, w_*) whole small leaves (at most p2p_sym_wave_rows() rows) for the
+// wave-per-job kernel.
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                    const int64_t *run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
+                    const int64_t *run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
+                    const int64_t *w_run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
                     const double *w_sorted, double *out_sorted, hipStream_t s);
 int p2p_sym_rows_per_job();
+int p2p_sym_wave_rows(); // 0: no wave jobs (BBFMM_P2P_SYM_WAVE=0)
+int wx_sym_rows_per_job();
 // M2P + P2L in one pass for targets = all sources, one rhs (X = W^T): jobs are row chunks of the leaves that have a
 // W list, w_range their ranges in w_cells; row sums go to out_sorted (M2P), column sums to L (P2L), both atomically.
 void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
@@ -170,5 +176,7 @@ bool l2p_order_supported(int p, int d);
 
 // FP64 MFMA lane-layout check + peak microbenchmark.
 int mfma_f64_selftest(double *tflops, int *layout_errors, double *info);
+// FP64 vector-ALU peak: chip-wide v_fma_f64 rate (TFLOP/s) and the shader clock it runs at (MHz).
+int valu_f64_selftest(double *tflops, double *mhz);
 
 } // namespace bbfmm

@@ -1642,14 +1642,18 @@ int FmmTree::build_source_target_set() {
 // own jobs.  (U lists are symmetric: linear_tree.rs:295-364 collects adjacent leaves from both sides.)
 int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe) {
     const HostTree &t = tree_;
-    const int64_t max_rows = p2p_sym_rows_per_job();
+    // Two kinds of jobs over the same run lists: a leaf of at most p2p_sym_wave_rows() rows is ONE job of the
+    // wave-per-job kernel (no barriers, columns in registers: faster where a leaf's work is small); bigger leaves go
+    // in chunks of at most p2p_sym_rows_per_job() rows to the workgroup-per-job kernel, whose per-job overhead is
+    // spread over eight waves (faster there).
+    const int64_t max_rows = p2p_sym_rows_per_job(), wave_rows = p2p_sym_wave_rows();
     const int64_t nj_cells = static_cast<int64_t>(job_cells.size());
     // per chunk of leaves into local buffers (threads), concatenated in order
     constexpr int64_t kChunkS = 2048;
     const int64_t nch = (nj_cells + kChunkS - 1) / kChunkS;
     struct Part {
-        std::vector<int32_t> runs, tb, te;
-        std::vector<int64_t> range; // run ranges relative to the part's first run
+        std::vector<int32_t> runs, tb, te, wtb, wte;
+        std::vector<int64_t> range, wrange; // run ranges relative to the part's first run
     };
     std::vector<Part> parts(static_cast<size_t>(std::max<int64_t>(nch, 1)));
     parallel_for_chunks(nj_cells, kChunkS, [&](int64_t lo, int64_t hi) {
@@ -1673,32 +1677,45 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
                     add(std::max({b, a1, pe}), e, 0);         // after the leaf, another rank's
                 }
                 const int64_t last = static_cast<int64_t>(P.runs.size() / 3);
-                // the leaf's rows in equal chunks of at most max_rows
-                const int64_t na = a1 - a0, nj = (na + max_rows - 1) / max_rows;
-                for (int64_t i = 0; i < nj; ++i) {
-                    P.tb.push_back(static_cast<int32_t>(a0 - pb + na * i / nj));
-                    P.te.push_back(static_cast<int32_t>(a0 - pb + na * (i + 1) / nj));
-                    P.range.push_back(first);
-                    P.range.push_back(last);
+                const int64_t na = a1 - a0;
+                if (na <= wave_rows) { // one wave takes the whole leaf
+                    P.wtb.push_back(static_cast<int32_t>(a0 - pb));
+                    P.wte.push_back(static_cast<int32_t>(a1 - pb));
+                    P.wrange.push_back(first);
+                    P.wrange.push_back(last);
+                } else { // the leaf's rows in equal chunks of at most max_rows
+                    const int64_t nj = (na + max_rows - 1) / max_rows;
+                    for (int64_t i = 0; i < nj; ++i) {
+                        P.tb.push_back(static_cast<int32_t>(a0 - pb + na * i / nj));
+                        P.te.push_back(static_cast<int32_t>(a0 - pb + na * (i + 1) / nj));
+                        P.range.push_back(first);
+                        P.range.push_back(last);
+                    }
                 }
             }
         }
     });
-    std::vector<int64_t> range;
-    std::vector<int32_t> runs, tb, te;
+    std::vector<int64_t> range, wrange;
+    std::vector<int32_t> runs, tb, te, wtb, wte;
     {
-        size_t nr = 0, njobs = 0;
-        for (const Part &P : parts) nr += P.runs.size(), njobs += P.tb.size();
+        size_t nr = 0, njobs = 0, nwjobs = 0;
+        for (const Part &P : parts) nr += P.runs.size(), njobs += P.tb.size(), nwjobs += P.wtb.size();
         runs.reserve(nr);
         tb.reserve(njobs);
         te.reserve(njobs);
         range.reserve(2 * njobs);
+        wtb.reserve(nwjobs);
+        wte.reserve(nwjobs);
+        wrange.reserve(2 * nwjobs);
         for (const Part &P : parts) {
             const int64_t base = static_cast<int64_t>(runs.size() / 3);
             runs.insert(runs.end(), P.runs.begin(), P.runs.end());
             tb.insert(tb.end(), P.tb.begin(), P.tb.end());
             te.insert(te.end(), P.te.begin(), P.te.end());
             for (int64_t v : P.range) range.push_back(base + v);
+            wtb.insert(wtb.end(), P.wtb.begin(), P.wtb.end());
+            wte.insert(wte.end(), P.wte.begin(), P.wte.end());
+            for (int64_t v : P.wrange) wrange.push_back(base + v);
         }
     }
     ts->n_wx_jobs = 0;
@@ -1709,7 +1726,8 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
         for (size_t j = 0; j < job_cells.size(); ++j) {
             const int32_t c = job_cells[j];
             if (t.w.ptr[c + 1] == t.w.ptr[c]) continue;
-            const int64_t a0 = t.pt_begin[c], na = t.pt_end[c] - a0, nj = (na + max_rows - 1) / max_rows;
+            const int64_t max_rows_wx = wx_sym_rows_per_job();
+            const int64_t a0 = t.pt_begin[c], na = t.pt_end[c] - a0, nj = (na + max_rows_wx - 1) / max_rows_wx;
             for (int64_t i = 0; i < nj; ++i) {
                 wtb.push_back(static_cast<int32_t>(a0 + na * i / nj));
                 wte.push_back(static_cast<int32_t>(a0 + na * (i + 1) / nj));
@@ -1722,6 +1740,10 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
         CHK(dupload(&ts->wx_te, wte));
         CHK(dupload(&ts->wx_range, wr));
     }
+    ts->n_symw_jobs = static_cast<int>(wtb.size());
+    CHK(dupload(&ts->symw_tb, wtb));
+    CHK(dupload(&ts->symw_te, wte));
+    CHK(dupload(&ts->symw_ptr, wrange));
     ts->n_sym_jobs = static_cast<int>(tb.size());
     CHK(dupload(&ts->sym_tb, tb));
     CHK(dupload(&ts->sym_te, te));
@@ -1938,6 +1960,10 @@ void FmmTree::free_target_set(TargetSet *ts) {
     dfree(&ts->sym_te);
     dfree(&ts->sym_ptr);
     dfree(&ts->sym_runs);
+    dfree(&ts->symw_tb);
+    dfree(&ts->symw_te);
+    dfree(&ts->symw_ptr);
+    ts->n_symw_jobs = 0;
     dfree(&ts->wx_tb);
     dfree(&ts->wx_te);
     dfree(&ts->wx_range);
@@ -2135,8 +2161,8 @@ int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStre
         }();
         if (timed) phase_begin();
         if (ts.sym && sym_on && !deterministic_ && !with_grads && k == 1) // targets = sources, one rhs: every unordered pair once
-            launch_p2p_sym(kernel_, ts.n_sym_jobs, ts.sym_tb.p, ts.sym_te.p, ts.sym_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_,
-                           d_w_sorted_.p, ts.out.p, st);
+            launch_p2p_sym(kernel_, ts.n_sym_jobs, ts.sym_tb.p, ts.sym_te.p, ts.sym_ptr.p, ts.n_symw_jobs, ts.symw_tb.p, ts.symw_te.p,
+                           ts.symw_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_, d_w_sorted_.p, ts.out.p, st);
         else
             launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
         if (timed) phase_end(kPhP2P);

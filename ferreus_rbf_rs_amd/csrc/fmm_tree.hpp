@@ -75,6 +75,9 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     DevBuf<int32_t> sym_tb, sym_te; // jobs: row chunks of the leaves
     DevBuf<int64_t> sym_ptr;        // 2 per job: run range of the job's leaf
     DevBuf<int32_t> sym_runs;
+    int n_symw_jobs = 0;            // whole small leaves: one wave each (device.hpp launch_p2p_sym)
+    DevBuf<int32_t> symw_tb, symw_te;
+    DevBuf<int64_t> symw_ptr;
     // M2P + P2L fused (whole source set only): row chunks of the leaves with a W list and their W ranges
     int n_wx_jobs = 0;
     DevBuf<int32_t> wx_tb, wx_te;

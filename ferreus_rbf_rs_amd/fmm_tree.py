@@ -448,6 +448,14 @@ class FmmTree:
         return Lc
 
 
+def fp64_valu_selftest():
+    """(chip-wide v_fma_f64 TFLOP/s, shader clock in MHz during the run) on the current device."""
+    tf, mhz = ctypes.c_double(0), ctypes.c_double(0)
+    if L.load().bbfmm_fp64_valu_selftest(ctypes.byref(tf), ctypes.byref(mhz)) != L.OK:
+        raise RuntimeError("the FP64 VALU microbenchmark needs a HIP device")
+    return tf.value, mhz.value
+
+
 def mfma_f64_selftest():
     """(measured FP64 MFMA TFLOP/s, lane-layout mismatches) on the current device."""
     tf = ctypes.c_double(0)

@@ -326,6 +326,10 @@ int bbfmm_reset_phase_ms(bbfmm_handle *h);
  * cycles/MFMA of a lone wave, its clock (MHz), cycles/MFMA/SIMD and clock with every CU busy at
  * 1 wave/SIMD, TFLOP/s at 1 and at 2 waves/SIMD. */
 int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors, double *info6);
+/* FP64 vector-ALU microbenchmark (device): chip-wide v_fma_f64 rate in *tflops and the shader clock it ran at in
+ * *clock_mhz -- the issue roofline of the pair kernels (P2P, M2P, P2L), which the FP64 load pulls under the nominal
+ * 2.4 GHz. */
+int bbfmm_fp64_valu_selftest(double *tflops, double *clock_mhz);
 
 /* ---- test hooks (host loops, no device; never reached from a compute entry point) ----
  * Dense n x n (column-major) M2M matrix of child `child_index` exactly as the reference

@@ -24,7 +24,7 @@ def main():
     st = tree.stats()
     y = tree.fast_matrix_vector_product(w[:, 0].copy())
     y_again = tree.fast_matrix_vector_product(w[:, 0].copy())
-    x = rng.random((5000, 3))
+    x = pts[rng.choice(n, 5000, replace=False)] * (1.0 - 1e-9)   # inside occupied leaves (the tree is sparse: empty cells do not exist)
     tree.set_weights(w)
     z = tree.evaluate(w, x)
     nv, nc = tree.debug_m2l_variants()

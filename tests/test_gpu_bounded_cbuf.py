@@ -17,10 +17,12 @@ def _cloud(seed, n):
     return np.vstack([rng.random((n, 3)), clustered_points(rng, n // 3, 3)])
 
 
-@pytest.mark.parametrize("budget_mb,nrhs", [(40.0, 1), (6.0, 3), (1.5, 5)])
-def test_bounded_intermediate_matches_the_oracle(monkeypatch, budget_mb, nrhs):
+@pytest.mark.parametrize("fraction,nrhs", [(0.6, 1), (0.1, 3), (0.02, 5)])
+def test_bounded_intermediate_matches_the_oracle(monkeypatch, fraction, nrhs):
     pts = _cloud(41, 90000)
-    monkeypatch.setenv("BBFMM_M2L_CBUF_MB", str(budget_mb))
+    whole = F.FmmTree(pts, 6, F.KernelParams(F.KernelType(0)), True, True, host_only=True).stats().m2l_slots_bytes_per_rhs
+    budget_mb = fraction * whole / 1048576.0                 # a budget of that fraction of all slots of one rhs
+    monkeypatch.setenv("BBFMM_M2L_CBUF_MB", "%.6f" % budget_mb)
     t = F.FmmTree(pts, 6, F.KernelParams(F.KernelType(0)), True, True)
     monkeypatch.delenv("BBFMM_M2L_CBUF_MB")
     r = O.FmmTree(pts, 6, 0, True, True, None, None)
@@ -31,7 +33,7 @@ def test_bounded_intermediate_matches_the_oracle(monkeypatch, budget_mb, nrhs):
     y, yr = t.evaluate(w, pts), r.evaluate(w, pts)
     st = t.stats()
     assert st.m2l_batches > 1 and st.n_w > 0
-    if budget_mb <= 6.0:
+    if fraction <= 0.1:
         assert st.m2l_batches > st.depth - 1                       # a level cut into groups of target classes
     assert st.m2l_intermediate_bytes <= max(budget_mb * 1048576 * 1.01, st.m2l_slots_bytes_per_rhs / 8 * 1.3)
     assert st.m2l_intermediate_bytes < st.m2l_slots_bytes_per_rhs * nrhs
@@ -55,7 +57,7 @@ def test_bounded_intermediate_partition_equals_the_default_path(monkeypatch):
     ref = torch.zeros_like(w)
     ref_tree.matvec_device(w.data_ptr(), n, 2, ref.data_ptr(), n, True)
     assert ref_tree.stats().m2l_batches == 1
-    monkeypatch.setenv("BBFMM_M2L_CBUF_MB", "2.0")
+    monkeypatch.setenv("BBFMM_M2L_CBUF_MB", "%.6f" % (0.05 * ref_tree.stats().m2l_slots_bytes_per_rhs / 1048576.0))
     t = F.FmmTree(pts, 5, F.KernelParams(F.KernelType(2)), True, True)
     monkeypatch.delenv("BBFMM_M2L_CBUF_MB")
     assert t.stats().m2l_batches > t.stats().depth - 1
