@@ -99,7 +99,8 @@ def parse():
     ap.add_argument("--configs", default="auto",
                     help="comma list of: auto (with the default workload: the other single-GPU configs at N = 1, "
                          "config 5 = 40M Spheroidal3 at N > 1), off, solve (config 3 end to end: 10M thin-plate spline "
-                         "FGMRES + Schwarz, N = 1), extensions (the labelled extensions, N = 1)")
+                         "FGMRES + Schwarz, N = 1), extensions (the labelled extensions, N = 1), config5 (config 5 at "
+                         "N > 1 whatever the headline workload)")
     ap.add_argument("--config5-points", type=int, default=CONFIG5["points"], help="points of config 5 on the N > 1 line")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"],
                     help="gloo: CPU-staged exchange; ranks may then share a GPU (LOCAL_RANK modulo the device "
@@ -666,7 +667,7 @@ def main():
                 extra["config3_solve_tps_10M_fgmres_schwarz"] = run_config3_solve(F)
             except Exception as e:  # noqa: BLE001
                 extra["config3_solve_tps_10M_fgmres_schwarz"] = {"error": f"{type(e).__name__}: {e}"}
-    elif world > 1 and default_workload and "auto" in want:
+    elif world > 1 and ((default_workload and "auto" in want) or "config5" in want):
         # config 5 (40M Spheroidal3) partitioned over the same ranks; every rank takes part
         del tree, w, out, stream, pm
         tree = w = out = stream = pm = None

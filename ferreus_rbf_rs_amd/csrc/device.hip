@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace bbfmm {
@@ -1363,6 +1364,9 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     // 2 x { operator [e][ng][k*16 + col], IN tile [wave][tg][eh][k][j] x 2 }; stage 1 adds the slot
     // lookups of the current column block, [wave][cell 0..15][slot_t] int32
     extern __shared__ double lds[];
+    // experiment switches of stage 1 ride in the high bits of slot_t (profiles/: where the store tail goes)
+    const bool s1_no_store = STAGE == 1 && (slot_t & (1 << 30)) != 0, s1_nt_store = STAGE == 1 && (slot_t & (1 << 29)) != 0;
+    if (STAGE == 1) slot_t &= 0xffff;
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
     const int kr = blockIdx.y;
@@ -1562,13 +1566,21 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                         const int sl = srow[max(pk[pr] >> 24, 0)];
                         const int okm = (spv ? -1 : 0) & ~(pk[pr] | sl); // sign bit set: valid cell, row, slot
                         double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[pr] & 0xffffff) : dump;
-                        *reinterpret_cast<double2 *>(dst) = make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
+                        if (s1_nt_store) {
+                            typedef double d2v __attribute__((ext_vector_type(2)));
+                            d2v val;
+                            val.x = acc[tg][2 * pr];
+                            val.y = acc[tg][2 * pr + 1];
+                            __builtin_nontemporal_store(val, reinterpret_cast<d2v *>(dst));
+                        } else if (!s1_no_store) {
+                            *reinterpret_cast<double2 *>(dst) = make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
+                        }
                     }
                     if (NS) {
                         const int sl = srow[max(pk[NP] >> 24, 0)];
                         const int okm = (spv ? -1 : 0) & ~(pk[NP] | sl);
                         double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[NP] & 0xffffff) : dump;
-                        *dst = acc[tg][NG16 - 1];
+                        if (!s1_no_store) *dst = acc[tg][NG16 - 1];
                     }
                 }
             } else if (STAGE >= 2) {
@@ -1898,7 +1910,7 @@ template <int NG16, int STAGE, int MINW>
 static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles, int n_pad, int g16_0,
                             int n_colblocks, int K, int64_t C, const double *in, int64_t in_len, double *out,
                             int64_t out_len, const uint16_t *qlist, int slot_t, const int32_t *tile_idx, hipStream_t s) {
-    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 128 + 8 * 16 * slot_t) * 4 : 0); // + aux, cell and slot tables
+    const size_t lds = 2 * sizeof(double) * (size_t)(2 * NG16 * 128 + 2048) + (STAGE == 1 ? (size_t)(2 * 192 + 128 + 8 * 16 * (slot_t & 0xffff)) * 4 : 0); // + aux, cell and slot tables
     // function attributes are per device: one flag per (template instance, device), set from whichever thread
     // launches there first (handles are bound to their device and may be used from any host thread)
     static std::atomic<uint64_t> attr_set[4] = {{0}, {0}, {0}, {0}};
@@ -2040,7 +2052,14 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
         }
     }
     const int n_colblocks = own_blocks ? 1 : zsplit; // tiles that name their own blocks are not split further
-    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr, slot_t, tile_idx, s);
+    // BBFMM_M2L_S1_STORES=off | nt: experiments on the scatter stores (off: results are wrong; for timing only)
+    static const int store_flags = [] {
+        const char *e = std::getenv("BBFMM_M2L_S1_STORES");
+        if (!e) return 0;
+        return std::string(e) == "off" ? (1 << 30) : std::string(e) == "nt" ? (1 << 29) : 0;
+    }();
+    m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr,
+                           slot_t | store_flags, tile_idx, s);
 }
 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.

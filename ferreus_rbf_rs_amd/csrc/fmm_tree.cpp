@@ -1726,14 +1726,19 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
         for (size_t j = 0; j < job_cells.size(); ++j) {
             const int32_t c = job_cells[j];
             if (t.w.ptr[c + 1] == t.w.ptr[c]) continue;
-            const int64_t max_rows_wx = wx_sym_rows_per_job();
+            // jobs = (row chunk of the leaf) x (chunk of its W list): a nearly uniform tree has a few dozen coarse
+            // leaves with long W lists (10M uniform points: 90 leaves of 250 points, about 100 W cells each), and whole-list
+            // jobs would be a handful of long workgroups (0.96 ms for 0.6e9 kernel evaluations); both sums are atomic
+            const int64_t max_rows_wx = wx_sym_rows_per_job(), max_cells_wx = 16;
             const int64_t a0 = t.pt_begin[c], na = t.pt_end[c] - a0, nj = (na + max_rows_wx - 1) / max_rows_wx;
-            for (int64_t i = 0; i < nj; ++i) {
-                wtb.push_back(static_cast<int32_t>(a0 + na * i / nj));
-                wte.push_back(static_cast<int32_t>(a0 + na * (i + 1) / nj));
-                wr.push_back(t.w.ptr[c]);
-                wr.push_back(t.w.ptr[c + 1]);
-            }
+            const int64_t w0 = t.w.ptr[c], nw = t.w.ptr[c + 1] - w0, nwj = (nw + max_cells_wx - 1) / max_cells_wx;
+            for (int64_t i = 0; i < nj; ++i)
+                for (int64_t jw = 0; jw < nwj; ++jw) {
+                    wtb.push_back(static_cast<int32_t>(a0 + na * i / nj));
+                    wte.push_back(static_cast<int32_t>(a0 + na * (i + 1) / nj));
+                    wr.push_back(w0 + nw * jw / nwj);
+                    wr.push_back(w0 + nw * (jw + 1) / nwj);
+                }
         }
         ts->n_wx_jobs = static_cast<int>(wtb.size());
         CHK(dupload(&ts->wx_tb, wtb));

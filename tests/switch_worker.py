@@ -14,10 +14,10 @@ def main():
     out_path, flags = sys.argv[1], sys.argv[2:]
     import ferreus_rbf_rs_amd as F
     rng = np.random.default_rng(2024)
-    n = 260000
-    pts = np.vstack([rng.random((200000, 3)), np.clip(rng.normal(size=(60000, 3)) * 0.03 + 0.4, 0.0, 0.999)])
+    n = 460000
+    pts = np.vstack([rng.random((400000, 3)), np.clip(rng.normal(size=(60000, 3)) * 0.03 + 0.4, 0.0, 0.999)])
     w = rng.standard_normal((n, 2))
-    # 40 points per leaf: the uniform part sits at level 5 (32^3 cells), whose faces hold runs of 256 same-class
+    # 40 points per leaf: the uniform part (12 points per cell: no empty cells) sits at level 5 (32^3 cells), whose faces hold runs of 256 same-class
     # cells with equal V-list patterns -- enough for stage-1 boundary variants when one tile qualifies
     tree = F.FmmTree(pts, 6, F.KernelParams(F.FmmKernelType.LinearRbf), True, True,
                      params=F.FmmParams(40, 2, 1e-6, 1024), deterministic="deterministic" in flags)

@@ -63,7 +63,8 @@ def test_bench_launches_its_own_ranks():
     touching the GPU and relays rank 0's line (here with the gloo exchange so that both fit one GPU)."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "gloo",
-                        "--points", "400000", "--steps", "3", "--warmup", "1", "--cpu-baseline", "off"],
+                        "--points", "400000", "--steps", "3", "--warmup", "1", "--cpu-baseline", "off",
+                        "--configs", "config5", "--config5-points", "300000"],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
@@ -71,3 +72,9 @@ def test_bench_launches_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["scaling"] == "strong"
     assert "target-subtree partition x2" in j["config"]["parallelism"]
+    # the N > 1 line is a checked claim: dense rows of the exchanged result, and config 5's workload on the same ranks
+    assert j["dense_rows_rel_err"] is not None and j["dense_rows_rel_err"] < 1e-6
+    c5 = j["configs"]["config5_spheroidal3_40M"]
+    assert "error" not in c5, c5
+    assert c5["n_gpus"] == 2 and c5["ms_per_step"] > 0 and c5["dense_rows_rel_err"] < 1e-5
+    assert "Spheroidal3Rbf" in c5["workload"] and c5["workload"].startswith("300000 ")
