@@ -268,9 +268,11 @@ def cpu_baseline(args, kernel_id):
     }
 
 
-def roofline_of(stats, K, per_launch, world, pair_frac=1.0):
-    """Roofline entry of the dominant kernel (largest average launch among the M2L stages and P2P);
-    algorithmic work per launch as DESIGN.md section 5 defines it."""
+def roofline_of(stats, K, per_launch, world, launches=None):
+    """Roofline entry of the dominant kernel (largest time per matvec among the M2L stages and the pair phases);
+    algorithmic work as DESIGN.md section 5 defines it.  `per_launch` holds the time of ALL launches of a phase in one
+    matvec (one launch when the M2L intermediate is a single batch and all right-hand sides go in one pass -- the
+    headline; otherwise `launches_per_step` of them, and work and time are both the sums over those launches)."""
     m2l_stage_flops = stats.m2l_flops_k1 * K / 2.0          # each stage does 2*n*r per pair
     p2p_tile_bytes = stats.p2p_tile_bytes_k1 + (K - 1) * 8 * (stats.p2p_tile_bytes_k1 // 32)
     kern = {
@@ -289,6 +291,7 @@ def roofline_of(stats, K, per_launch, world, pair_frac=1.0):
         "kernel": dominant, "bound": kd["bound"], "achieved": achieved, "peak": kd["peak"],
         "unit": kd["unit"], "frac": (achieved / kd["peak"]) if achieved else None,
         "traffic": None, "avg_launch_ms": per_launch[dominant], "algorithmic_work_per_launch": kd["work"],
+        "launches_per_step": (launches or {}).get(dominant, 1),
     }
 
 
@@ -359,14 +362,16 @@ def phase_roofline(stats, N, K, order, kernel, per_step_ms, sym_pairs):
         key = {"P2P": "p2p_sym" if sym_pairs else "p2p", "P2L": "wx_sym" if (sym_pairs and K == 1) else "p2l",
                "M2P": "m2p"}.get(ph)
         if key and instr and key in instr.get("kernels", {}).get(kernel, {}):
-            ipp = instr["kernels"][kernel][key]["fp64_valu_per_pair"]
-            if ph == "P2P":
-                evals = (stats.p2p_pairs + N) / 2.0 if sym_pairs else float(stats.p2p_pairs)
-            else:
-                evals = float(stats.wx_pairs)            # the fused kernel evaluates each (point, node) pair once for both
-            e["valu_issue"] = {"kernel_evaluations": evals * K, "fp64_valu_instr_per_evaluation": ipp,
-                               "achieved_lane_instr_per_s": evals * K * ipp / sec, "peak_lane_instr_per_s": FP64_VALU_LANE_INSTR_PEAK,
-                               "frac": evals * K * ipp / sec / FP64_VALU_LANE_INSTR_PEAK, "counted_from": instr["file"]}
+            ipp = instr["kernels"][kernel][key]["fp64_valu_per_pair"]     # distance + phi + the row and the column FMA
+            if key.endswith("_sym"):                     # one rhs, every pair once, both sums from one evaluation
+                evals = (stats.p2p_pairs + N) / 2.0 if ph == "P2P" else float(stats.wx_pairs)
+                per_eval = ipp
+            else:                                        # ordered pairs: one evaluation serves the K row sums
+                evals = float(stats.p2p_pairs) if ph == "P2P" else float(stats.wx_pairs)
+                per_eval = ipp - 2 + K
+            e["valu_issue"] = {"kernel_evaluations": evals, "fp64_valu_instr_per_evaluation": per_eval,
+                               "achieved_lane_instr_per_s": evals * per_eval / sec, "peak_lane_instr_per_s": FP64_VALU_LANE_INSTR_PEAK,
+                               "frac": evals * per_eval / sec / FP64_VALU_LANE_INSTR_PEAK, "counted_from": instr["file"]}
         out[ph] = e
     return out
 
@@ -450,9 +455,8 @@ def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None):
     if rank != 0:
         return None
     # a phase interval brackets all launches of the phase (rhs chunks, column chunks): per interval = per pass
-    per_step = {k: (phases[k] / counts[k] if counts[k] else 0.0) for k in phases}
     per_step_total = {k: phases[k] / steps for k in phases}
-    _, roof = roofline_of(stats, K, per_step, world)
+    _, roof = roofline_of(stats, K, per_step_total, world, {k: counts[k] // max(steps, 1) for k in counts})
     err = dense_rows_err(torch, dev, cfg["kernel"], cfg["base_range"], cfg["total_sill"], pts, w, out)
     ext = {}
     if cfg.get("direct_small_w_leaves"):
@@ -582,11 +586,11 @@ def main():
 
     line = None
     if rank == 0:
-        per_launch = {k: (phases[k] / counts[k] if counts[k] else 0.0) for k in phases}
+        per_launch = {k: phases[k] / args.steps for k in phases}
         n = stats.n_nodes
         C = stats.n_cells
         # algorithmic work per launch (this rank; at N=1 the whole matvec) -- DESIGN.md section 5
-        dominant, roofline = roofline_of(stats, K, per_launch, world)
+        dominant, roofline = roofline_of(stats, K, per_launch, world, {k: counts[k] // max(args.steps, 1) for k in counts})
         # HBM-side bytes and MFMA-pipe utilisation of the dominant kernel from the committed PMC passes of this
         # same command on these same sources (FETCH_SIZE x2 (gfx950 correction for 16-B/lane reads) +
         # WRITE_SIZE, KiB -> bytes, per launch; derived metrics MfmaUtil, MfmaFlopsF64); null otherwise.

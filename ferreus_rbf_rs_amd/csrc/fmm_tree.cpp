@@ -544,6 +544,13 @@ int FmmTree::build_m2l_tables() {
     m2l_flops_k1_ = 0;
     m2l_flops_level_.clear();
     if (t.depth < 2) return BBFMM_OK;
+    // budget of the intermediate: a sixteenth of the device's memory (18 GiB on a 288 GB MI355X: the slots of one
+    // right-hand side of a 10M-point tree fit at orders 7 and 9), at least 4 GiB; 16 GiB without a device
+    if (!host_only_) {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && total_b > 0)
+            m2l_budget_bytes_ = std::max<int64_t>(int64_t(4) << 30, static_cast<int64_t>(total_b / 16));
+    }
     if (const char *e = std::getenv("BBFMM_M2L_CBUF_MB")) { // read per handle (tests vary it inside one process)
         const double mb = std::atof(e); // fractions allowed (the CPU tests cut small trees into groups)
         if (mb > 0) m2l_budget_bytes_ = static_cast<int64_t>(mb * 1048576.0);

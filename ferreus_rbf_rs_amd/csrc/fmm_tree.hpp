@@ -263,7 +263,7 @@ class FmmTree {
     std::vector<uint16_t> m2l_qlist_h_;
     // cbuf: bounded intermediate of the two M2L stages.  The batches run one after another through one buffer of
     // cbuf_batch_len_ doubles per right-hand side (the largest batch + the dump area); m2l_rhs_chunk_ right-hand sides
-    // go through it per pass.  Budget: BBFMM_M2L_CBUF_MB (default 16384).
+    // go through it per pass.  Budget: BBFMM_M2L_CBUF_MB (default: a sixteenth of the device memory, at least 4096).
     std::vector<M2lBatch> m2l_batches_;
     std::vector<int32_t> m2l_batch_of_class_;          // per device class (level classes, then variants / group operators)
     std::vector<std::vector<int32_t>> m2l_group_ops_;  // per level class: its stage-1 group operators (indices into

@@ -271,7 +271,8 @@ typedef struct {
     /* The intermediate of the two M2L stages (one slot of sum_t rank_t doubles per target cell; the reference holds
      * none, bbfmm.rs:864-986 multiplies pair by pair) is bounded: the levels -- or, for a level that alone exceeds the
      * budget, 2 / 4 / 8 groups of its target classes -- go through one buffer in `m2l_batches` passes, a few
-     * right-hand sides at a time.  Budget: BBFMM_M2L_CBUF_MB (default 16384). */
+     * right-hand sides at a time.  Budget: BBFMM_M2L_CBUF_MB (default: a sixteenth of the device's memory, 18 GiB on
+     * MI355X, at least 4096). */
     int32_t m2l_batches;                     /* passes through the buffer per right-hand-side chunk                        */
     int32_t m2l_rhs_per_pass;                /* right-hand sides per pass (0 until weights were set)                        */
     int64_t m2l_slots_bytes_per_rhs;         /* all slots of one right-hand side (what an unbounded buffer would hold)      */

@@ -359,7 +359,7 @@ def test_eighty_million_points_depth_seven_tree():
     w = torch.rand((2, n), dtype=torch.float64, device="cuda", generator=g) - 0.5
     y = torch.zeros_like(w)
     t.matvec_device(w.data_ptr(), n, 1, y[0].data_ptr(), n, True)
-    assert t.stats().m2l_intermediate_bytes < 17.2e9                       # the budget (16 GiB), not 87 GB
+    assert t.stats().m2l_intermediate_bytes < 20e9                         # the budget (a sixteenth of the device memory), not 87 GB
     t.matvec_device(w[1].data_ptr(), n, 1, y[1].data_ptr(), n, True)
     a, b = 0.75, -1.25
     wc = (a * w[0] + b * w[1]).contiguous()
