@@ -529,6 +529,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE JSON line: whatever a library prints there (gloo's connection notes, RCCL's banner) goes to
+    # stderr instead -- file descriptor 1 is pointed at stderr for the whole run and the line is written to the saved one
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world > 1:  # every rank builds the whole tree: share the host cores instead of 8 x 64 setup threads
         os.environ.setdefault("BBFMM_HOST_THREADS", str(max(4, (os.cpu_count() or 8) // world)))
 
@@ -688,7 +693,8 @@ def main():
             line["configs"] = extra
         if world == 1 and args.cpu_baseline != "off":
             line["cpu_baseline"] = cpu_baseline(args, kernel_id)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
