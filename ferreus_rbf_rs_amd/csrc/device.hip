@@ -1366,7 +1366,9 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     extern __shared__ double lds[];
     // experiment switches of stage 1 ride in the high bits of slot_t (profiles/: where the store tail goes)
     const bool s1_no_store = STAGE == 1 && (slot_t & (1 << 30)) != 0, s1_nt_store = STAGE == 1 && (slot_t & (1 << 29)) != 0;
-    if (STAGE == 1) slot_t &= 0xffff;
+    // timing-only switches of the per-step synchronisation (wrong results): no wait for the DMA / no workgroup barrier
+    const bool dbg_nowait = (slot_t & (1 << 28)) != 0, dbg_nobar = (slot_t & (1 << 27)) != 0;
+    slot_t &= 0xffff;
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
     const int kr = blockIdx.y;
@@ -1620,7 +1622,9 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                 continue;
             }
         }
-        wait_dma_and_barrier();
+        if (dbg_nowait) __syncthreads();
+        else if (dbg_nobar) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else wait_dma_and_barrier();
     }
 }
 
@@ -1922,8 +1926,14 @@ static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, i
         if (dev >= 0 && dev < 256) attr_set[dev >> 6].fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
     const int zdim = STAGE == 2 && slot_t > 1 ? n_colblocks * slot_t : n_colblocks; // stage 2: slot_t = parts of the contraction
+    // BBFMM_M2L_DEBUG_SYNC=nowait | nobar: the per-step DMA wait / workgroup barrier left out (timing only, wrong results)
+    static const int sync_flags = [] {
+        const char *e = std::getenv("BBFMM_M2L_DEBUG_SYNC");
+        if (!e) return 0;
+        return std::string(e) == "nowait" ? (1 << 28) : std::string(e) == "nobar" ? (1 << 27) : 0;
+    }();
     hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, zdim), dim3(512), lds, s, classes,
-                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t, tile_idx);
+                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t | sync_flags, tile_idx);
 }
 
 // Column-chunk plan: 16-column groups per workgroup.  Stage 1 walks column blocks of kM2lS1Block =

@@ -19,6 +19,10 @@ for v in default off nt; do
   cd $ROOT
 done
 unset BBFMM_M2L_S1_STORES
+# the per-step synchronisation of both stages, timing only (wrong results): no wait for the LDS-DMA / no workgroup barrier
+for v in nowait nobar; do
+  BBFMM_M2L_DEBUG_SYNC=$v python3 bench.py --steps 20 --warmup 3 --configs off --cpu-baseline off > gpurun_out/${TAG}_s1_sync_$v.json 2>/dev/null
+done
 python3 - "$TAG" "$COUNTERS" <<'PY'
 import csv, glob, json, os, sys
 tag, counters = sys.argv[1], sys.argv[2].split()
@@ -40,8 +44,15 @@ for v in ("default", "off", "nt"):
         if vals:
             e[c] = sum(vals) / len(vals)
     res["variants"][v] = e
+res["sync"] = {}
+for v in ("nowait", "nobar"):
+    j = json.load(open(root + '/%s_s1_sync_%s.json' % (tag, v)))
+    res["sync"][v] = {"stage1_ms": j["phase_ms_per_step"]["M2L_stage1"], "stage2_ms": j["phase_ms_per_step"]["M2L_stage2"]}
+res["sync"]["note"] = ("BBFMM_M2L_DEBUG_SYNC=nowait: the per-step s_waitcnt vmcnt(0) for the LDS-DMA left out; nobar: the per-step "
+                       "workgroup barrier left out -- both stages, timing only")
 json.dump(res, open(root + '/%s_stage1_experiments.json' % tag, 'w'), indent=1)
 lines = ["%-10s %s" % (v, "  ".join("%s=%s" % (k, ("%.4g" % x) if isinstance(x, float) else x) for k, x in e.items())) for v, e in res["variants"].items()]
+lines += ["sync %-7s stage1_ms=%.4g stage2_ms=%.4g" % (v, e["stage1_ms"], e["stage2_ms"]) for v, e in res["sync"].items() if v != "note"]
 open(root + '/%s_stage1_experiments.txt' % tag, 'w').write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
