@@ -60,6 +60,22 @@ static inline int grid_for(int64_t n, int block) {
     return (int)g;
 }
 
+// the same for a subset of the sorted positions (a partition reads the weights of its subtree and halo only)
+__global__ void gather_weights_subset_kernel(const double *__restrict__ w, int64_t ldw, const int32_t *__restrict__ order,
+                                             const int32_t *__restrict__ pos, int64_t n_pos, int64_t N, double *__restrict__ ws) {
+    const int k = blockIdx.y;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n_pos; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t i = pos[t];
+        ws[k * N + i] = w[k * ldw + order[i]];
+    }
+}
+void launch_gather_weights_subset(const double *w, int64_t ldw, int K, const int32_t *order, const int32_t *pos, int64_t n_pos,
+                                  int64_t N, double *w_sorted, hipStream_t s) {
+    if (n_pos == 0) return;
+    hipLaunchKernelGGL(gather_weights_subset_kernel, dim3(grid_for(n_pos, 256), K), dim3(256), 0, s, w, ldw, order, pos, n_pos, N,
+                       w_sorted);
+}
+
 void launch_gather_weights(const double *w, int64_t ldw, int K, const int32_t *order, int64_t N, double *w_sorted,
                            hipStream_t s) {
     if (N == 0) return;

@@ -70,6 +70,8 @@ struct M2lTileDesc { // one workgroup of stage 1 or stage 2
 // ---- launchers (all asynchronous on `s`) ----
 void launch_gather_weights(const double *w, int64_t ldw, int K, const int32_t *order, int64_t N,
                            double *w_sorted, hipStream_t s);
+void launch_gather_weights_subset(const double *w, int64_t ldw, int K, const int32_t *order, const int32_t *pos, int64_t n_pos,
+                                  int64_t N, double *w_sorted, hipStream_t s);
 void launch_scatter_output(const double *out_sorted, int64_t n, int K, const int32_t *perm,
                            double *out, int64_t ldo, int accumulate, hipStream_t s);
 void launch_gather_rows(const double *src, int64_t ld_src, int ncols, const int32_t *idx, int64_t n,

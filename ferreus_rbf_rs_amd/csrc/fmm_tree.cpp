@@ -1035,6 +1035,11 @@ int FmmTree::build_m2l_tables() {
     // launch lists, batch by batch: stage 1 from the per-batch lists, stage 2 = the class tiles (classes of a batch
     // are consecutive) with the tail of every batch split
     m2l_tiles2_h_.clear();
+    const bool unrestricted_blocks = [] {
+        const char *e = std::getenv("BBFMM_M2L_S1_BLOCK_TILES");
+        return e && std::atoi(e) != 0;
+    }();
+    m2l_s1_block_tiles_ = unrestricted_blocks;
     {
         size_t next = 0;
         for (size_t b = 0; b < m2l_batches_.size(); ++b) {
@@ -1042,7 +1047,25 @@ int FmmTree::build_m2l_tables() {
             mb.t1_first = static_cast<int32_t>(m2l_tiles1_h_.size());
             for (M2lTileDesc td : tiles1_of_batch[b]) {
                 if (td.level_class < 0) td.level_class = static_cast<int32_t>(m2l_host_.size()) + (-1 - td.level_class);
-                m2l_tiles1_h_.push_back(td);
+                if (!unrestricted_blocks) {
+                    m2l_tiles1_h_.push_back(td);
+                    continue;
+                }
+                // experiment (BBFMM_M2L_S1_BLOCK_TILES=1): one tile per column block instead of one persistent walk
+                const bool variant = static_cast<size_t>(td.level_class) >= m2l_host_.size();
+                const HostM2lClass &hc = variant ? m2l_variants_[static_cast<size_t>(td.level_class) - m2l_host_.size()]
+                                                 : m2l_host_[static_cast<size_t>(td.level_class)];
+                if (td.pad == 0) { // contiguous positions: spell them out
+                    const int32_t first = td.first;
+                    td.first = static_cast<int32_t>(m2l_tile_idx1_h_.size());
+                    for (int32_t q = 0; q < td.count; ++q) m2l_tile_idx1_h_.push_back(first + q);
+                }
+                td.pad = 2;
+                td.q_count = 1;
+                for (int zb = 0; zb < hc.r_pad16 / kM2lS1Block; ++zb) {
+                    td.q_first = zb;
+                    m2l_tiles1_h_.push_back(td);
+                }
             }
             mb.t1_count = static_cast<int32_t>(m2l_tiles1_h_.size()) - mb.t1_first;
             std::vector<M2lTileDesc> part;
@@ -2095,7 +2118,7 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
         double *l_chunk = l_out + static_cast<size_t>(k0) * C * m2l_len;
         for (int b = 0; b < nb; ++b) {
             const M2lBatch &mb = m2l_batches_[static_cast<size_t>(b)];
-            const int t1_first = dp ? dp->batch_t1[2 * b] : mb.t1_first, t1_count = dp ? dp->batch_t1[2 * b + 1] : mb.t1_count;
+            const int t1_first = dp ? dp->batch_t1[4 * b] : mb.t1_first, t1_count = dp ? dp->batch_t1[4 * b + 1] : mb.t1_count;
             const int t2_first = dp ? dp->batch_t2[2 * b] : mb.t2_first, t2_count = dp ? dp->batch_t2[2 * b + 1] : mb.t2_count;
             if (t2_count == 0) continue; // no target of this batch is active: nobody reads its slots
             phase_begin();
@@ -2103,12 +2126,14 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
                 launch_m2l_zero_segments(d_m2l_zero_.p + 2 * m2l_zero_ptr_[static_cast<size_t>(b)],
                                          m2l_zero_ptr_[static_cast<size_t>(b) + 1] - m2l_zero_ptr_[static_cast<size_t>(b)], kb, d_cbuf_.p,
                                          cbuf_batch_len_, stream_);
-            if (dp)
+            if (dp) { // whole-operator tiles, then the tiles of single column blocks (sources in the halo of the target set)
                 launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p + t1_first, dp->d_tile_idx.p, t1_count, m2l_len, m2l_slot_t_, kb,
-                                  C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, dp->tiles1_own_blocks);
-            else
+                                  C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, false);
+                launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p + dp->batch_t1[4 * b + 2], dp->d_tile_idx.p, dp->batch_t1[4 * b + 3],
+                                  m2l_len, m2l_slot_t_, kb, C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, true);
+            } else
                 launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p + t1_first, d_tile_idx1_.p, t1_count, m2l_len, m2l_slot_t_, kb, C,
-                                  m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_);
+                                  m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, m2l_s1_block_tiles_);
             phase_end(kPhM2L1);
             phase_begin();
             if (dp)
@@ -2384,8 +2409,9 @@ int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, doub
     CHK(ensure_rhs_capacity(k));
     nrhs_ = k;
     have_locals_ = locals_requested_ = false;
-    phase_begin();
-    launch_gather_weights(d_w, ldw, k, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_begin(); // only the weights this rank reads: its subtree and halo (the rest of w_sorted keeps stale values)
+    launch_gather_weights_subset(d_w, ldw, k, d_order_.p, part_plan_.d_gather_pos.p, static_cast<int64_t>(part_plan_.gather_pos_h.size()), N,
+                                 d_w_sorted_.p, stream_);
     phase_end(kPhGather);
     if (part_targets_.out.n < static_cast<size_t>(k) * part_targets_.m) {
         dfree(&part_targets_.out);
@@ -2630,8 +2656,6 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
             tiles->push_back(td);
         }
     };
-    for (const SrcOp &so : sops)
-        add_tiles(needed, so.bit, so.dev_class, so.h->cells, &t1b[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(so.dev_class)])]);
     std::vector<int> tpos_of(static_cast<size_t>(ops_.n_vec));
     for (size_t lc = 0; lc < m2l_host_.size(); ++lc) {
         const HostM2lClass &hc = m2l_host_[lc];
@@ -2670,13 +2694,29 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         }
     }
     for (auto &tl : t2b) split_tile_tail(&tl, n_cu_);
-    // Sparse target sets: a needed source cell still needs only the column blocks (kM2lS1Block stacked
-    // rows = a few transfer vectors) that hold a transfer vector towards an ACTIVE target.  When that is
-    // well under the whole operator, stage 1 runs one tile per (column block, the sources it needs).
+    // Stage-1 tiles.  A needed source cell needs only the column blocks (kM2lS1Block stacked rows = a few transfer
+    // vectors) that hold a transfer vector towards an ACTIVE target: all of them inside the target set, about half in
+    // its three-cell halo (a partition's subtree: 31 % of the needed cells at eight ranks), a handful for scattered
+    // targets.  The plan holds one tile per (column block, the sources that need it).  Measured at 10M points (stage 1
+    // of one rank of 2 / 3 / 4 / 8): whole-operator tiles for every needed cell 9.79 / - / 5.64 / 3.28 ms; whole
+    // operators for the cells that need at least 80 % of their blocks and per-block tiles for the rest 10.03 / 6.96 /
+    // 5.34 / 2.94; per-block tiles throughout 9.75 / 6.72 / 5.12 / 2.72 -- thousands of short tiles leave no launch
+    // tail, and a persistent walk over the blocks buys almost nothing (the unrestricted 10M-point stage 1 as per-block
+    // tiles: 17.25 against 17.14 ms).  The analysis runs for partitions and for target sets under half of the cells;
+    // denser sets take whole operators.  BBFMM_M2L_SPARSE_RATIO = r: cells needing at least r of their blocks go
+    // into whole-operator tiles (0: whole operators only; default 2 = per-block tiles only).
+    std::vector<std::vector<M2lTileDesc>> t1s(nb); // per-block tiles
     int64_t n_active = 0;
     for (uint8_t a : active) n_active += a;
-    dp->tiles1_own_blocks = false;
-    if (n_active * 2 < C) { // (denser sets need nearly every block of every source: skip the analysis)
+    static const double full_ratio = [] {
+        const char *e = std::getenv("BBFMM_M2L_SPARSE_RATIO");
+        return e ? std::atof(e) : 2.0;
+    }();
+    const bool analyse = full_ratio > 0.0 && (restrict_upward || n_active * 2 < C);
+    if (!analyse) {
+        for (const SrcOp &so : sops)
+            add_tiles(needed, so.bit, so.dev_class, so.h->cells, &t1b[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(so.dev_class)])]);
+    } else {
         std::vector<int64_t> bm_off(sops.size() + 1, 0); // per source operator: n_blk x n_cells flags
         for (size_t si = 0; si < sops.size(); ++si)
             bm_off[si + 1] = bm_off[si] + static_cast<int64_t>(sops[si].h->r_pad16 / kM2lS1Block) * static_cast<int64_t>(sops[si].h->cells.size());
@@ -2708,50 +2748,62 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
                 }
             }
         });
-        int64_t whole = 0, part = 0; // cell-blocks of work: needed cells x all blocks, against the flagged ones
-        for (const SrcOp &so : sops) {
-            int64_t nn = 0;
-            for (int32_t c : so.h->cells) nn += (needed[c] & so.bit) ? 1 : 0;
-            whole += nn * (so.h->r_pad16 / kM2lS1Block);
-        }
-        for (uint8_t f : bm) part += f;
-        static const double max_ratio = [] {
-            const char *e = std::getenv("BBFMM_M2L_SPARSE_RATIO");
-            return e ? std::atof(e) : 0.9;
-        }();
-        dp->tiles1_own_blocks = whole > 0 && static_cast<double>(part) < max_ratio * static_cast<double>(whole);
-        if (dp->tiles1_own_blocks) {
-            for (auto &tl : t1b) tl.clear();
-            for (size_t si = 0; si < sops.size(); ++si) {
-                const HostM2lClass &hs = *sops[si].h;
-                const int64_t nc = static_cast<int64_t>(hs.cells.size());
-                std::vector<M2lTileDesc> &out = t1b[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(sops[si].dev_class)])];
-                for (int zb = 0; zb < hs.r_pad16 / kM2lS1Block; ++zb) {
-                    const size_t start = dp->tile_idx_h.size();
-                    const uint8_t *f = &bm[static_cast<size_t>(bm_off[si] + zb * nc)];
-                    for (int64_t i = 0; i < nc; ++i)
-                        if (f[i]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
-                    for (size_t fst = start; fst < dp->tile_idx_h.size(); fst += kM2lTile) {
-                        M2lTileDesc td;
-                        std::memset(&td, 0, sizeof td);
-                        td.level_class = sops[si].dev_class;
-                        td.first = static_cast<int32_t>(fst);
-                        td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - fst));
-                        td.q_first = zb;
-                        td.q_count = 1;
-                        td.pad = 2;
-                        out.push_back(td);
-                    }
+        for (size_t si = 0; si < sops.size(); ++si) {
+            const HostM2lClass &hs = *sops[si].h;
+            const int64_t nc = static_cast<int64_t>(hs.cells.size());
+            const int n_blk = hs.r_pad16 / kM2lS1Block;
+            const size_t bidx = static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(sops[si].dev_class)]);
+            // whole-operator cells
+            std::vector<uint8_t> whole(static_cast<size_t>(nc), 0);
+            const size_t start_full = dp->tile_idx_h.size();
+            for (int64_t i = 0; i < nc; ++i) {
+                int cnt = 0;
+                for (int zb = 0; zb < n_blk; ++zb) cnt += bm[static_cast<size_t>(bm_off[si] + zb * nc + i)];
+                if (cnt > 0 && static_cast<double>(cnt) >= full_ratio * n_blk) {
+                    whole[static_cast<size_t>(i)] = 1;
+                    dp->tile_idx_h.push_back(static_cast<int32_t>(i));
+                }
+            }
+            for (size_t fst = start_full; fst < dp->tile_idx_h.size(); fst += kM2lTile) {
+                M2lTileDesc td;
+                std::memset(&td, 0, sizeof td);
+                td.level_class = sops[si].dev_class;
+                td.first = static_cast<int32_t>(fst);
+                td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - fst));
+                td.pad = 1;
+                t1b[bidx].push_back(td);
+            }
+            // the rest, block by block
+            for (int zb = 0; zb < n_blk; ++zb) {
+                const size_t start = dp->tile_idx_h.size();
+                const uint8_t *f = &bm[static_cast<size_t>(bm_off[si] + zb * nc)];
+                for (int64_t i = 0; i < nc; ++i)
+                    if (f[i] && !whole[static_cast<size_t>(i)]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
+                for (size_t fst = start; fst < dp->tile_idx_h.size(); fst += kM2lTile) {
+                    M2lTileDesc td;
+                    std::memset(&td, 0, sizeof td);
+                    td.level_class = sops[si].dev_class;
+                    td.first = static_cast<int32_t>(fst);
+                    td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - fst));
+                    td.q_first = zb;
+                    td.q_count = 1;
+                    td.pad = 2;
+                    t1s[bidx].push_back(td);
                 }
             }
         }
     }
-    dp->batch_t1.assign(2 * nb, 0);
+    dp->batch_t1.assign(4 * nb, 0); // per batch: whole-operator tiles (first, count), per-block tiles (first, count)
     dp->batch_t2.assign(2 * nb, 0);
+    dp->n_tiles1_blocks = 0;
     for (size_t b = 0; b < nb; ++b) {
-        dp->batch_t1[2 * b] = static_cast<int32_t>(dp->tiles1_h.size());
-        dp->batch_t1[2 * b + 1] = static_cast<int32_t>(t1b[b].size());
+        dp->batch_t1[4 * b] = static_cast<int32_t>(dp->tiles1_h.size());
+        dp->batch_t1[4 * b + 1] = static_cast<int32_t>(t1b[b].size());
         dp->tiles1_h.insert(dp->tiles1_h.end(), t1b[b].begin(), t1b[b].end());
+        dp->batch_t1[4 * b + 2] = static_cast<int32_t>(dp->tiles1_h.size());
+        dp->batch_t1[4 * b + 3] = static_cast<int32_t>(t1s[b].size());
+        dp->tiles1_h.insert(dp->tiles1_h.end(), t1s[b].begin(), t1s[b].end());
+        dp->n_tiles1_blocks += static_cast<int64_t>(t1s[b].size());
         dp->batch_t2[2 * b] = static_cast<int32_t>(dp->tiles2_h.size());
         dp->batch_t2[2 * b + 1] = static_cast<int32_t>(t2b[b].size());
         dp->tiles2_h.insert(dp->tiles2_h.end(), t2b[b].begin(), t2b[b].end());
@@ -2819,6 +2871,21 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         for (int64_t c = 0; c < C; ++c) dp->reads_h[static_cast<size_t>(c)] = needed[static_cast<size_t>(c)] ? 1 : 0;
         for (int32_t leaf : target_leaves)
             for (int64_t q = t.w.ptr[leaf]; q < t.w.ptr[leaf + 1]; ++q) dp->reads_h[t.w.idx[q]] = 1;
+        // weights read: the points of the anterpolated leaves, of the U lists of the target leaves (near field) and of
+        // the X lists of the active cells (P2L) -- as sorted positions, for the restricted gather
+        {
+            std::vector<uint8_t> leaf_read(static_cast<size_t>(C), 0);
+            for (int32_t c : dp->up_leaves_h) leaf_read[static_cast<size_t>(c)] = 1;
+            for (int32_t leaf : target_leaves)
+                for (int64_t q = t.u.ptr[leaf]; q < t.u.ptr[leaf + 1]; ++q) leaf_read[static_cast<size_t>(t.u.idx[q])] = 1;
+            for (int32_t c : x_cells_)
+                if (active[c])
+                    for (int64_t q = t.x.ptr[c]; q < t.x.ptr[c + 1]; ++q) leaf_read[static_cast<size_t>(t.x.idx[q])] = 1;
+            dp->gather_pos_h.clear();
+            for (int32_t c : src_leaves_) // sorted by position
+                if (leaf_read[static_cast<size_t>(c)])
+                    for (int64_t i = t.pt_begin[c]; i < t.pt_end[c]; ++i) dp->gather_pos_h.push_back(static_cast<int32_t>(i));
+        }
         // children lists: the parents of level Lc sum the children they own only
         dp->part_child_ptr_h.assign(static_cast<size_t>(C) + 1, 0);
         dp->part_child_idx_h.reserve(t.children.idx.size());
@@ -2836,6 +2903,7 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
         CHK(tupload(&dp->d_up_leaves, dp->up_leaves_h));
         dp->d_up_parents.resize(dp->up_parents_h.size());
         for (size_t l = 0; l < dp->up_parents_h.size(); ++l) CHK(tupload(&dp->d_up_parents[l], dp->up_parents_h[l]));
+        CHK(tupload(&dp->d_gather_pos, dp->gather_pos_h));
         CHK(tupload(&dp->d_part_child_ptr, dp->part_child_ptr_h));
         CHK(tupload(&dp->d_part_child_idx, dp->part_child_idx_h));
     }
@@ -2855,6 +2923,7 @@ void FmmTree::free_downward_plan(DownwardPlan *dp) {
     for (auto &b : dp->d_up_parents) dfree(&b);
     dfree(&dp->d_part_child_ptr);
     dfree(&dp->d_part_child_idx);
+    dfree(&dp->d_gather_pos);
     dfree(&dp->d_active);
     dfree(&dp->d_tiles2);
     dfree(&dp->d_tiles1);
@@ -2935,7 +3004,7 @@ int FmmTree::fill_subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan *sp)
         std::fprintf(stderr, "[bbfmm] subset plan: %lld rows, target set %.3f s, downward plan %.3f s (%zu stage-1 tiles%s)\n",
                      static_cast<long long>(m), std::chrono::duration<double>(t_1 - t_0).count(),
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_1).count(), sp->dp.tiles1_h.size(),
-                     sp->dp.tiles1_own_blocks ? ", one column block each" : "");
+                     sp->dp.n_tiles1_blocks > 0 ? ", of which some cover one column block each" : "");
     if (rc == BBFMM_OK) rc = dalloc(&sp->ts.out, static_cast<size_t>(std::max<int64_t>(m, 1)));
     if (rc != BBFMM_OK) {
         free_target_set(&sp->ts);

@@ -90,8 +90,9 @@ struct DownwardPlan {
     std::vector<uint8_t> active;            // cells with targets (leaves and their ancestors)
     std::vector<M2lTileDesc> tiles2_h;      // compact stage-2 tiles over the active cells (tail split), batch by batch
     std::vector<M2lTileDesc> tiles1_h;      // compact stage-1 tiles over the V-list sources of active cells, batch by batch
-    std::vector<int32_t> batch_t1, batch_t2; // 2 per batch: first tile and count in the two lists
-    bool tiles1_own_blocks = false;         // sparse plan: a stage-1 tile per (column block, sources that block needs)
+    std::vector<int32_t> batch_t1, batch_t2; // per batch: stage 1 (first, count) of the whole-operator tiles and of the
+                                             // per-block tiles (4 ints); stage 2 (first, count)
+    int64_t n_tiles1_blocks = 0;            // stage-1 tiles that cover one column block (sources needing few blocks)
     std::vector<int32_t> tile_idx_h;        // class positions of the cells of both tile lists
     std::vector<uint16_t> qlist_h;          // active contraction steps of the stage-2 tiles
     int n_x_jobs = 0;
@@ -110,6 +111,8 @@ struct DownwardPlan {
     std::vector<int64_t> part_child_ptr_h;          // children CSR with the rows of level coarse_level cut to the
     std::vector<int32_t> part_child_idx_h;          // children this rank owns
     std::vector<uint8_t> reads_h;                   // cells whose multipoles the rank's downward / leaf pass reads
+    std::vector<int32_t> gather_pos_h;              // sorted source positions whose weights the rank reads (P2M of its
+    DevBuf<int32_t> d_gather_pos;                   // share, near field and X lists of its targets)
     DevBuf<int32_t> d_up_leaves;
     std::vector<DevBuf<int32_t>> d_up_parents;
     DevBuf<int64_t> d_part_child_ptr;
@@ -274,6 +277,7 @@ class FmmTree {
     int64_t cbuf_total_len_ = 0;                       // sum of all slots (what one unbounded buffer would hold)
     int64_t m2l_budget_bytes_ = int64_t(16384) << 20;
     int m2l_rhs_chunk_ = 1;
+    bool m2l_s1_block_tiles_ = false; // experiment: the unrestricted stage 1 as one tile per column block
     double m2l_flops_k1_ = 0;
     int n_cu_ = 256;      // compute units of the device (tail splitting of the tile lists)
     int device_ = -1;     // the HIP device that was current in create(): every entry point binds its thread to it
