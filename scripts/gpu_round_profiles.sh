@@ -53,7 +53,13 @@ for k, v in sorted(agg.items()):
     lines.append(line)
     if k in phase:
         p = phase[k]
-        if fb is not None and wb is not None: per_bytes[p] = fb + wb
+        # (a phase that runs two kernels per step -- the near field: wave jobs + workgroup jobs -- adds their bytes and
+        # keeps the counters of the one that moves more)
+        if fb is not None and wb is not None:
+            if p in per_bytes and per_bytes[p] > fb + wb:
+                per_bytes[p] += fb + wb
+                continue
+            per_bytes[p] = per_bytes.get(p, 0.0) + fb + wb
         per_kernel[p] = {'mfma_util_pct': mean(v.get('MfmaUtil')) if v.get('MfmaFlopsF64') and max(v['MfmaFlopsF64']) > 0 else None,
                          'executed_fp64_mfma_flops_per_launch': mean(v.get('MfmaFlopsF64')),
                          'valu_busy_pct': mean(v.get('VALUBusy')), 'valu_utilization_pct': mean(v.get('VALUUtilization'))}
