@@ -15,7 +15,9 @@ cases = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 
 
-def cloud(kind, n):
+def cloud(kind, n, d=3):
+    if d < 3:
+        return np.unique(np.vstack([rng.random((n // 2, d)), np.clip(rng.normal(size=(n - n // 2, d)) * 0.05 + 0.3, 0.0, 0.999)]), axis=0)
     if kind == "uniform":
         return rng.random((n, 3))
     if kind == "clustered":
@@ -38,22 +40,27 @@ for case in range(cases):
     leaf = int(rng.integers(30, 257))
     frac = [0.5, 0.12, 0.03][int(rng.integers(0, 3))]
     world = [2, 3, 5][int(rng.integers(0, 3))]
-    pts = cloud(kind, n)
+    d = [3, 3, 3, 2, 1][int(rng.integers(0, 5))]
+    adaptive, sparse = bool(rng.integers(0, 4) > 0), bool(rng.integers(0, 4) > 0)
+    if d < 3:
+        n = min(n, 120_000)
+    pts = cloud(kind, n, d)
     n = pts.shape[0]
     kp = F.KernelParams(F.KernelType(kid), base_range=0.3, total_sill=0.2)
     par = F.FmmParams(leaf, 2, 10.0 ** -order, 1024)
     os.environ.pop("BBFMM_M2L_CBUF_MB", None)
-    ref_t = F.FmmTree(pts, order, kp, True, True, params=par)
+    mk = lambda **kw: F.FmmTree(pts, order, kp, adaptive, sparse, params=par, **kw)
+    ref_t = mk()
     st = ref_t.stats()
     w = torch.from_numpy(rng.standard_normal((K, n))).cuda()
     ref = torch.zeros_like(w)
     ref_t.matvec_device(w.data_ptr(), n, K, ref.data_ptr(), n, True)
     scale = float(ref.abs().max())
-    res = {"case": case, "cloud": kind, "n": n, "order": order, "kernel": kid, "K": K, "leaf": leaf, "depth": st.depth, "n_w": st.n_w}
+    res = {"case": case, "cloud": kind, "d": d, "adaptive": adaptive, "sparse": sparse, "n": n, "order": order, "kernel": kid, "K": K, "leaf": leaf, "depth": st.depth, "n_w": st.n_w}
     # (1) small budget
     if st.m2l_slots_bytes_per_rhs > 0:
         os.environ["BBFMM_M2L_CBUF_MB"] = "%.6f" % (frac * st.m2l_slots_bytes_per_rhs / 1048576.0)
-    t = F.FmmTree(pts, order, kp, True, True, params=par)
+    t = mk()
     os.environ.pop("BBFMM_M2L_CBUF_MB", None)
     out = torch.zeros_like(w)
     t.matvec_device(w.data_ptr(), n, K, out.data_ptr(), n, True)
@@ -80,15 +87,15 @@ for case in range(cases):
     res["err_partition"] = float((full - ref).abs().max()) / scale if not bool(torch.isnan(full).any()) else float("nan")
     del t
     # (3) deterministic handle
-    d = F.FmmTree(pts, order, kp, True, True, params=par, deterministic=True)
+    dt = mk(deterministic=True)
     o1, o2 = torch.zeros_like(w), torch.zeros_like(w)
-    d.matvec_device(w.data_ptr(), n, K, o1.data_ptr(), n, True)
-    d.matvec_device(w.data_ptr(), n, K, o2.data_ptr(), n, True)
+    dt.matvec_device(w.data_ptr(), n, K, o1.data_ptr(), n, True)
+    dt.matvec_device(w.data_ptr(), n, K, o2.data_ptr(), n, True)
     res["err_deterministic"] = float((o1 - ref).abs().max()) / scale
     res["deterministic_bitwise"] = bool(torch.equal(o1, o2))
     ok = res["err_budget"] < 1e-12 and res["err_partition"] < 1e-12 and res["err_deterministic"] < 1e-12 and res["deterministic_bitwise"]
     res["ok"] = bool(ok)
     fails += 0 if ok else 1
     print(json.dumps(res), flush=True)
-    del d, ref_t
+    del dt, ref_t
 print(json.dumps({"cases": cases, "failures": fails}))
