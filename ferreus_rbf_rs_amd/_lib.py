@@ -72,8 +72,8 @@ SIGNATURES = {
     "bbfmm_partition_row_count": (c_i64, [c_p]),
     "bbfmm_partition_rows": (ctypes.c_int, [c_p, c_p]),
     "bbfmm_partition_coarse_count": (c_i64, [c_p]),
-    "bbfmm_matvec_partition_upward": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p]),
-    "bbfmm_matvec_partition_finish": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i32]),
+    "bbfmm_matvec_partition_upward": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p]),
+    "bbfmm_matvec_partition_finish": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i32, c_p]),
     "bbfmm_debug_partition_upward_counts": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     "bbfmm_get_tree_stats": (ctypes.c_int, [c_p, c_p]),
     "bbfmm_tree_built_on_device": (ctypes.c_int, [c_p]),

@@ -191,13 +191,13 @@ int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out) {
 
 int64_t bbfmm_partition_coarse_count(const bbfmm_handle *h) { return h ? h->tree.partition_coarse_count() : -1; }
 
-int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse) {
-    GUARD(h) return h->tree.matvec_partition_upward(d_w, ldw, k, d_coarse);
+int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse, void *comm_stream) {
+    GUARD(h) return h->tree.matvec_partition_upward(d_w, ldw, k, d_coarse, static_cast<hipStream_t>(comm_stream));
     END_GUARD(h)
 }
 
-int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync) {
-    GUARD(h) return h->tree.matvec_partition_finish(d_coarse, d_out, ldo, sync != 0);
+int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync, void *comm_stream) {
+    GUARD(h) return h->tree.matvec_partition_finish(d_coarse, d_out, ldo, sync != 0, static_cast<hipStream_t>(comm_stream));
     END_GUARD(h)
 }
 

@@ -129,6 +129,8 @@ FmmTree::~FmmTree() {
     free_dev_tree_points(&dev_points_);
     if (ev_fork_) (void)hipEventDestroy(ev_fork_);
     if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (ev_pack_) (void)hipEventDestroy(ev_pack_);
+    if (ev_comm_) (void)hipEventDestroy(ev_comm_);
     if (stream2_) (void)hipStreamDestroy(stream2_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
@@ -338,6 +340,8 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
         HIPCHK(hipStreamCreate(&stream2_));
         HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_pack_, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_comm_, hipEventDisableTiming));
         timer.lap("device, streams");
     }
     // The subdivision (Morton codes, sort, cells, per-leaf point lists) runs on the device when there is one and
@@ -2400,7 +2404,7 @@ int64_t FmmTree::partition_coarse_count() const {
 
 // First half of the partitioned matvec: set_weights restricted to this rank's share of the upward pass
 // (bbfmm.rs:383-401, 666-772 split by subtree), partial coarse multipoles packed rhs-major into d_coarse.
-int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse) {
+int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse, hipStream_t comm_stream) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     if (!have_part_) return fail(BBFMM_BAD_ARGUMENT, "bbfmm_set_partition (world > 1) must be called first");
     const int64_t N = tree_.n_points, C = tree_.n_cells();
@@ -2423,6 +2427,14 @@ int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, doub
         HIPCHK(hipMemcpyAsync(d_coarse + static_cast<size_t>(j) * cnt, d_M_.p + static_cast<size_t>(j) * C * cheb_.n_pad,
                               static_cast<size_t>(cnt) * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     phase_end(kPhM2M);
+    // The collective may start as soon as the packed multipoles are there: the caller's communication stream waits for
+    // that point only, and the near field of the owned targets (P2P: needs the weights, not the multipoles) is queued
+    // behind it, so that the all-reduce runs beside it instead of in front of it.
+    if (comm_stream) {
+        HIPCHK(hipEventRecord(ev_pack_, stream_));
+        HIPCHK(hipStreamWaitEvent(comm_stream, ev_pack_, 0));
+    }
+    CHK(leaf_pass_near(part_targets_, k, false, stream_, 1));
     part_pending_k_ = k;
     return BBFMM_OK;
 }
@@ -2430,7 +2442,7 @@ int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, doub
 // Second half: d_coarse holds the sum over all ranks of what matvec_partition_upward packed (an all-reduce on this
 // handle's stream, or any stream ordered with it); evaluate at the owned targets (bbfmm.rs:444-507 over this
 // rank's cells_with_targets), owned rows of d_out written, the others untouched.
-int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync) {
+int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync, hipStream_t comm_stream) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     if (!have_part_ || part_pending_k_ < 1) return fail(BBFMM_BAD_ARGUMENT, "bbfmm_matvec_partition_upward must be called first");
     const int64_t N = tree_.n_points, C = tree_.n_cells();
@@ -2438,6 +2450,10 @@ int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int6
     const int k = part_pending_k_;
     if (!d_out || ldo < N || (cnt > 0 && !d_coarse)) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
     part_pending_k_ = 0;
+    if (comm_stream) { // the summed multipoles are ready when the communication stream gets here
+        HIPCHK(hipEventRecord(ev_comm_, comm_stream));
+        HIPCHK(hipStreamWaitEvent(stream_, ev_comm_, 0));
+    }
     phase_begin();
     for (int j = 0; j < k && cnt > 0; ++j)
         HIPCHK(hipMemcpyAsync(d_M_.p + static_cast<size_t>(j) * C * cheb_.n_pad, d_coarse + static_cast<size_t>(j) * cnt,
@@ -2445,7 +2461,7 @@ int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int6
     phase_end(kPhM2M);
     const TargetSet &ts = part_targets_;
     CHK(downward(k, &part_plan_));
-    CHK(leaf_pass_near(ts, k, false, stream_, 3));
+    CHK(leaf_pass_near(ts, k, false, stream_, 2)); // M2P (the outputs were zeroed and P2P ran in the first half)
     CHK(leaf_pass_far(ts, k, false));
     phase_begin();
     launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);

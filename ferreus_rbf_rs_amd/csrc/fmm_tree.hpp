@@ -159,8 +159,11 @@ class FmmTree {
     // upward: gather + own P2M / M2M, packs k x partition_coarse_count() partial multipoles into d_coarse;
     // finish: takes their sum over the ranks, runs the downward and leaf passes of the owned targets.
     int64_t partition_coarse_count() const;
-    int matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse);
-    int matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync);
+    // comm_stream (may be null): the stream the caller runs the all-reduce on.  It is made to wait for the packed
+    // multipoles only, so that the collective overlaps the near field queued behind the pack; finish makes the handle's
+    // stream wait for it.  Null: the caller orders the collective after the handle's stream itself.
+    int matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse, hipStream_t comm_stream);
+    int matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync, hipStream_t comm_stream);
     int register_subset(const int64_t *idx, int64_t n_idx, int *id_out);
     int matvec_subset_device(int id, const double *d_w, double *d_y, bool sync);
     int set_partition(int rank, int world);
@@ -302,6 +305,7 @@ class FmmTree {
     // ---- device state
     hipStream_t stream_ = nullptr, stream2_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipEvent_t ev_pack_ = nullptr, ev_comm_ = nullptr; // partitioned matvec: packed multipoles ready / all-reduce done
     struct PendingPhase {
         int phase;
         hipEvent_t e0, e1;

@@ -81,10 +81,11 @@ class OwnedRowsExchange:
 
 
 class PartitionedMatvec:
-    """One matvec of a partitioned handle: upward (own share) -> all-reduce of the coarse multipoles -> downward and
-    leaf pass of the owned targets -> all-gather of the owned potentials.  Everything is queued on the handle's HIP
-    stream (wrapped as a torch ExternalStream so that RCCL orders itself with the kernels); nothing synchronises the
-    host except the gloo staging path."""
+    """One matvec of a partitioned handle: upward (own share) -> all-reduce of the coarse multipoles, beside the near
+    field -> downward and leaf pass of the owned targets -> all-gather of the owned potentials.  The kernels and the
+    all-gather are queued on the handle's HIP stream (wrapped as a torch ExternalStream so that RCCL orders itself with
+    the kernels), the all-reduce on a second stream that the library orders with events; nothing synchronises the host
+    except the gloo staging path."""
 
     def __init__(self, tree, n_total: int, k: int, device, group=None):
         self.tree, self.group, self.k, self.n = tree, group, k, n_total
@@ -97,6 +98,9 @@ class PartitionedMatvec:
         if self.staged:
             self.h_coarse = torch.zeros((k, max(self.count, 1)), dtype=torch.float64).pin_memory()
         self.stream = torch.cuda.ExternalStream(tree.stream(), device=device) if device.type == "cuda" else None
+        # the all-reduce runs on its own stream: the library makes it wait for the packed multipoles only, so that the
+        # collective overlaps the near field queued behind the pack, and makes its own stream wait for it in `finish`
+        self.comm = torch.cuda.Stream(device=device) if device.type == "cuda" else None
 
     def check_partition(self) -> bool:
         return self.xchg.check_partition()
@@ -116,10 +120,11 @@ class PartitionedMatvec:
         if self.world == 1:
             self.tree.matvec_device(w.data_ptr(), self.n, self.k, out.data_ptr(), self.n, sync=False)
             return out
-        self.tree.matvec_partition_upward(w.data_ptr(), self.n, self.k, self.coarse.data_ptr())
-        with torch.cuda.stream(self.stream):
+        comm = self.comm.cuda_stream
+        self.tree.matvec_partition_upward(w.data_ptr(), self.n, self.k, self.coarse.data_ptr(), comm)
+        with torch.cuda.stream(self.comm):
             self.all_reduce_coarse()
-        self.tree.matvec_partition_finish(self.coarse.data_ptr(), out.data_ptr(), self.n, sync=False)
+        self.tree.matvec_partition_finish(self.coarse.data_ptr(), out.data_ptr(), self.n, False, comm)
         with torch.cuda.stream(self.stream):
             self.xchg.exchange(out)
         return out

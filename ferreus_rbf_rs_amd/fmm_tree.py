@@ -304,14 +304,15 @@ class FmmTree:
         """Doubles per right-hand side of the coarse multipoles a partition exchanges (0: none)."""
         return int(self._lib.bbfmm_partition_coarse_count(self._h))
 
-    def matvec_partition_upward(self, d_w: int, ldw: int, k: int, d_coarse: int):
+    def matvec_partition_upward(self, d_w: int, ldw: int, k: int, d_coarse: int, comm_stream: int = 0):
         """First half of the partitioned matvec (device pointers): this rank's share of the upward pass; packs
-        k x partition_coarse_count() partial coarse multipoles into d_coarse for the all-reduce."""
-        self._raise(self._lib.bbfmm_matvec_partition_upward(self._h, d_w, ldw, k, d_coarse or None))
+        k x partition_coarse_count() partial coarse multipoles into d_coarse for the all-reduce, then queues the near
+        field.  comm_stream: the HIP stream (pointer) the all-reduce will be issued on (0: ordered by the caller)."""
+        self._raise(self._lib.bbfmm_matvec_partition_upward(self._h, d_w, ldw, k, d_coarse or None, comm_stream or None))
 
-    def matvec_partition_finish(self, d_coarse: int, d_out: int, ldo: int, sync: bool = True):
+    def matvec_partition_finish(self, d_coarse: int, d_out: int, ldo: int, sync: bool = True, comm_stream: int = 0):
         """Second half: d_coarse summed over the ranks; downward + leaf pass of the owned targets."""
-        self._raise(self._lib.bbfmm_matvec_partition_finish(self._h, d_coarse or None, d_out, ldo, int(sync)))
+        self._raise(self._lib.bbfmm_matvec_partition_finish(self._h, d_coarse or None, d_out, ldo, int(sync), comm_stream or None))
 
     def debug_partition_upward_counts(self):
         """(counts, reads, info): the rank's upward plan walked with point counts (see the header)."""

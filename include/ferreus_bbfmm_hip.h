@@ -241,10 +241,14 @@ int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out);
  *      any stream that waits for it) --
  *   bbfmm_matvec_partition_finish  takes the summed d_coarse, runs the downward and leaf passes of the owned
  *                                  targets, writes the owned rows of d_out (ld ldo) like bbfmm_matvec_device.
+ * comm_stream (hipStream_t as void*, may be NULL): the stream the caller issues the all-reduce on.  _upward makes it wait
+ * for the packed multipoles only and queues the near field (P2P) of the owned targets behind the pack on the handle's own
+ * stream, so that the collective runs beside it; _finish makes the handle's stream wait for comm_stream before it reads
+ * d_coarse.  With NULL the caller orders the collective after the handle's stream itself (everything serial).
  * bbfmm_matvec_device on a partitioned handle still works on its own (it then runs the whole upward pass). */
 int64_t bbfmm_partition_coarse_count(const bbfmm_handle *h);
-int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse);
-int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync);
+int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse, void *comm_stream);
+int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync, void *comm_stream);
 /* Test hook (host side, also on BBFMM_FLAG_HOST_ONLY handles): walks this rank's upward plan with point COUNTS in
  * place of multipoles (P2M -> points of the leaf, M2M -> sum over the plan's children).  counts_out[c] (n_cells):
  * what the plan leaves in cell c before the exchange (-1: never written); reads_out[c] = 1 where the rank's downward
