@@ -1,5 +1,6 @@
-"""N > 1 path on CPU: two processes over the gloo backend run the partition bookkeeping and the
-all-gather exchange that bench.py uses with RCCL (ferreus_rbf_rs_amd/distributed.py)."""
+"""N > 1 path on CPU: two processes over the gloo backend run the partition bookkeeping, the all-gather of the owned
+rows and the all-reduce of the split upward pass (on point counts in place of multipoles) that bench.py uses with RCCL
+(ferreus_rbf_rs_amd/distributed.py)."""
 import os
 import socket
 import sys
@@ -38,7 +39,22 @@ def _worker(rank, world, port, n, k, q):
         out = torch.full((k, n), float("nan"), dtype=torch.float64)
         out[:, torch.as_tensor(rows)] = truth[:, torch.as_tensor(rows)]
         ex.exchange(out)
-        q.put((rank, ok_cover, bool(torch.equal(out, truth)), len(rows)))
+        ok_exchange = bool(torch.equal(out, truth))
+        # the split upward pass with the REAL collective: every rank walks its own plan with point counts in place of
+        # multipoles (bbfmm_debug_partition_upward_counts), the coarse prefixes are summed by one all-reduce -- what
+        # PartitionedMatvec does with the multipoles -- and must equal the whole upward pass on every rank
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_partition_upward import _true_counts
+        counts, reads, info = tree.debug_partition_upward_counts()
+        n_coarse = int(info[1])
+        coarse = torch.from_numpy(counts[:n_coarse].astype(np.float64))
+        dist.all_reduce(coarse)
+        truth_counts, level = _true_counts(tree, 3)
+        sel = level[:n_coarse] >= 1
+        ok_upward = n_coarse > 0 and bool(np.array_equal(coarse.numpy()[sel], truth_counts[:n_coarse][sel].astype(np.float64)))
+        fine = (level > int(info[0])) & (reads == 1)
+        ok_upward = ok_upward and bool(np.array_equal(counts[fine], truth_counts[fine]))
+        q.put((rank, ok_cover, ok_exchange and ok_upward, len(rows)))
         dist.destroy_process_group()
     except Exception as e:  # noqa: BLE001
         q.put((rank, False, False, repr(e)))
