@@ -75,8 +75,9 @@ EXTENSION_CONFIGS = [
 CONFIG5 = {"name": "config5_spheroidal3_40M", "points": 40_000_000, "kernel": "Spheroidal3Rbf", "order": 7, "nrhs": 1,
            "base_range": 0.1, "total_sill": 0.1}
 
-# measured once at the full 10M points (scripts/cpu_port_full_size.py -> profiles/r02_cpu_port_full_10M.json)
-CPU_PORT_FULL_SIZE = {"value_full_size": 0.0213, "full_size_threads": 256, "full_size_from": "profiles/r02_cpu_port_full_10M.json"}
+# measured at the full 10M points (scripts/cpu_port_full_size.py): round 3 49.1 s per matvec on 256 threads
+# (profiles/r03_cpu_port_full_10M.json), round 2 46.9 s (profiles/r02_cpu_port_full_10M.json)
+CPU_PORT_FULL_SIZE = {"value_full_size": 0.0204, "full_size_threads": 256, "full_size_from": "profiles/r03_cpu_port_full_10M.json"}
 
 # FP64 vector issue peak: 256 CUs x 4 SIMDs, one wave64 FP64 instruction per 4 cycles, at the 2.4 GHz AMD's
 # 78.6 TFLOP/s assumes (= 78.6e12 / 2 lane-FMAs per second)
@@ -226,7 +227,7 @@ def cpu_baseline(args, kernel_id):
     is O(N), so the rate is scaled by the point ratio.  The sample is run at the host's full thread
     count and at a half and a quarter of it (small problems do not always like every hardware thread);
     the fastest is reported with its thread count.  `value_full_size` is the same code measured once at the
-    full 10M points (46.9 s per matvec on 256 threads): the scaled sample flatters the CPU (caches), which only
+    full 10M points (49.1 s per matvec on 256 threads): the scaled sample flatters the CPU (caches), which only
     makes `value` conservative for the GPU."""
     from oracle import bbfmm_oracle as O
     n_cpu = args.cpu_points or max(20000, args.points // 64)
