@@ -58,6 +58,11 @@ def test_mfma_lane_layout_and_peak():
     assert tf > 20.0                       # sanity: a bare MFMA loop reaches tens of TFLOP/s
 
 
+def test_fp64_valu_microbenchmark():
+    tf, mhz = F.fp64_valu_selftest()       # the issue roofline the bench quotes the pair kernels against
+    assert 20.0 < tf < 90.0 and 1000.0 < mhz < 3000.0
+
+
 def test_config1_50k_linear():
     # BASELINE.json configs[0]: 50k random points, single rhs (reference-native kernel)
     check(np.random.default_rng(1).random((50000, 3)))
