@@ -87,12 +87,15 @@ class PartitionedMatvec:
     the kernels), the all-reduce on a second stream that the library orders with events; nothing synchronises the host
     except the gloo staging path."""
 
-    def __init__(self, tree, n_total: int, k: int, device, group=None):
+    def __init__(self, tree, n_total: int, k: int, device, group=None, always_exchange: bool = False):
+        """always_exchange: a one-rank group takes the N > 1 path too (both collectives run, on their streams) instead
+        of the plain matvec -- the check of the stream and event ordering that a one-GPU box can make with RCCL."""
         self.tree, self.group, self.k, self.n = tree, group, k, n_total
         device = torch.device(device)
         self.world = dist.get_world_size(group)
+        self.split = self.world > 1 or always_exchange
         self.xchg = OwnedRowsExchange(tree.partition_rows(), n_total, k, device, group)
-        self.count = tree.partition_coarse_count() if self.world > 1 else 0
+        self.count = tree.partition_coarse_count() if self.split else 0
         self.staged = self.xchg.staged
         self.coarse = torch.zeros((k, max(self.count, 1)), dtype=torch.float64, device=device)
         if self.staged:
@@ -106,7 +109,7 @@ class PartitionedMatvec:
         return self.xchg.check_partition()
 
     def all_reduce_coarse(self):
-        if self.count == 0 or self.world == 1:
+        if self.count == 0 or not self.split:
             return
         if self.staged:
             self.h_coarse.copy_(self.coarse)                             # device -> pinned host (synchronises)
@@ -117,7 +120,7 @@ class PartitionedMatvec:
 
     def step(self, w: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
         """w: K x N weights (device, contiguous, the same on every rank); out: K x N, complete on return."""
-        if self.world == 1:
+        if not self.split:
             self.tree.matvec_device(w.data_ptr(), self.n, self.k, out.data_ptr(), self.n, sync=False)
             return out
         comm = self.comm.cuda_stream

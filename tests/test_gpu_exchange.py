@@ -81,5 +81,29 @@ def test_single_rank_rccl_exchange_matches_unpartitioned():
             assert not torch.isnan(full).any()
             assert (full - ref).abs().max() / ref.abs().max() < 1e-12, world
         tree.set_partition(0, 1)
+        # the whole N > 1 step on the one-rank RCCL group: all-reduce on the side stream between the library's events,
+        # all-gather on the handle's stream, no host synchronisation in between, several steps back to back.  The
+        # group has one rank, so the sum holds rank 0's share of the coarse multipoles only: the reference is the same
+        # two calls made one after the other with host synchronisation (stream and event ordering is what is checked)
+        from ferreus_rbf_rs_amd.distributed import PartitionedMatvec
+        tree.set_partition(0, 2)
+        cnt = tree.partition_coarse_count()
+        c = torch.zeros((K, cnt), dtype=torch.float64, device=dev)
+        tree.matvec_partition_upward(w.data_ptr(), n, K, c.data_ptr())
+        torch.cuda.synchronize()
+        stream.synchronize()
+        o_sync = torch.zeros_like(w)
+        tree.matvec_partition_finish(c.data_ptr(), o_sync.data_ptr(), n, True)
+        idx = torch.as_tensor(tree.partition_rows(), device=dev)
+        pm = PartitionedMatvec(tree, n, K, dev, always_exchange=True)
+        assert pm.count == cnt > 0 and not pm.check_partition()      # (half of the rows: not a cover)
+        outs = [torch.zeros_like(w) for _ in range(4)]
+        for o in outs:
+            pm.step(w, o)
+        pm.synchronize()
+        torch.cuda.synchronize()
+        for o in outs:
+            assert (o[:, idx] - o_sync[:, idx]).abs().max() / ref.abs().max() < 1e-13
+        tree.set_partition(0, 1)
     finally:
         dist.destroy_process_group()
