@@ -98,12 +98,16 @@ int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_s
     *out = DomainPrep();
     if (basis_size == 0) return BBFMM_OK;
     const int n = static_cast<int>(dom->idx.size());
+    std::vector<double> loc(static_cast<size_t>(d) * n); // the domain's coordinates, gathered once
+    for (int a = 0; a < d; ++a)
+        for (int i = 0; i < n; ++i) loc[static_cast<size_t>(a) * n + i] = pts[a * ld + dom->idx[i]];
     // get_cheb_cube_scaling_factors (common.rs:299-322) of the domain's points
     for (int a = 0; a < d; ++a) {
-        double lo = pts[a * ld + dom->idx[0]], hi = lo;
-        for (int64_t i : dom->idx) {
-            lo = std::min(lo, pts[a * ld + i]);
-            hi = std::max(hi, pts[a * ld + i]);
+        const double *xa = &loc[static_cast<size_t>(a) * n];
+        double lo = xa[0], hi = lo;
+        for (int i = 0; i < n; ++i) {
+            lo = std::min(lo, xa[i]);
+            hi = std::max(hi, xa[i]);
         }
         out->tr[a] = (hi + lo) / 2.0;
         out->sc[a] = (hi - lo) / 2.0;
@@ -117,7 +121,7 @@ int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_s
     std::vector<double> mono(static_cast<size_t>(n) * basis_size, 0.0);
     for (int i = 0; i < n; ++i) {
         double sx[3] = {0, 0, 0};
-        for (int a = 0; a < d; ++a) sx[a] = (pts[a * ld + dom->idx[i]] - out->tr[a]) / out->sc[a];
+        for (int a = 0; a < d; ++a) sx[a] = (loc[static_cast<size_t>(a) * n + i] - out->tr[a]) / out->sc[a];
         double *row = &mono[static_cast<size_t>(i) * basis_size];
         row[0] = 1.0;
         if (degree >= 1)
@@ -160,6 +164,9 @@ int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_s
     }
     dom->idx.swap(nidx);
     dom->internal.swap(nint);
+    out->xyz.resize(static_cast<size_t>(d) * n);
+    for (int a = 0; a < d; ++a)
+        for (int i = 0; i < n; ++i) out->xyz[static_cast<size_t>(a) * n + i] = loc[static_cast<size_t>(a) * n + order[i]];
     // Lagrange coefficients on the special points and Q = -(N_ns lag)^T (domain.rs:296-307)
     out->sp_mono.resize(static_cast<size_t>(rank) * rank);
     for (int a = 0; a < rank; ++a)
@@ -185,7 +192,7 @@ int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_s
         if ((x) != hipSuccess) return BBFMM_DEVICE_ERROR;                                                            \
     } while (0)
 
-template <class T> static int up(T **dst, const std::vector<T> &v, hipStream_t s) {
+template <class T, class A> static int up(T **dst, const std::vector<T, A> &v, hipStream_t s) {
     *dst = nullptr;
     if (v.empty()) return BBFMM_OK;
     DHIP(hipMalloc(reinterpret_cast<void **>(dst), v.size() * sizeof(T)));
@@ -198,7 +205,7 @@ template <class T> static int up(T **dst, const std::vector<T> &v, hipStream_t s
 // assembles the same Q^T A Q (the formula of ddm_assemble_kernel), inverts it by Gauss-Jordan
 // elimination with partial pivoting and stores the symmetrised inverse packed like a factor; the solve
 // kernel multiplies by it.  Meant for the occasional small domain, not for speed.
-static int host_domain_inverse(const std::vector<double> *xyz, int64_t o, int k, int m, const double *q,
+static int host_domain_inverse(const PodDoubles *xyz, int64_t o, int k, int m, const double *q,
                                const KernelSpec &ks, double nugget, std::vector<double> *packed) {
     auto phi = [&](int64_t a, int64_t b) {
         const double dx = xyz[0][a] - xyz[0][b], dy = xyz[1][a] - xyz[1][b], dz = xyz[2][a] - xyz[2][b];
@@ -401,19 +408,24 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
         lv->max_m = std::max<int>(lv->max_m, static_cast<int>(m));
     }
     lv->n_entries = lv->dom_off[nd];
-    std::vector<double> xyz[3];
+    // (20M entries and 80M Q values on level 0 of 10M points: no serial zero fill, every element is written below)
+    PodDoubles xyz[3];
     std::vector<uint8_t> internal(static_cast<size_t>(lv->n_entries));
     lv->gidx_h.resize(static_cast<size_t>(lv->n_entries));
-    for (int a = 0; a < 3; ++a) xyz[a].assign(static_cast<size_t>(lv->n_entries), 0.0);
-    std::vector<double> q(static_cast<size_t>(lv->q_off[nd]));
+    for (int a = 0; a < 3; ++a) xyz[a].resize(static_cast<size_t>(lv->n_entries));
+    PodDoubles q(static_cast<size_t>(lv->q_off[nd]));
     parallel_for(nd, 1, [&](int64_t i) {
         const DdmDomain &dom = level->leaves[i];
         const int64_t o = lv->dom_off[i];
-        for (size_t e = 0; e < dom.idx.size(); ++e) {
+        const size_t ne = dom.idx.size();
+        std::vector<double> &pxyz = lv->prep[i].xyz; // (empty without a polynomial part: gather here)
+        for (size_t e = 0; e < ne; ++e) {
             lv->gidx_h[o + e] = dom.idx[e];
             internal[o + e] = dom.internal[e];
-            for (int a = 0; a < d; ++a) xyz[a][o + e] = pts[a * ld + dom.idx[e]];
+            for (int a = 0; a < 3; ++a)
+                xyz[a][o + e] = a >= d ? 0.0 : (pxyz.empty() ? pts[a * ld + dom.idx[e]] : pxyz[static_cast<size_t>(a) * ne + e]);
         }
+        std::vector<double>().swap(pxyz);
         std::copy(lv->prep[i].q.begin(), lv->prep[i].q.end(), q.begin() + lv->q_off[i]);
     });
     lap("host pack", false);

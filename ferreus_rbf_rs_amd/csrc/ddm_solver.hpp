@@ -20,6 +20,8 @@ struct DomainPrep { // host result of the polynomial part of Domain::factorise (
     std::vector<double> q;       // Q top block, k x m row-major (m = points - k): -(L(x_j))_a
     std::vector<double> sp_mono; // k x k special-point monomials, row-major (point, monomial)
     double tr[3] = {0, 0, 0}, sc[3] = {1, 1, 1};
+    std::vector<double> xyz;     // the domain's coordinates in its (reordered) point order, axis-major d x n; handed to the
+                                 // level's packed arrays and released (gathered once: the points are scattered)
 };
 
 // Reorders dom->idx / dom->internal so that the special points come first (domain.rs:250-279).

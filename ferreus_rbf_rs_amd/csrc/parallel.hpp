@@ -1,15 +1,19 @@
-// Minimal host thread pool helper: dynamic chunked parallel_for over [0, n).
+// Minimal host thread pool: dynamic chunked parallel_for over [0, n).
 // (The reference parallelises its host loops with rayon; this plays that role for
-// the host-side tree / list / operator setup.  No OpenMP runtime dependency.)
+// the host-side tree / list / operator setup and the solvers' vector loops.  No OpenMP runtime dependency.)
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <utility>
 #include <vector>
+
+#include <pthread.h>
 
 namespace bbfmm {
 
@@ -36,6 +40,86 @@ inline int host_threads() {
     return n;
 }
 
+// Persistent helper threads.  Starting and joining 63 threads costs 1.6 ms on the 256-core host of an MI355X box
+// (scripts/: measured), which a setup made of hundreds of short loops -- and every vector operation of FGMRES -- paid
+// per loop.  One job at a time: a loop started while another one runs (a nested loop, a second host thread) falls back
+// to threads of its own.  The pool is created on first use and never destroyed (its threads sleep until the process
+// ends); a forked child starts a new one.
+class HostPool {
+public:
+    static HostPool *get() {
+        HostPool *p = slot().load(std::memory_order_acquire);
+        if (p) return p;
+        static std::mutex create;
+        std::lock_guard<std::mutex> g(create);
+        p = slot().load(std::memory_order_acquire);
+        if (!p) {
+            static const int registered = pthread_atfork(nullptr, nullptr, [] { slot().store(nullptr); busy_flag() = false; });
+            (void)registered;
+            p = new HostPool(std::max(0, host_threads() - 1));
+            slot().store(p, std::memory_order_release);
+        }
+        return p;
+    }
+    // Runs worker() on the caller and on up to `helpers` pool threads; false (nothing done) when the pool is busy.
+    template <class W> bool run(int helpers, W &worker) {
+        if (busy_flag() || threads_.empty() || !job_.try_lock()) return false;
+        busy_flag() = true;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fn_ = [](void *a) { (*static_cast<W *>(a))(); };
+            arg_ = &worker;
+            wanted_ = std::min<int>(helpers, static_cast<int>(threads_.size()));
+        }
+        cv_work_.notify_all();
+        worker();
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            wanted_ = 0; // the caller ran out of chunks: helpers that have not started are not needed any more
+            cv_done_.wait(lk, [&] { return running_ == 0; });
+            fn_ = nullptr;
+        }
+        busy_flag() = false;
+        job_.unlock();
+        return true;
+    }
+
+private:
+    explicit HostPool(int n) {
+        threads_.reserve(static_cast<size_t>(n));
+        for (int i = 0; i < n; ++i) threads_.emplace_back([this] { loop(); });
+    }
+    void loop() {
+        busy_flag() = true; // loops started from inside a job use threads of their own
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_work_.wait(lk, [&] { return wanted_ > 0; });
+            --wanted_;
+            ++running_;
+            void (*fn)(void *) = fn_;
+            void *arg = arg_;
+            lk.unlock();
+            fn(arg);
+            lk.lock();
+            if (--running_ == 0 && wanted_ == 0) cv_done_.notify_all();
+        }
+    }
+    static std::atomic<HostPool *> &slot() {
+        static std::atomic<HostPool *> p{nullptr};
+        return p;
+    }
+    static bool &busy_flag() { // this thread is inside a job (as its caller or as a helper)
+        static thread_local bool b = false;
+        return b;
+    }
+    std::mutex m_, job_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> threads_;
+    void (*fn_)(void *) = nullptr;
+    void *arg_ = nullptr;
+    int wanted_ = 0, running_ = 0;
+};
+
 // fn(begin, end) is called on disjoint chunks.
 template <class F> void parallel_for_chunks(int64_t n, int64_t chunk, F &&fn) {
     if (n <= 0) return;
@@ -52,6 +136,7 @@ template <class F> void parallel_for_chunks(int64_t n, int64_t chunk, F &&fn) {
             fn(b, std::min(n, b + chunk));
         }
     };
+    if (HostPool::get()->run(nt - 1, worker)) return;
     std::vector<std::thread> threads;
     threads.reserve(nt - 1);
     for (int i = 0; i < nt - 1; ++i) threads.emplace_back(worker);

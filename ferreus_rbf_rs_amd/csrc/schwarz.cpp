@@ -37,8 +37,8 @@ struct Schwarz {
     KernelSpec ks{};
     DdmTree ddm;
     std::vector<DdmLevelSolver> levels;
-    std::vector<double> mono;  // N x basis column-major, the solver's global monomial matrix (rbf.rs:485-491)
-    std::vector<double> ortho; // N x basis column-major, thin Q of mono (rbf.rs:493-495)
+    PodDoubles mono;           // N x basis column-major, the solver's global monomial matrix (rbf.rs:485-491)
+    PodDoubles ortho;          // N x basis column-major, thin Q of mono (rbf.rs:493-495)
     std::vector<double> a_special; // coarse domain: k x n_coarse rows of A (domain.rs:352-355), row-major
     hipStream_t stream = nullptr;  // the tree's stream (not owned): products and level work stay in order
     int device = -1;               // the tree's device: the entry points bind the calling thread to it
@@ -226,44 +226,75 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
     double gscale[6] = {0, 0, 0, 1, 1, 1}; // translation, scale of the global monomial basis
     if (S.basis) {
         double *tr = gscale, *sc = gscale + 3;
+        // Vectors of n entries on all host threads.  Sums run over fixed blocks of 65,536 entries whose partial
+        // results are added in block order: the same bits whatever the thread count.
+        constexpr int64_t kBlk = 65536;
+        const int64_t nblk = (n + kBlk - 1) / kBlk;
+        std::vector<double> part(static_cast<size_t>(nblk) * 2);
+        auto dot = [&](const double *x, const double *y) {
+            parallel_for(nblk, 1, [&](int64_t b) {
+                double sum = 0.0;
+                for (int64_t i = b * kBlk; i < std::min(n, (b + 1) * kBlk); ++i) sum += x[i] * y[i];
+                part[static_cast<size_t>(b)] = sum;
+            });
+            double sum = 0.0;
+            for (int64_t b = 0; b < nblk; ++b) sum += part[static_cast<size_t>(b)];
+            return sum;
+        };
         for (int a = 0; a < d; ++a) {
-            double lo = points[a * ld], hi = lo;
-            for (int64_t i = 0; i < n; ++i) {
-                lo = std::min(lo, points[a * ld + i]);
-                hi = std::max(hi, points[a * ld + i]);
+            const double *x = points + a * ld;
+            parallel_for(nblk, 1, [&](int64_t b) {
+                double lo = x[b * kBlk], hi = lo;
+                for (int64_t i = b * kBlk; i < std::min(n, (b + 1) * kBlk); ++i) {
+                    lo = std::min(lo, x[i]);
+                    hi = std::max(hi, x[i]);
+                }
+                part[static_cast<size_t>(2 * b)] = lo;
+                part[static_cast<size_t>(2 * b + 1)] = hi;
+            });
+            double lo = part[0], hi = part[1];
+            for (int64_t b = 1; b < nblk; ++b) {
+                lo = std::min(lo, part[static_cast<size_t>(2 * b)]);
+                hi = std::max(hi, part[static_cast<size_t>(2 * b + 1)]);
             }
             tr[a] = (hi + lo) / 2.0;
             sc[a] = (hi - lo) / 2.0;
             if (sc[a] == 0.0) sc[a] = 1.0;
         }
-        S.mono.assign(static_cast<size_t>(n) * S.basis, 0.0);
-        for (int64_t i = 0; i < n; ++i) {
-            double sx[3] = {0, 0, 0};
-            for (int a = 0; a < d; ++a) sx[a] = (points[a * ld + i] - tr[a]) / sc[a];
-            S.mono[i] = 1.0;
-            if (S.degree >= 1)
-                for (int a = 0; a < d; ++a) S.mono[static_cast<size_t>(1 + a) * n + i] = sx[a];
-            if (S.degree == 2) {
-                int c = 1 + d;
-                for (int a = 0; a < d; ++a)
-                    for (int b = a; b < d; ++b) S.mono[static_cast<size_t>(c++) * n + i] = sx[a] * sx[b];
+        S.mono.resize(static_cast<size_t>(n) * S.basis);
+        parallel_for_chunks(n, kBlk, [&](int64_t i0, int64_t i1) {
+            for (int64_t i = i0; i < i1; ++i) {
+                double sx[3] = {0, 0, 0};
+                for (int a = 0; a < d; ++a) sx[a] = (points[a * ld + i] - tr[a]) / sc[a];
+                S.mono[i] = 1.0;
+                if (S.degree >= 1)
+                    for (int a = 0; a < d; ++a) S.mono[static_cast<size_t>(1 + a) * n + i] = sx[a];
+                if (S.degree == 2) {
+                    int c = 1 + d;
+                    for (int a = 0; a < d; ++a)
+                        for (int b = a; b < d; ++b) S.mono[static_cast<size_t>(c++) * n + i] = sx[a] * sx[b];
+                }
             }
-        }
-        S.ortho = S.mono; // modified Gram-Schmidt, twice
+        });
+        S.ortho.resize(S.mono.size()); // modified Gram-Schmidt, twice
+        parallel_for_chunks(static_cast<int64_t>(S.mono.size()), kBlk, [&](int64_t i0, int64_t i1) {
+            std::copy(S.mono.begin() + i0, S.mono.begin() + i1, S.ortho.begin() + i0);
+        });
         for (int pass = 0; pass < 2; ++pass)
             for (int b = 0; b < S.basis; ++b) {
                 double *qb = &S.ortho[static_cast<size_t>(b) * n];
                 for (int c = 0; c < b; ++c) {
                     const double *qc = &S.ortho[static_cast<size_t>(c) * n];
-                    double s = 0.0;
-                    for (int64_t i = 0; i < n; ++i) s += qc[i] * qb[i];
-                    for (int64_t i = 0; i < n; ++i) qb[i] -= s * qc[i];
+                    const double sdot = dot(qc, qb);
+                    parallel_for_chunks(n, kBlk, [&](int64_t i0, int64_t i1) {
+                        for (int64_t i = i0; i < i1; ++i) qb[i] -= sdot * qc[i];
+                    });
                 }
-                double nn = 0.0;
-                for (int64_t i = 0; i < n; ++i) nn += qb[i] * qb[i];
-                nn = std::sqrt(nn);
+                const double nn = std::sqrt(dot(qb, qb));
                 if (nn == 0.0) return BBFMM_BAD_ARGUMENT;
-                for (int64_t i = 0; i < n; ++i) qb[i] /= nn;
+                parallel_for_chunks(n, kBlk, [&](int64_t i0, int64_t i1) {
+                    for (int64_t i = i0; i < i1; ++i) qb[i] /= nn;
+                });
             }
     }
     S.levels.resize(S.ddm.levels.size());

@@ -83,6 +83,37 @@ def test_median_selection_split_equals_the_stable_argsort_with_ties():
     _same_tree(DDMTree(pts, prm), _oracle_levels(pts, prm))
 
 
+@pytest.mark.parametrize("case", ["ties", "uniform3", "clustered2", "line1"])
+def test_threaded_split_of_large_domains_equals_the_serial_pass(case, monkeypatch):
+    """Domains above BBFMM_DDM_LARGE_DOMAIN points are cut on all host threads (bucketed selection of the cut value,
+    per-chunk counts, ordered scatter); with the threshold at 64 points every split of these small trees takes that
+    pass, and the result must still be the restatement's -- ties, signed zeros and degenerate ranges included."""
+    rng = np.random.default_rng(17)
+    if case == "ties":
+        pts = np.round(rng.random((4000, 3)), 2) - 0.5
+        pts[::97] = 0.0
+        pts[1::97, 0] = -0.0
+        prm = DDMParams(50, 0.5, 0.125, 200)
+    elif case == "uniform3":
+        pts = rng.random((6000, 3))
+        prm = DDMParams(64, 0.5, 0.125, 256)
+    elif case == "clustered2":
+        pts = _clustered(rng, 2500, 2)
+        prm = DDMParams(40, 1.0, 0.3, 100)
+    else:
+        pts = np.repeat(rng.random((350, 1)), 2, axis=0)        # every coordinate twice
+        prm = DDMParams(20, 0.5, 0.25, 60)
+    monkeypatch.setenv("BBFMM_DDM_LARGE_DOMAIN", "64")
+    forced = DDMTree(pts, prm)
+    monkeypatch.setenv("BBFMM_DDM_LARGE_DOMAIN", "1000000000")
+    serial = DDMTree(pts, prm)
+    _same_tree(forced, _oracle_levels(pts, prm))
+    for a, b in zip(forced.levels, serial.levels):
+        for da, db in zip(a.leaf_domains, b.leaf_domains):
+            assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
+            np.testing.assert_array_equal(da.extents, db.extents)
+
+
 def test_params_for_points_keep_three_fine_levels():
     """bbfmm_ddm_params_for_points (extension): defaults below ~2.1M points, above that a coarse threshold of
     n/470 + 1 (a level keeps at most N (1/8 + 1/341) points), so that the hierarchy ends after three fine levels."""
