@@ -1,3 +1,7 @@
+// Cost of one parallel_for of csrc/parallel.hpp with nothing to do, and of a streaming loop with a nested loop inside.
+//   g++ -O2 -std=c++17 -pthread scripts/host_pool_microbench.cpp -o /tmp/host_pool && /tmp/host_pool
+// Measured on the 256-core host of an MI355X box, 64 threads: 1.57 ms per loop when every loop started and joined its
+// own threads, 0.155 ms on the persistent pool.
 #include "../ferreus_rbf_rs_amd/csrc/parallel.hpp"
 #include <chrono>
 #include <cstdio>

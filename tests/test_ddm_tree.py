@@ -114,6 +114,32 @@ def test_threaded_split_of_large_domains_equals_the_serial_pass(case, monkeypatc
             np.testing.assert_array_equal(da.extents, db.extents)
 
 
+def test_concurrent_builds_share_the_host_pool():
+    """The host loops run on one persistent pool of helper threads, one loop at a time; a loop that finds the pool
+    taken (another host thread's build, a nested loop) runs on threads of its own.  Four builds at once must give the
+    tree of a build on its own."""
+    import threading
+    rng = np.random.default_rng(23)
+    pts = rng.random((30000, 3))
+    prm = DDMParams(64, 0.5, 0.125, 512)
+    alone = DDMTree(pts, prm)
+    got = [None] * 4
+
+    def work(i):
+        got[i] = DDMTree(pts, prm)                      # (ctypes drops the GIL for the call)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for tree in got:
+        assert tree is not None and len(tree.levels) == len(alone.levels)
+        for a, b in zip(tree.levels, alone.levels):
+            assert list(a.point_indices) == list(b.point_indices)
+            for da, db in zip(a.leaf_domains, b.leaf_domains):
+                assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
+
+
 def test_params_for_points_keep_three_fine_levels():
     """bbfmm_ddm_params_for_points (extension): defaults below ~2.1M points, above that a coarse threshold of
     n/470 + 1 (a level keeps at most N (1/8 + 1/341) points), so that the hierarchy ends after three fine levels."""
