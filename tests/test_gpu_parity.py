@@ -145,6 +145,23 @@ def test_independent_operators_agree_to_bbfmm_accuracy():
     assert relerr(t.evaluate(w, pts), r.evaluate(w, pts)) < 1e-6
 
 
+@pytest.mark.parametrize("kid,order", [(0, 5), (2, 6), (3, 4)])
+def test_independent_uncompressed_operators_agree_to_rounding(kid, order):
+    """M2lCompressionType::None leaves nothing to the factorisation: the M2L operators are the kernel at the node
+    pairs of a transfer vector.  Oracle and product then build them independently (no injection), and everything --
+    operator tables, transfer-vector numbering, permutations, the stacked GEMMs -- must agree to rounding, not to the
+    compression tolerance of the ACA / SVD comparisons."""
+    pts = np.random.default_rng(40 + kid).random((6000, 3))
+    prm = (48, 0, 1e-7, 1024)
+    t, r = make(pts, kid=kid, order=order, params=prm, inject=False, br=0.5, sill=0.25)
+    w = np.random.default_rng(41).random((pts.shape[0], 2))
+    t.set_weights(w)
+    r.set_weights(w)
+    y, yr = t.evaluate(w, pts), r.evaluate(w, pts)
+    assert relerr(t.debug_get_coefficients("L", 2), r.L) < TOL
+    assert relerr(y, yr) < TOL
+
+
 def test_errors_match_the_reference():
     # ferreus_bbfmm/src/bbfmm.rs:1464-1500 through the whole ABI (set_weights included)
     t = F.FmmTree(np.array([[0.5]]), 3, F.KernelParams(F.FmmKernelType.LinearRbf), True, False, extents=[0.0, 1.0])
