@@ -140,6 +140,30 @@ def test_concurrent_builds_share_the_host_pool():
                 assert list(da.overlapping_point_indices) == list(db.overlapping_point_indices)
 
 
+def test_forked_child_starts_its_own_host_pool():
+    """The helper threads do not exist in a fork()ed child: it must start a pool of its own instead of waiting for
+    the parent's."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np\n"
+        f"sys.path.insert(0, {root!r})\n"
+        "from ferreus_rbf_rs_amd.ddm import DDMParams, DDMTree\n"
+        "pts = np.random.default_rng(1).random((30000, 3)); prm = DDMParams(64, 0.5, 0.125, 512)\n"
+        "a = DDMTree(pts, prm)\n"
+        "pid = os.fork()\n"
+        "if pid == 0:\n"
+        "    b = DDMTree(pts, prm)\n"
+        "    same = all(list(x.point_indices) == list(y.point_indices) for x, y in zip(a.levels, b.levels))\n"
+        "    os._exit(0 if same else 3)\n"
+        "_, st = os.waitpid(pid, 0)\n"
+        "c = DDMTree(pts, prm)\n"
+        "sys.exit(0 if os.WIFEXITED(st) and os.WEXITSTATUS(st) == 0 and len(c.levels) == len(a.levels) else 4)\n")
+    assert subprocess.run([sys.executable, "-c", code], timeout=300).returncode == 0
+
+
 def test_params_for_points_keep_three_fine_levels():
     """bbfmm_ddm_params_for_points (extension): defaults below ~2.1M points, above that a coarse threshold of
     n/470 + 1 (a level keeps at most N (1/8 + 1/341) points), so that the hierarchy ends after three fine levels."""
