@@ -257,7 +257,9 @@ def build_ddm_tree(points, st, params=None):
             internal = dom.internal_indices()
             ip = points[np.asarray(internal)]
             sample = min(len(internal), num_coarse)
-            center = ip.sum(axis=0) / ip.shape[0]                                      # get_centroid
+            # get_centroid (domain_decomposition.rs:350-359) folds each column left to right; numpy's sum is pairwise on a
+            # contiguous axis (1-D point sets), which moves the centroid by an ulp and with it the argmin among tied points
+            center = np.add.accumulate(ip, axis=0)[-1] / ip.shape[0]
             dist = np.sqrt(((ip - center) ** 2).sum(axis=1))
             center_index = int(np.argmin(dist))
             sel = farthest_point_sampling(ip, sample, center_index)
