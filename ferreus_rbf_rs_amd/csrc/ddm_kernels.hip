@@ -105,8 +105,7 @@ constexpr int CB = 64; // block-column width of the per-domain factorisation
 
 // In-place lower Cholesky, one workgroup per matrix, LEFT-looking over 64-column block columns: a
 // block column is first brought up to date with everything left of it (64 x 64 tiles on
-// v_mfma_f64_16x16x4: each of the four waves owns a 32 x 32 quadrant = 2 x 2 MFMA tiles; the two factor
-// panels are staged through LDS 32 columns at a time and the accumulators stay in registers over the
+// v_mfma_f64_16x16x4, one tile = 4 x 4 MFMA tiles per wave; the accumulators stay in registers over the
 // whole sweep, so a tile is read and written once), then its diagonal block is factorised in LDS,
 // inverted there in place, and the rows below are a product with that inverse on the same tiles.
 // (The right-looking order with 32-column panels re-read and re-wrote the whole trailing matrix per
@@ -117,63 +116,94 @@ constexpr int CB = 64; // block-column width of the per-domain factorisation
 // the sixteen lanes of a result register walk down a column of the packed factor (contiguous).
 using d4 = __attribute__((ext_vector_type(4))) double;
 
-// acc[ci][ri] += Pc[cb + 16ci + .][k0..k0+32) Pr[rb + 16ri + .][k0..)^T for the wave's quadrant
-template <int LDC, int LDR>
-__device__ __forceinline__ void quad_mfma32(const double (*Pc)[LDC], int ck0, const double (*Pr)[LDR], int cb, int rb,
-                                            int lane, d4 (&acc)[2][2]) {
-    const int li = lane & 15, lk = lane >> 4;
+// A 64 x 64 tile per WAVE, operands straight from HBM into the MFMA registers: lane l of an operand fragment holds
+// element [l & 15][k + (l >> 4)] of a 16-row group, and the sixteen lanes of a k column are sixteen consecutive rows of
+// a packed column -- one 128-byte segment -- so the loads need no staging, the waves of a workgroup never wait for
+// each other inside a sweep, and the k step after the one being multiplied is already on its way.
+//   acc[ci][ri] += C[16 ci + .][k] R[16 ri + .][k]^T,  k = k0 .. k0 + K (K a multiple of 4)
+// colsrc(ci, k) / rowsrc(ri, k) return the lane's element of the column-side / row-side fragment.
+// The lane's packed column (column c0 + k + (l >> 4), as a pointer such that p[r] is row r of it) is carried along.
+// The loads are unconditional (the callers clamp rows and select zeros afterwards) and the two fragment sets take
+// turns, so that no wait stands between a set's loads and the other set's products (K a multiple of 8).
+template <class CF, class RF>
+__device__ __forceinline__ void wave_tile_sweep(const double *A, int m, int c0, int K, int lk, CF &&colsrc, RF &&rowsrc,
+                                                d4 (&acc)[4][4]) {
+    int c = c0 + lk;
+    const double *p = A + (static_cast<int64_t>(c) * m - static_cast<int64_t>(c) * (c - 1) / 2 - c); // pk(r, c) = p[r]
+    double a0[4], b0[4], a1[4], b1[4];
 #pragma unroll
-    for (int s4 = 0; s4 < NB / 4; ++s4) {
-        const int kk = 4 * s4 + lk;
-        const double a0 = Pc[cb + li][ck0 + kk], a1 = Pc[cb + 16 + li][ck0 + kk];
-        const double b0 = Pr[rb + li][kk], b1 = Pr[rb + 16 + li][kk];
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    for (int i = 0; i < 4; ++i) {
+        a0[i] = colsrc(i, 0, p);
+        b0[i] = rowsrc(i, 0, p);
+    }
+#pragma unroll 1
+    for (int k = 0; k < K; k += 8) {
+        p += 4 * m - 4 * c - 10; // pk(r, c + 4) - pk(r, c)
+        c += 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a1[i] = colsrc(i, k + 4, p);
+            b1[i] = rowsrc(i, k + 4, p);
+        }
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[ci], b0[ri], acc[ci][ri], 0, 0, 0);
+        if (k + 8 < K) { // (wave-uniform; the last turn re-reads its own columns instead of running past the sweep)
+            p += 4 * m - 4 * c - 10;
+            c += 4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a0[i] = colsrc(i, k + 8 < K ? k + 8 : k + 4, p);
+            b0[i] = rowsrc(i, k + 8 < K ? k + 8 : k + 4, p);
+        }
+#pragma unroll
+        for (int ci = 0; ci < 4; ++ci)
+#pragma unroll
+            for (int ri = 0; ri < 4; ++ri) acc[ci][ri] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[ci], b1[ri], acc[ci][ri], 0, 0, 0);
     }
 }
 
-__global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
+__global__ __launch_bounds__(256, 2) void ddm_cholesky_kernel(View v, int *fail) {
     const int dom = blockIdx.x;
     const int64_t o = v.dom_off[dom];
     const int m = static_cast<int>(v.dom_off[dom + 1] - o) - v.k[dom];
     double *A = v.fac + v.fac_off[dom];
-    // LDS: the diagonal block (steps 2, 3) and the column-panel chunk of step 1 share one buffer -- 50 KB per
-    // workgroup, three workgroups per CU
+    // LDS: the diagonal block (steps 2, 3) only -- 34 KB per workgroup
     __shared__ double Ldbuf[CB * (CB + 1)];
-    __shared__ double Pr[64][NB + 1];
     __shared__ double colj[CB];
     __shared__ int bad;
     double(*Ld)[CB + 1] = reinterpret_cast<double(*)[CB + 1]>(Ldbuf);
-    double(*Pc)[NB + 1] = reinterpret_cast<double(*)[NB + 1]>(Ldbuf);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1); // the wave's quadrant of a 64 x 64 tile
     const int li = lane & 15, lk = lane >> 4;
     if (tid == 0) bad = 0;
     for (int jb = 0; jb < m; jb += CB) {
         const int nb = min(CB, m - jb);
-        // 1. A[jb.., jb..jb+nb) -= L[jb.., 0..jb) L[jb..jb+nb, 0..jb)^T
+        // 1. A[jb.., jb..jb+nb) -= L[jb.., 0..jb) L[jb..jb+nb, 0..jb)^T, a 64-row tile per wave and turn: the four waves
+        //    walk adjacent tiles through the same columns at about the same time (the block row's fragments come from
+        //    the cache for three of them)
         if (jb > 0)
-            for (int tr = jb; tr < m; tr += 64) {
-                d4 acc[2][2] = {};
-                for (int kc = 0; kc < jb; kc += NB) { // jb is a multiple of 64: full chunks
-                    __syncthreads();
-                    for (int e = tid; e < 64 * NB; e += 256) {
-                        const int r = e % 64, c = e / 64;
-                        Pr[r][c] = (tr + r < m) ? A[pk(tr + r, kc + c, m)] : 0.0;
-                        Pc[r][c] = (r < nb) ? A[pk(jb + r, kc + c, m)] : 0.0;
-                    }
-                    __syncthreads();
-                    quad_mfma32(Pc, 0, Pr, cb, rb, lane, acc);
-                }
+            for (int tr = jb + 64 * wave; tr < m; tr += 256) {
+                d4 acc[4][4] = {};
+                auto colsrc = [&](int ci, int, const double *p) {
+                    const int r = 16 * ci + li;
+                    const double x = p[jb + min(r, nb - 1)];
+                    return r < nb ? x : 0.0;
+                };
+                auto rowsrc = [&](int ri, int, const double *p) {
+                    const int r = tr + 16 * ri + li;
+                    const double x = p[min(r, m - 1)];
+                    return r < m ? x : 0.0;
+                };
+                wave_tile_sweep(A, m, 0, jb, lk, colsrc, rowsrc, acc); // jb is a multiple of 64
 #pragma unroll
-                for (int ci = 0; ci < 2; ++ci)
+                for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-                    for (int ri = 0; ri < 2; ++ri)
+                    for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int r = tr + rb + 16 * ri + li, c = jb + cb + 16 * ci + lk + 4 * q;
+                            const int r = tr + 16 * ri + li, c = jb + 16 * ci + lk + 4 * q;
                             if (r < m && c < jb + nb && r >= c) A[pk(r, c, m)] -= acc[ci][ri][q];
                         }
             }
@@ -208,7 +238,7 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
         }
         if (jb + nb >= m) break;
         // 3. rows below the block: X = A21 L11^{-T}.  L11 is inverted in place in LDS (column by column from
-        // the right, as LAPACK's trti2), then X is a product on the same MFMA tiles.
+        // the right, as LAPACK's trti2), then X is a product on the same MFMA tiles, a row tile per wave.
         __syncthreads();
         for (int j = CB - 1; j >= 0; --j) {
             if (tid < CB) colj[tid] = Ld[tid][j];
@@ -222,25 +252,23 @@ __global__ __launch_bounds__(256) void ddm_cholesky_kernel(View v, int *fail) {
             }
             __syncthreads();
         }
-        for (int tr = jb + nb; tr < m; tr += 64) {
-            d4 acc[2][2] = {};
-            for (int kh = 0; kh < CB; kh += NB) {
-                __syncthreads();
-                for (int e = tid; e < 64 * NB; e += 256) {
-                    const int r = e % 64, c = e / 64;
-                    Pr[r][c] = (tr + r < m && kh + c < nb) ? A[pk(tr + r, jb + kh + c, m)] : 0.0;
-                }
-                __syncthreads();
-                quad_mfma32(Ld, kh, Pr, cb, rb, lane, acc); // inv(L11)[column of X][k]
-            }
-            __syncthreads(); // every read of this row tile is done before it is overwritten
+        for (int tr = jb + nb + 64 * wave; tr < m; tr += 256) {
+            d4 acc[4][4] = {};
+            auto colsrc = [&](int ci, int k, const double *) { return Ld[16 * ci + li][k + lk]; }; // inv(L11)[column of X][k]
+            auto rowsrc = [&](int ri, int, const double *p) { // (nb = 64 here: the last block column has no rows below)
+                const int r = tr + 16 * ri + li;
+                const double x = p[min(r, m - 1)];
+                return r < m ? x : 0.0;
+            };
+            wave_tile_sweep(A, m, jb, CB, lk, colsrc, rowsrc, acc);
+            // (every element of this wave's row tile has been read: the sweep's last loads fed its last products)
 #pragma unroll
-            for (int ci = 0; ci < 2; ++ci)
+            for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-                for (int ri = 0; ri < 2; ++ri)
+                for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const int r = tr + rb + 16 * ri + li, c = cb + 16 * ci + lk + 4 * q;
+                        const int r = tr + 16 * ri + li, c = 16 * ci + lk + 4 * q;
                         if (r < m && c < nb) A[pk(r, jb + c, m)] = acc[ci][ri][q];
                     }
         }
@@ -305,62 +333,62 @@ __global__ __launch_bounds__(256) void big_diag_kernel(double *A, int m, int jb,
     }
 }
 
-// rows r0 + 64 * blockIdx.x ..: X = A[rows, jb..jb+64) inv(L11)^T
-__global__ __launch_bounds__(256) void big_panel_kernel(double *A, int m, int jb, int r0, const double *__restrict__ Linv) {
+// rows r0 + 64 * (4 blockIdx.x + wave) ..: X = A[rows, jb..jb+64) inv(L11)^T, a row tile per wave (the block has 64
+// columns: the launches below only come when rows lie under it)
+__global__ __launch_bounds__(256, 2) void big_panel_kernel(double *A, int m, int jb, int r0, const double *__restrict__ Linv) {
     __shared__ double Ld[CB][CB + 1];
-    __shared__ double Pr[64][NB + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1), li = lane & 15, lk = lane >> 4;
-    const int tr = r0 + 64 * blockIdx.x, nb = min(CB, m - jb);
+    const int li = lane & 15, lk = lane >> 4;
+    const int tr = r0 + 64 * (4 * blockIdx.x + wave);
     for (int e = tid; e < CB * CB; e += 256) Ld[e >> 6][e & (CB - 1)] = Linv[e];
-    d4 acc[2][2] = {};
-    for (int kh = 0; kh < CB; kh += NB) {
-        __syncthreads();
-        for (int e = tid; e < 64 * NB; e += 256) {
-            const int r = e & 63, c = e >> 6;
-            Pr[r][c] = (tr + r < m && kh + c < nb) ? A[pk(tr + r, jb + kh + c, m)] : 0.0;
-        }
-        __syncthreads();
-        quad_mfma32(Ld, kh, Pr, cb, rb, lane, acc);
-    }
     __syncthreads();
+    if (tr >= m) return; // (whole wave; no barrier below)
+    d4 acc[4][4] = {};
+    auto colsrc = [&](int ci, int k, const double *) { return Ld[16 * ci + li][k + lk]; };
+    auto rowsrc = [&](int ri, int, const double *p) {
+        const int r = tr + 16 * ri + li;
+        const double x = p[min(r, m - 1)];
+        return r < m ? x : 0.0;
+    };
+    wave_tile_sweep(A, m, jb, CB, lk, colsrc, rowsrc, acc);
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+    for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-        for (int ri = 0; ri < 2; ++ri)
+        for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = tr + rb + 16 * ri + li, c = cb + 16 * ci + lk + 4 * q;
-                if (r < m && c < nb) A[pk(r, jb + c, m)] = acc[ci][ri][q];
+                const int r = tr + 16 * ri + li, c = 16 * ci + lk + 4 * q;
+                if (r < m) A[pk(r, jb + c, m)] = acc[ci][ri][q];
             }
 }
 
-// A[tile] -= L[rows, k0..k0+K) L[cols, k0..k0+K)^T for the 64 x 64 tiles (tr, tc), tr = r0 + 64 bx,
-// tc = c0 + 64 by, tc <= tr, columns below c1 (K a multiple of 32)
-__global__ __launch_bounds__(256) void big_syrk_kernel(double *A, int m, int k0, int K, int r0, int c0, int c1) {
-    const int tr = r0 + 64 * blockIdx.x, tc = c0 + 64 * blockIdx.y;
-    if (tc > tr || tr >= m || tc >= c1) return;
-    __shared__ double Pr[64][NB + 1], Pc[64][NB + 1];
+// A[tile] -= L[rows, k0..k0+K) L[cols, k0..k0+K)^T for the 64 x 64 tiles (tr, tc), tr = r0 + 64 (4 bx + wave),
+// tc = c0 + 64 by, tc <= tr, columns below c1 (K a multiple of 8); a tile per wave, the four waves of a workgroup
+// share the column side through the cache
+__global__ __launch_bounds__(256, 2) void big_syrk_kernel(double *A, int m, int k0, int K, int r0, int c0, int c1) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rb = 32 * (wave >> 1), cb = 32 * (wave & 1), li = lane & 15, lk = lane >> 4;
-    d4 acc[2][2] = {};
-    for (int kc = 0; kc < K; kc += NB) {
-        __syncthreads();
-        for (int e = tid; e < 64 * NB; e += 256) {
-            const int r = e & 63, c = e >> 6;
-            Pr[r][c] = (tr + r < m) ? A[pk(tr + r, k0 + kc + c, m)] : 0.0;
-            Pc[r][c] = (tc + r < c1) ? A[pk(tc + r, k0 + kc + c, m)] : 0.0;
-        }
-        __syncthreads();
-        quad_mfma32(Pc, 0, Pr, cb, rb, lane, acc);
-    }
+    const int li = lane & 15, lk = lane >> 4;
+    const int tr = r0 + 64 * (4 * blockIdx.x + wave), tc = c0 + 64 * blockIdx.y;
+    if (tc > tr || tr >= m || tc >= c1) return;
+    d4 acc[4][4] = {};
+    auto colsrc = [&](int ci, int, const double *p) {
+        const int r = tc + 16 * ci + li;
+        const double x = p[min(r, c1 - 1)];
+        return r < c1 ? x : 0.0;
+    };
+    auto rowsrc = [&](int ri, int, const double *p) {
+        const int r = tr + 16 * ri + li;
+        const double x = p[min(r, m - 1)];
+        return r < m ? x : 0.0;
+    };
+    wave_tile_sweep(A, m, k0, K, lk, colsrc, rowsrc, acc);
 #pragma unroll
-    for (int ci = 0; ci < 2; ++ci)
+    for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
-        for (int ri = 0; ri < 2; ++ri)
+        for (int ri = 0; ri < 4; ++ri)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int r = tr + rb + 16 * ri + li, c = tc + cb + 16 * ci + lk + 4 * q;
+                const int r = tr + 16 * ri + li, c = tc + 16 * ci + lk + 4 * q;
                 if (r < m && c < c1 && r >= c) A[pk(r, c, m)] -= acc[ci][ri][q];
             }
 }
@@ -638,18 +666,19 @@ void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
         const int m = lv.max_m;
         double *A = lv.d_fac, *Linv = lv.d_work;
         auto tiles = [](int rows) { return static_cast<unsigned>((rows + 63) / 64); };
+        auto tiles4 = [](int rows) { return static_cast<unsigned>((rows + 255) / 256); }; // a 64-row tile per wave
         for (int jb = 0; jb < m; jb += 2 * CB) {
             const int h1 = jb + CB, end = std::min(m, jb + 2 * CB); // second half [h1, end), trailing part from end
             hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, jb, Linv, lv.d_linv, d_fail);
             if (h1 >= m) break;
-            hipLaunchKernelGGL(big_panel_kernel, dim3(tiles(m - h1)), dim3(256), 0, s, A, m, jb, h1, Linv);
+            hipLaunchKernelGGL(big_panel_kernel, dim3(tiles4(m - h1)), dim3(256), 0, s, A, m, jb, h1, Linv);
             // second half of the panel brought up to date with the first (K = 64)
-            hipLaunchKernelGGL(big_syrk_kernel, dim3(tiles(m - h1), 1), dim3(256), 0, s, A, m, jb, CB, h1, h1, end);
+            hipLaunchKernelGGL(big_syrk_kernel, dim3(tiles4(m - h1), 1), dim3(256), 0, s, A, m, jb, CB, h1, h1, end);
             hipLaunchKernelGGL(big_diag_kernel, dim3(1), dim3(256), 0, s, A, m, h1, Linv, lv.d_linv, d_fail);
             if (end >= m) break;
-            hipLaunchKernelGGL(big_panel_kernel, dim3(tiles(m - end)), dim3(256), 0, s, A, m, h1, end, Linv);
+            hipLaunchKernelGGL(big_panel_kernel, dim3(tiles4(m - end)), dim3(256), 0, s, A, m, h1, end, Linv);
             const unsigned t = tiles(m - end);
-            hipLaunchKernelGGL(big_syrk_kernel, dim3(t, t), dim3(256), 0, s, A, m, jb, 2 * CB, end, end, m);
+            hipLaunchKernelGGL(big_syrk_kernel, dim3(tiles4(m - end), t), dim3(256), 0, s, A, m, jb, 2 * CB, end, end, m);
         }
         return;
     }
