@@ -439,7 +439,6 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     if ((rc = up(&lv->d_k, lv->k, s)) != BBFMM_OK) return rc;
     if ((rc = up(&lv->d_internal, internal, s)) != BBFMM_OK) return rc;
     if ((rc = up(&lv->d_q, q, s)) != BBFMM_OK) return rc;
-    lap("upload (points, Q)", true);
     if (!q.empty()) {
         DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_t), q.size() * sizeof(double)));
         DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_g), q.size() * sizeof(double)));
