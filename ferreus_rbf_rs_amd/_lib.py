@@ -74,6 +74,11 @@ SIGNATURES = {
     "bbfmm_partition_coarse_count": (c_i64, [c_p]),
     "bbfmm_matvec_partition_upward": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_p, c_p]),
     "bbfmm_matvec_partition_finish": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_i32, c_p]),
+    "bbfmm_partition_world": (c_i32, [c_p]),
+    "bbfmm_partition_rank": (c_i32, [c_p]),
+    "bbfmm_partition_bounds": (ctypes.c_int, [c_p, c_i32, c_p]),
+    "bbfmm_matvec_partition_finish_sorted": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p]),
+    "bbfmm_partition_scatter": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i64, c_i32, c_p, c_i64]),
     "bbfmm_debug_partition_upward_counts": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     "bbfmm_get_tree_stats": (ctypes.c_int, [c_p, c_p]),
     "bbfmm_tree_built_on_device": (ctypes.c_int, [c_p]),

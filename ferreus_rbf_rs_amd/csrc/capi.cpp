@@ -196,6 +196,28 @@ int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ld
     END_GUARD(h)
 }
 
+int32_t bbfmm_partition_world(const bbfmm_handle *h) {
+    if (!h) return -1;
+    const std::vector<int64_t> &b = h->tree.partition_bounds();
+    return b.empty() ? 1 : static_cast<int32_t>(b.size()) - 1;
+}
+int32_t bbfmm_partition_rank(const bbfmm_handle *h) { return h ? h->tree.partition_rank() : -1; }
+int bbfmm_partition_bounds(const bbfmm_handle *h, int32_t world, int64_t *bounds_out) {
+    if (!h || !bounds_out) return BBFMM_BAD_ARGUMENT;
+    const std::vector<int64_t> &b = h->tree.partition_bounds();
+    if (b.empty() || static_cast<size_t>(world) + 1 != b.size()) return BBFMM_BAD_ARGUMENT;
+    std::copy(b.begin(), b.end(), bounds_out);
+    return BBFMM_OK;
+}
+int bbfmm_matvec_partition_finish_sorted(bbfmm_handle *h, const double *d_coarse, double *d_seg, int64_t ld, void *comm_stream) {
+    GUARD(h) return h->tree.matvec_partition_finish_sorted(d_coarse, d_seg, ld, static_cast<hipStream_t>(comm_stream));
+    END_GUARD(h)
+}
+int bbfmm_partition_scatter(bbfmm_handle *h, const double *d_all, int32_t first_part, int32_t n_parts, int64_t m_max, int32_t k,
+                            double *d_out, int64_t ldo) {
+    GUARD(h) return h->tree.partition_scatter(d_all, first_part, n_parts, m_max, k, d_out, ldo);
+    END_GUARD(h)
+}
 int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync, void *comm_stream) {
     GUARD(h) return h->tree.matvec_partition_finish(d_coarse, d_out, ldo, sync != 0, static_cast<hipStream_t>(comm_stream));
     END_GUARD(h)

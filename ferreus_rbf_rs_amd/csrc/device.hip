@@ -81,6 +81,24 @@ void launch_gather_weights(const double *w, int64_t ldw, int K, const int32_t *o
     if (N == 0) return;
     hipLaunchKernelGGL(gather_weights_kernel, dim3(grid_for(N, 256), K), dim3(256), 0, s, w, ldw, order, N, w_sorted);
 }
+__global__ void scatter_parts_kernel(const double *__restrict__ all, ScatterParts parts, int64_t m_max, int K,
+                                     const int32_t *__restrict__ order, double *__restrict__ out, int64_t ldo) {
+    const int k = blockIdx.y;
+    const int64_t n = parts.bound[parts.n] - parts.bound[0];
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t g = parts.bound[0] + i; // sorted position
+        int r = 0;
+        while (r + 1 < parts.n && g >= parts.bound[r + 1]) ++r;
+        out[k * ldo + order[g]] = all[((int64_t)r * K + k) * m_max + (g - parts.bound[r])];
+    }
+}
+void launch_scatter_parts(const double *all, const ScatterParts &parts, int64_t m_max, int K, const int32_t *order, double *out,
+                          int64_t ldo, hipStream_t s) {
+    const int64_t n = parts.bound[parts.n] - parts.bound[0];
+    if (n <= 0) return;
+    hipLaunchKernelGGL(scatter_parts_kernel, dim3(grid_for(n, 256), K), dim3(256), 0, s, all, parts, m_max, K, order, out, ldo);
+}
+
 void launch_scatter_output(const double *out_sorted, int64_t n, int K, const int32_t *perm, double *out, int64_t ldo,
                            int accumulate, hipStream_t s) {
     if (n == 0) return;

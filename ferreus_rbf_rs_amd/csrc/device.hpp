@@ -72,6 +72,15 @@ void launch_gather_weights(const double *w, int64_t ldw, int K, const int32_t *o
                            double *w_sorted, hipStream_t s);
 void launch_gather_weights_subset(const double *w, int64_t ldw, int K, const int32_t *order, const int32_t *pos, int64_t n_pos,
                                   int64_t N, double *w_sorted, hipStream_t s);
+// Gathered potentials of a partitioned matvec (all[part][k][m_max], each part's rows in the tree's sorted order) to their
+// rows of out: part r holds the sorted points bound[r] .. bound[r + 1).
+constexpr int kMaxScatterParts = 64;
+struct ScatterParts {
+    int n;
+    int64_t bound[kMaxScatterParts + 1];
+};
+void launch_scatter_parts(const double *all, const ScatterParts &parts, int64_t m_max, int K, const int32_t *order, double *out,
+                          int64_t ldo, hipStream_t s);
 void launch_scatter_output(const double *out_sorted, int64_t n, int K, const int32_t *perm,
                            double *out, int64_t ldo, int accumulate, hipStream_t s);
 void launch_gather_rows(const double *src, int64_t ld_src, int ncols, const int32_t *idx, int64_t n,

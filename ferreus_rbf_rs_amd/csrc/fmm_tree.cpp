@@ -2442,13 +2442,13 @@ int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, doub
 // Second half: d_coarse holds the sum over all ranks of what matvec_partition_upward packed (an all-reduce on this
 // handle's stream, or any stream ordered with it); evaluate at the owned targets (bbfmm.rs:444-507 over this
 // rank's cells_with_targets), owned rows of d_out written, the others untouched.
-int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync, hipStream_t comm_stream) {
+int FmmTree::partition_finish_core(const double *d_coarse, hipStream_t comm_stream, int *k_out) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     if (!have_part_ || part_pending_k_ < 1) return fail(BBFMM_BAD_ARGUMENT, "bbfmm_matvec_partition_upward must be called first");
-    const int64_t N = tree_.n_points, C = tree_.n_cells();
+    const int64_t C = tree_.n_cells();
     const int64_t cnt = partition_coarse_count();
     const int k = part_pending_k_;
-    if (!d_out || ldo < N || (cnt > 0 && !d_coarse)) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
+    if (cnt > 0 && !d_coarse) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
     part_pending_k_ = 0;
     if (comm_stream) { // the summed multipoles are ready when the communication stream gets here
         HIPCHK(hipEventRecord(ev_comm_, comm_stream));
@@ -2463,11 +2463,53 @@ int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int6
     CHK(downward(k, &part_plan_));
     CHK(leaf_pass_near(ts, k, false, stream_, 2)); // M2P (the outputs were zeroed and P2P ran in the first half)
     CHK(leaf_pass_far(ts, k, false));
+    *k_out = k;
+    return BBFMM_OK;
+}
+
+int FmmTree::matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync, hipStream_t comm_stream) {
+    if (!d_out || ldo < tree_.n_points) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
+    int k = 0;
+    CHK(partition_finish_core(d_coarse, comm_stream, &k));
+    const TargetSet &ts = part_targets_;
     phase_begin();
     launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);
     phase_end(kPhScatter);
     HIPCHK(hipGetLastError());
     if (sync) HIPCHK(hipStreamSynchronize(stream_));
+    return BBFMM_OK;
+}
+
+int FmmTree::matvec_partition_finish_sorted(const double *d_coarse, double *d_seg, int64_t ld, hipStream_t comm_stream) {
+    if (!d_seg || ld < part_targets_.m) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
+    int k = 0;
+    CHK(partition_finish_core(d_coarse, comm_stream, &k));
+    const TargetSet &ts = part_targets_;
+    phase_begin();
+    if (ts.m > 0)
+        HIPCHK(hipMemcpy2DAsync(d_seg, static_cast<size_t>(ld) * sizeof(double), ts.out.p, static_cast<size_t>(ts.m) * sizeof(double),
+                                static_cast<size_t>(ts.m) * sizeof(double), static_cast<size_t>(k), hipMemcpyDeviceToDevice, stream_));
+    phase_end(kPhScatter);
+    HIPCHK(hipGetLastError());
+    return BBFMM_OK;
+}
+
+int FmmTree::partition_scatter(const double *d_all, int first_part, int n_parts, int64_t m_max, int k, double *d_out, int64_t ldo) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (part_world_ < 2 || part_bounds_.size() != static_cast<size_t>(part_world_) + 1)
+        return fail(BBFMM_BAD_ARGUMENT, "the handle has no partition");
+    if (!d_all || !d_out || k < 1 || ldo < tree_.n_points || first_part < 0 || n_parts < 1 || first_part + n_parts > part_world_)
+        return fail(BBFMM_BAD_ARGUMENT, "bad arguments of the gathered scatter");
+    if (n_parts > kMaxScatterParts) return fail(BBFMM_UNSUPPORTED, "more gathered parts than the scatter kernel takes");
+    ScatterParts sp;
+    sp.n = n_parts;
+    for (int r = 0; r <= n_parts; ++r) sp.bound[r] = part_bounds_[static_cast<size_t>(first_part + r)];
+    for (int r = 0; r < n_parts; ++r)
+        if (sp.bound[r + 1] - sp.bound[r] > m_max) return fail(BBFMM_BAD_ARGUMENT, "a part holds more rows than m_max");
+    phase_begin();
+    launch_scatter_parts(d_all, sp, m_max, k, d_order_.p, d_out, ldo, stream_);
+    phase_end(kPhScatter);
+    HIPCHK(hipGetLastError());
     return BBFMM_OK;
 }
 
@@ -3093,6 +3135,7 @@ int FmmTree::set_partition(int rank, int world) {
     free_downward_plan(&part_plan_);
     part_pending_k_ = 0;
     part_rows_.clear();
+    part_bounds_.clear();
     if (world == 1) return BBFMM_OK;
     // balance the leaf-pass + M2L work proxy: P2P pair count + a per-point share of the far field
     const size_t nl = src_leaves_.size();
@@ -3115,6 +3158,13 @@ int FmmTree::set_partition(int rank, int world) {
         return i;
     };
     const size_t lb = rank == 0 ? 0 : cut(rank), le = rank == world - 1 ? nl : cut(rank + 1);
+    // every part's range of the sorted points (the same on every rank: the gathered potentials are scattered by it)
+    part_bounds_.assign(static_cast<size_t>(world) + 1, 0);
+    for (int r = 1; r < world; ++r) {
+        const size_t l = cut(r);
+        part_bounds_[static_cast<size_t>(r)] = l < nl ? t.pt_begin[src_leaves_[l]] : N;
+    }
+    part_bounds_[static_cast<size_t>(world)] = N;
     std::vector<int32_t> owned_leaves(src_leaves_.begin() + static_cast<std::ptrdiff_t>(lb),
                                       src_leaves_.begin() + static_cast<std::ptrdiff_t>(le));
     // owned targets: one contiguous range of the sorted sources

@@ -164,6 +164,12 @@ class FmmTree {
     // stream wait for it.  Null: the caller orders the collective after the handle's stream itself.
     int matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse, hipStream_t comm_stream);
     int matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync, hipStream_t comm_stream);
+    // the same, but the owned potentials stay in the tree's sorted order: k rows of d_seg (ld >= the owned count), the
+    // block a rank sends to the all-gather; partition_scatter then writes gathered blocks of parts [first, first + n)
+    // -- d_all[part][k][m_max] -- to their rows of d_out in one pass over the tree's permutation
+    int matvec_partition_finish_sorted(const double *d_coarse, double *d_seg, int64_t ld, hipStream_t comm_stream);
+    int partition_scatter(const double *d_all, int first_part, int n_parts, int64_t m_max, int k, double *d_out, int64_t ldo);
+    const std::vector<int64_t> &partition_bounds() const { return part_bounds_; } // world + 1 offsets into the sorted points
     int register_subset(const int64_t *idx, int64_t n_idx, int *id_out);
     int matvec_subset_device(int id, const double *d_w, double *d_y, bool sync);
     int set_partition(int rank, int world);
@@ -194,6 +200,7 @@ class FmmTree {
     }
     const std::vector<int64_t> &partition_rows() const { return part_rows_; }
     bool partitioned() const { return part_world_ > 1; }
+    int partition_rank() const { return part_rank_; }
     const std::vector<HostM2lClass> &m2l_host() const { return m2l_host_; }
     void m2l_variant_stats(int64_t *n_variants, int64_t *n_cells) const {
         *n_variants = static_cast<int64_t>(m2l_variants_.size());
@@ -288,7 +295,8 @@ class FmmTree {
     int m2l_slot_t_ = 1; // most transfer vectors any stage-1 column block touches
     // partition
     int part_rank_ = 0, part_world_ = 1;
-    std::vector<int64_t> part_rows_;
+    std::vector<int64_t> part_rows_, part_bounds_;
+    int partition_finish_core(const double *d_coarse, hipStream_t comm_stream, int *k_out);
     bool part_empty_ = false;
     DownwardPlan part_plan_;                     // partition: restricted downward pass
     std::vector<std::unique_ptr<SubsetPlan>> subset_plans_; // partial matvecs, least recently used evicted

@@ -314,6 +314,31 @@ class FmmTree:
         """Second half: d_coarse summed over the ranks; downward + leaf pass of the owned targets."""
         self._raise(self._lib.bbfmm_matvec_partition_finish(self._h, d_coarse or None, d_out, ldo, int(sync), comm_stream or None))
 
+    def partition_world(self) -> int:
+        """Parts of the handle's partition (1: none set)."""
+        return int(self._lib.bbfmm_partition_world(self._h))
+
+    def partition_rank(self) -> int:
+        """The part of its partition this handle owns."""
+        return int(self._lib.bbfmm_partition_rank(self._h))
+
+    def partition_bounds(self) -> np.ndarray:
+        """world + 1 offsets into the tree's sorted points: part r owns bounds[r] .. bounds[r + 1) (the same on every
+        rank of a `set_partition(rank, world)`)."""
+        world = self.partition_world()
+        b = np.zeros(world + 1, dtype=np.int64)
+        self._raise(self._lib.bbfmm_partition_bounds(self._h, world, b.ctypes.data))
+        return b
+
+    def matvec_partition_finish_sorted(self, d_coarse: int, d_seg: int, ld: int, comm_stream: int = 0):
+        """Second half with the owned potentials left in sorted order: k rows of d_seg (stride ld), the block a rank
+        sends to the all-gather (asynchronous on the handle's stream)."""
+        self._raise(self._lib.bbfmm_matvec_partition_finish_sorted(self._h, d_coarse or None, d_seg, ld, comm_stream or None))
+
+    def partition_scatter(self, d_all: int, first_part: int, n_parts: int, m_max: int, k: int, d_out: int, ldo: int):
+        """Gathered blocks d_all[n_parts][k][m_max] of parts first_part .. first_part + n_parts -> their rows of d_out."""
+        self._raise(self._lib.bbfmm_partition_scatter(self._h, d_all, first_part, n_parts, m_max, k, d_out, ldo))
+
     def debug_partition_upward_counts(self):
         """(counts, reads, info): the rank's upward plan walked with point counts (see the header)."""
         c = self.stats().n_cells

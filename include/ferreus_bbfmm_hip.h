@@ -249,6 +249,24 @@ int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out);
 int64_t bbfmm_partition_coarse_count(const bbfmm_handle *h);
 int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse, void *comm_stream);
 int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync, void *comm_stream);
+/* The exchange of the owned potentials in the tree's sorted order (what distributed.py's PartitionedMatvec uses): a part
+ * owns ONE range of the sorted points, so its potentials travel as one contiguous block and every rank writes the gathered
+ * blocks to their rows in a single pass over the tree's permutation -- no index arrays on the caller's side.
+ *   bbfmm_partition_world / _rank         parts of the handle's partition (1: none set) and the part it owns
+ *   bbfmm_partition_bounds                world + 1 offsets: part r owns the sorted points bounds[r] .. bounds[r + 1)
+ *                                         (the same on every rank; its own count is bounds[rank + 1] - bounds[rank]);
+ *                                         `world` must be bbfmm_partition_world
+ *   bbfmm_matvec_partition_finish_sorted  like _finish, but leaves the k x count owned potentials in d_seg (row stride
+ *                                         ld >= count) instead of scattering them -- the block to all-gather
+ *   bbfmm_partition_scatter               d_all[n_parts][k][m_max] = the gathered blocks of parts first_part ..
+ *                                         first_part + n_parts (normally 0, world) -> their rows of d_out (k x N, row
+ *                                         stride ldo); asynchronous on the handle's stream like the other calls */
+int32_t bbfmm_partition_world(const bbfmm_handle *h);
+int32_t bbfmm_partition_rank(const bbfmm_handle *h);
+int bbfmm_partition_bounds(const bbfmm_handle *h, int32_t world, int64_t *bounds_out);
+int bbfmm_matvec_partition_finish_sorted(bbfmm_handle *h, const double *d_coarse, double *d_seg, int64_t ld, void *comm_stream);
+int bbfmm_partition_scatter(bbfmm_handle *h, const double *d_all, int32_t first_part, int32_t n_parts, int64_t m_max, int32_t k,
+                            double *d_out, int64_t ldo);
 /* Test hook (host side, also on BBFMM_FLAG_HOST_ONLY handles): walks this rank's upward plan with point COUNTS in
  * place of multipoles (P2M -> points of the leaf, M2M -> sum over the plan's children).  counts_out[c] (n_cells):
  * what the plan leaves in cell c before the exchange (-1: never written); reads_out[c] = 1 where the rank's downward

@@ -80,6 +80,27 @@ def test_single_rank_rccl_exchange_matches_unpartitioned():
                 full[:, idx] = o[:, idx]
             assert not torch.isnan(full).any()
             assert (full - ref).abs().max() / ref.abs().max() < 1e-12, world
+            # the same through the sorted-order blocks: every rank's owned potentials as one contiguous block, the
+            # blocks side by side as the all-gather leaves them, one scatter over the tree's permutation
+            tree.set_partition(0, world)
+            bounds = tree.partition_bounds()
+            assert tree.partition_world() == world and len(bounds) == world + 1 and bounds[0] == 0 and bounds[-1] == n
+            m_max = int(np.diff(bounds).max())
+            recv = torch.full((world, K, m_max), float("nan"), dtype=torch.float64, device=dev)
+            for r in range(world):
+                tree.set_partition(r, world)
+                assert tree.partition_rank() == r and len(tree.partition_rows()) == bounds[r + 1] - bounds[r]
+                scratch = torch.zeros_like(total)
+                tree.matvec_partition_upward(w.data_ptr(), n, K, scratch.data_ptr())
+                tree.matvec_partition_finish_sorted(total.data_ptr(), recv[r].data_ptr(), m_max)
+                stream.synchronize()
+            full2 = torch.full_like(w, float("nan"))
+            tree.partition_scatter(recv.data_ptr(), 0, world, m_max, K, full2.data_ptr(), n)
+            stream.synchronize()
+            assert not torch.isnan(full2).any()
+            assert torch.equal(full2, full) or (full2 - full).abs().max() / ref.abs().max() < 1e-13, world
+            with pytest.raises(ValueError):
+                tree.partition_scatter(recv.data_ptr(), 1, world, m_max, K, full2.data_ptr(), n)   # parts beyond the world
         tree.set_partition(0, 1)
         # the whole N > 1 step on the one-rank RCCL group: all-reduce on the side stream between the library's events,
         # all-gather on the handle's stream, no host synchronisation in between, several steps back to back.  The
