@@ -39,6 +39,8 @@ void extents_of(const Pts &P, const int64_t *idx, int64_t np, std::vector<double
 
 // The same over np points given by contiguous coordinate arrays x[a][0..np).
 void extents_of(const double *const *x, int d, int64_t np, double *e) {
+    for (int a = 0; a < 2 * d && np <= 0; ++a) e[a] = 0.0; // (an empty half of a one-point domain: leaf_threshold 1, quota 1)
+    if (np <= 0) return;
     for (int a = 0; a < d; ++a) {
         const double *xa = x[a];
         double lo = xa[0], hi = xa[0];
