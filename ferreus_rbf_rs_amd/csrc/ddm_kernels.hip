@@ -511,10 +511,9 @@ __global__ __launch_bounds__(256) void ddm_solve_kernel(View v, const double *__
 }
 
 // ---- Domain::solve for ONE large domain (the coarse level): the substitutions run as a sequence of
-// launches over 64-column blocks so that the whole chip streams the factor instead of one workgroup.
+// launches over column blocks so that the whole chip streams the factor instead of one workgroup.
 // Both sweeps are right-looking (a solved block updates the entries still to be solved), so every
 // output has one writer and the result is deterministic.
-constexpr int SB = 64;
 
 __global__ __launch_bounds__(256) void big_gather_kernel(View v, const double *__restrict__ values, int n) {
     const int e = blockIdx.x * 256 + threadIdx.x;
@@ -529,76 +528,154 @@ __global__ __launch_bounds__(256) void big_rhs_kernel(View v, int k, int m) { //
     v.work[k + j] = s;
 }
 
-// forward step jb: z[jb..jb+nb) = L_bb^{-1} y[jb..), then y[r] -= L[r, jb..] z[jb..] for the rows below.
-// Every workgroup solves the diagonal block itself (cheaper than another launch); workgroup 0 stores it.
-__global__ __launch_bounds__(256) void big_fwd_step_kernel(const double *__restrict__ L, const double *__restrict__ linv,
-                                                           int m, int jb, double *y, double *__restrict__ z) {
-    // the diagonal block's inverse was stored at factorisation (row-major [row][k]): the block solve is a
-    // 64 x 64 product by all four waves instead of 64 dependent substitution steps
-    __shared__ double Li[SB][SB + 1];
-    __shared__ double yin[SB], yb[SB];
-    __shared__ double part[4][SB];
-    const int tid = threadIdx.x, nb = min(SB, m - jb);
-    const double *lb = linv + static_cast<int64_t>(jb / SB) * (SB * SB);
-    for (int e = tid; e < SB * SB; e += 256) Li[e >> 6][e & (SB - 1)] = lb[e];
-    if (tid < SB) yin[tid] = tid < nb ? y[jb + tid] : 0.0;
-    __syncthreads();
-    {
-        const int r = tid & (SB - 1), q4 = tid >> 6;
-        double s = 0.0;
-        for (int k = q4; k <= r; k += 4) s += Li[r][k] * yin[k];
-        part[q4][r] = s;
+// ---- substitutions of the one large domain in blocks of BB = 1024 (kBigSolveBlock): the 64-wide steps above are a chain
+// of 2 m / 64 dependent launches of ~22 us each (13.7 ms at m = 19.7k, whatever launches them); with the inverses of the
+// 1024 x 1024 diagonal blocks a block step is two launches -- a triangular product with the inverse, then the update of
+// everything below (above) -- and the chain is 4 m / 1024 launches over the same 2 x 1.5 GB of factor.
+constexpr int BB = kBigSolveBlock;
+
+// X = T^{-1} for the diagonal block T = L[j0.., j0..] (nb x nb, nb <= BB), one thread per column: row i of the
+// forward substitution on the unit vector; X is stored row-major (X[i][c] at i * BB + c), zero above the diagonal.
+// Every thread walks the same (i, k) -- rows above its own diagonal element come out as the zeros they are -- so that
+// T(i, k) is one (scalar) address per step and X[k][.] one coalesced row.
+__global__ __launch_bounds__(256) void big_block_inverse_kernel(const double *__restrict__ L, int m, double *__restrict__ binv) {
+    const int blk = blockIdx.x, j0 = blk * BB, nb = min(BB, m - j0);
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    double *X = binv + static_cast<int64_t>(blk) * BB * BB;
+    const int cfirst = blockIdx.y * 256; // rows above the workgroup's first column are zero for all of its columns
+    for (int i = 0; i < cfirst; ++i) X[static_cast<int64_t>(i) * BB + c] = 0.0;
+    for (int i = cfirst; i < nb; ++i) {
+        const double *t = L + pk(j0 + i, j0 + cfirst, m); // T(i, cfirst), then along the row: + (m - column - 1)
+        double sacc[8] = {i == c ? 1.0 : 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        int k = cfirst, col = j0 + cfirst;
+        for (; k + 7 < i; k += 8) { // eight independent loads and sums in flight
+            double tv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                tv[u] = t[0];
+                t += m - col - 1;
+                ++col;
+                xv[u] = X[static_cast<int64_t>(k + u) * BB + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sacc[u] -= tv[u] * xv[u];
+        }
+        for (; k < i; ++k) {
+            sacc[0] -= t[0] * X[static_cast<int64_t>(k) * BB + c];
+            t += m - col - 1;
+            ++col;
+        }
+        const double s0 = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]), s1 = (sacc[4] + sacc[5]) + (sacc[6] + sacc[7]);
+        // (t now points at T(i, i))
+        X[static_cast<int64_t>(i) * BB + c] = (c < nb && i >= c) ? (s0 + s1) / t[0] : 0.0;
     }
-    __syncthreads();
-    if (tid < SB) {
-        yb[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        if (blockIdx.x == 0 && tid < nb) z[jb + tid] = yb[tid];
-    }
-    __syncthreads();
-    // 64 rows per workgroup, the block's columns split over the four waves
-    const int lane = tid & 63, q = tid >> 6;
-    const int r = jb + nb + blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (r < m) {
-        const int c0 = q * 16, c1 = min(nb, c0 + 16);
-        for (int c = c0; c < c1; ++c) s += L[pk(r, jb + c, m)] * yb[c];
-    }
-    part[q][lane] = s;
-    __syncthreads();
-    if (q == 0 && r < m) y[r] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+    for (int i = nb; i < BB; ++i) X[static_cast<int64_t>(i) * BB + c] = 0.0;
 }
 
-// backward step jb: g[jb..jb+nb) = L_bb^{-T} z[jb..), then z[c] -= L[jb.., c]^T g[jb..) for the columns before.
-__global__ __launch_bounds__(256) void big_bwd_step_kernel(const double *__restrict__ L, const double *__restrict__ linv,
-                                                           int m, int jb, double *z, double *__restrict__ g) {
-    __shared__ double Li[SB][SB + 1];
-    __shared__ double zin[SB], yb[SB];
-    __shared__ double part[4][SB];
-    const int tid = threadIdx.x, nb = min(SB, m - jb);
-    const double *lb = linv + static_cast<int64_t>(jb / SB) * (SB * SB);
-    for (int e = tid; e < SB * SB; e += 256) Li[e >> 6][e & (SB - 1)] = lb[e];
-    if (tid < SB) zin[tid] = tid < nb ? z[jb + tid] : 0.0;
+// z[j0 + r] = sum_{k <= r} X[r][k] y[j0 + k]: 64 rows per workgroup, 16 per wave, the lanes run along a row
+__global__ __launch_bounds__(256) void big_blk_fwd_solve_kernel(const double *__restrict__ binv, int m, int j0,
+                                                                const double *__restrict__ y, double *__restrict__ z) {
+    __shared__ double ys[BB];
+    const int nb = min(BB, m - j0), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const double *X = binv + static_cast<int64_t>(j0 / BB) * BB * BB;
+    for (int e = tid; e < BB; e += 256) ys[e] = e < nb ? y[j0 + e] : 0.0;
     __syncthreads();
+    for (int q = 0; q < 16; ++q) {
+        const int r = blockIdx.x * 64 + wave * 16 + q;
+        if (r >= nb) break;
+        double sacc = 0.0;
+        for (int k = lane; k <= r; k += 64) sacc += X[static_cast<int64_t>(r) * BB + k] * ys[k];
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+        if (lane == 0) z[j0 + r] = sacc;
+    }
+}
+
+// y[r] -= sum_c L[r, j0 + c] z[j0 + c] for the rows r >= j0 + nb: 64 rows per workgroup (the lanes), the block's columns
+// split over sixteen waves (64 each); partial sums meet in LDS in a fixed order
+__global__ __launch_bounds__(1024) void big_blk_fwd_update_kernel(const double *__restrict__ L, int m, int j0, double *y,
+                                                                  const double *__restrict__ z) {
+    __shared__ double zs[BB];
+    __shared__ double part[16][64];
+    const int nb = min(BB, m - j0), tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    for (int e = tid; e < BB; e += 1024) zs[e] = e < nb ? z[j0 + e] : 0.0;
+    __syncthreads();
+    const int r = j0 + nb + blockIdx.x * 64 + lane;
+    double sacc[4] = {0.0, 0.0, 0.0, 0.0};
+    if (r < m) {
+        const int c0 = q * 64, c1 = min(nb, c0 + 64);
+        const double *p = L + pk(r, j0 + c0, m); // along the row: + (m - column - 1)
+        int col = j0 + c0;
+        for (int c = c0; c < c1; ++c) {
+            sacc[c & 3] += p[0] * zs[c];
+            p += m - col - 1;
+            ++col;
+        }
+    }
+    part[q][lane] = (sacc[0] + sacc[1]) + (sacc[2] + sacc[3]);
+    __syncthreads();
+    if (q == 0 && r < m) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][lane];
+        y[r] -= t;
+    }
+}
+
+// g[j0 + c] = sum_{i >= c} X[i][c] z[j0 + i]: 64 columns per workgroup (the lanes), the rows split over sixteen waves
+__global__ __launch_bounds__(1024) void big_blk_bwd_solve_kernel(const double *__restrict__ binv, int m, int j0,
+                                                                 const double *__restrict__ z, double *__restrict__ g) {
+    __shared__ double zs[BB];
+    __shared__ double part[16][64];
+    const int nb = min(BB, m - j0), tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const double *X = binv + static_cast<int64_t>(j0 / BB) * BB * BB;
+    for (int e = tid; e < BB; e += 1024) zs[e] = e < nb ? z[j0 + e] : 0.0;
+    __syncthreads();
+    const int c = blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0;
     {
-        const int r = tid & (SB - 1), q4 = tid >> 6; // gamma[r] = sum_{k >= r} inv[k][r] z[k]
-        double s = 0.0;
-        for (int k = r + q4; k < SB; k += 4) s += Li[k][r] * zin[k];
-        part[q4][r] = s;
+        // rows blockIdx.x * 64 .. nb (above them X is zero for these columns), dealt to the waves in runs of 64
+        const int i_lo = blockIdx.x * 64 + q * 64;
+        for (int i0 = i_lo; i0 < nb; i0 += 1024) {
+            const int i1 = min(nb, i0 + 64);
+            int i = i0;
+            for (; i + 1 < i1; i += 2) {
+                s0 += X[static_cast<int64_t>(i) * BB + c] * zs[i];
+                s1 += X[static_cast<int64_t>(i + 1) * BB + c] * zs[i + 1];
+            }
+            if (i < i1) s0 += X[static_cast<int64_t>(i) * BB + c] * zs[i];
+        }
     }
+    part[q][lane] = s0 + s1;
     __syncthreads();
-    if (tid < SB) {
-        yb[tid] = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        if (blockIdx.x == 0 && tid < nb) g[jb + tid] = yb[tid];
+    if (q == 0 && c < nb) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w][lane];
+        g[j0 + c] = t;
     }
+}
+
+// z[c] -= sum_i L[j0 + i, c] g[j0 + i] for the columns c < j0: 64 columns per workgroup, 4 per wave (sixteen waves); the
+// lanes run down the block's rows (contiguous in a packed column)
+__global__ __launch_bounds__(1024) void big_blk_bwd_update_kernel(const double *__restrict__ L, int m, int j0, double *z,
+                                                                  const double *__restrict__ g) {
+    __shared__ double gs[BB];
+    const int nb = min(BB, m - j0), tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int e = tid; e < BB; e += 1024) gs[e] = e < nb ? g[j0 + e] : 0.0;
     __syncthreads();
-    // 64 columns per workgroup, 16 per wave; the lanes run down the block's rows
-    const int lane = tid & 63, wave = tid >> 6;
-    const double gl = lane < nb ? yb[lane] : 0.0;
-    const int cbeg = blockIdx.x * 64 + wave * 16, cend = min(jb, cbeg + 16);
+    const int cbeg = blockIdx.x * 64 + wave * 4, cend = min(j0, cbeg + 4);
     for (int c = cbeg; c < cend; ++c) {
-        double s = lane < nb ? L[pk(jb + lane, c, m)] * gl : 0.0;
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-        if (lane == 0) z[c] -= s;
+        const double *col = L + pk(j0, c, m); // rows j0 .. of column c are contiguous
+        double s0 = 0.0, s1 = 0.0;
+        int i = lane;
+        for (; i + 64 < nb; i += 128) {
+            s0 += col[i] * gs[i];
+            s1 += col[i + 64] * gs[i + 64];
+        }
+        if (i < nb) s0 += col[i] * gs[i];
+        double sacc = s0 + s1;
+        for (int off = 32; off > 0; off >>= 1) sacc += __shfl_down(sacc, off, 64);
+        if (lane == 0) z[c] -= sacc;
     }
 }
 
@@ -685,6 +762,12 @@ void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s) {
     hipLaunchKernelGGL(ddm_cholesky_kernel, dim3(static_cast<unsigned>(lv.n_dom)), dim3(256), 0, s, make_view(lv), d_fail);
 }
 
+void launch_ddm_big_block_inverses(const DdmLevelSolver &lv, hipStream_t s) {
+    if (!ddm_level_is_big(lv) || !lv.d_binv) return;
+    const int m = lv.max_m;
+    hipLaunchKernelGGL(big_block_inverse_kernel, dim3((m + BB - 1) / BB, BB / 256), dim3(256), 0, s, lv.d_fac, m, lv.d_binv);
+}
+
 __global__ __launch_bounds__(256) void unpack_symmetric_kernel(const double *__restrict__ packed, int m, double *__restrict__ full) {
     const int c = blockIdx.x;
     for (int r = c + threadIdx.x; r < m; r += 256) {
@@ -714,12 +797,18 @@ int launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d
             const int lrc = big_lu_solve(lv, g, s);
             if (lrc != BBFMM_OK) return lrc;
         } else {
-            for (int jb = 0; jb < m; jb += SB) {
-                const int rest = m - jb - std::min(SB, m - jb);
-                hipLaunchKernelGGL(big_fwd_step_kernel, dim3(std::max(1, (rest + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, y, z);
+            for (int j0 = 0; j0 < m; j0 += BB) { // L z = y
+                const int nb = std::min(BB, m - j0), rest = m - j0 - nb;
+                hipLaunchKernelGGL(big_blk_fwd_solve_kernel, dim3((nb + 63) / 64), dim3(256), 0, s, lv.d_binv, m, j0, y, z);
+                if (rest > 0)
+                    hipLaunchKernelGGL(big_blk_fwd_update_kernel, dim3((rest + 63) / 64), dim3(1024), 0, s, L, m, j0, y, z);
             }
-            for (int jb = ((m - 1) / SB) * SB; jb >= 0; jb -= SB)
-                hipLaunchKernelGGL(big_bwd_step_kernel, dim3(std::max(1, (jb + 63) / 64)), dim3(256), 0, s, L, lv.d_linv, m, jb, z, g);
+            for (int j0 = ((m - 1) / BB) * BB; j0 >= 0; j0 -= BB) { // L^T g = z
+                const int nb = std::min(BB, m - j0);
+                hipLaunchKernelGGL(big_blk_bwd_solve_kernel, dim3((nb + 63) / 64), dim3(1024), 0, s, lv.d_binv, m, j0, z, g);
+                if (j0 > 0)
+                    hipLaunchKernelGGL(big_blk_bwd_update_kernel, dim3((j0 + 63) / 64), dim3(1024), 0, s, L, m, j0, z, g);
+            }
         }
         if (k) hipLaunchKernelGGL(big_special_kernel, dim3(k), dim3(256), 0, s, v, m, g);
         hipLaunchKernelGGL(big_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, s, v, n, k, g, d_out, all_points ? 1 : 0);

@@ -445,8 +445,11 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     }
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_fac), static_cast<size_t>(std::max<int64_t>(lv->fac_off[nd], 1)) * sizeof(double)));
     DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_work), static_cast<size_t>(std::max<int64_t>(lv->n_entries, 1)) * (ddm_level_is_big(*lv) ? 3 : 1) * sizeof(double)));
-    if (ddm_level_is_big(*lv))
+    if (ddm_level_is_big(*lv)) {
         DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_linv), static_cast<size_t>((lv->max_m + 63) / 64) * 4096 * sizeof(double)));
+        DHIP(hipMalloc(reinterpret_cast<void **>(&lv->d_binv),
+                       static_cast<size_t>((lv->max_m + kBigSolveBlock - 1) / kBigSolveBlock) * kBigSolveBlock * kBigSolveBlock * sizeof(double)));
+    }
     int *d_fail = nullptr; // one flag per domain
     DHIP(hipMalloc(reinterpret_cast<void **>(&d_fail), static_cast<size_t>(std::max<int64_t>(nd, 1)) * sizeof(int)));
     DHIP(hipMemsetAsync(d_fail, 0, static_cast<size_t>(std::max<int64_t>(nd, 1)) * sizeof(int), s));
@@ -464,7 +467,14 @@ int ddm_level_build(const double *pts, int64_t ld, int d, DdmLevel *level, const
     std::vector<int64_t> failed;
     for (int64_t i = 0; i < nd; ++i)
         if (fail[static_cast<size_t>(i)]) failed.push_back(i);
-    if (failed.empty()) return BBFMM_OK;
+    if (failed.empty()) {
+        if (ddm_level_is_big(*lv)) {
+            launch_ddm_big_block_inverses(*lv, s);
+            lap("inverses of the 1024-blocks", true);
+            DHIP(hipGetLastError());
+        }
+        return BBFMM_OK;
+    }
     // local systems that are not positive definite: host fallback per domain; the one large coarse matrix
     // (which would take the host hours) is assembled again, unpacked and factorised by pivoted LU on the device
     if (ddm_level_is_big(*lv)) {
@@ -510,6 +520,7 @@ void ddm_level_free(DdmLevelSolver *lv) {
     (void)hipFree(lv->d_work);
     (void)hipFree(lv->d_mode);
     (void)hipFree(lv->d_linv);
+    (void)hipFree(lv->d_binv);
     (void)hipFree(lv->d_tmp);
     (void)hipFree(lv->d_lu);
     (void)hipFree(lv->d_ipiv);

@@ -48,6 +48,8 @@ struct DdmLevelSolver {
     uint8_t *d_internal = nullptr;
     double *d_q = nullptr, *d_t = nullptr, *d_g = nullptr, *d_fac = nullptr;
     double *d_linv = nullptr;  // one large domain: inverses of the 64 x 64 diagonal blocks of the factor
+    double *d_binv = nullptr;  // ... and of its 1024 x 1024 diagonal blocks (row-major, full squares): the substitutions
+                               // walk blocks of 1024 (two launches each) instead of 64
     uint8_t *d_mode = nullptr; // per domain: 1 = fac holds the packed symmetric inverse (host fallback)
     double *d_tmp = nullptr;   // n_entries scratch for those domains
     int n_fallback = 0;
@@ -77,6 +79,9 @@ void launch_ddm_prep(const KernelSpec &ks, double nugget, int d, const DdmLevelS
 void launch_ddm_assemble(const KernelSpec &ks, double nugget, int d, const DdmLevelSolver &lv, hipStream_t s);
 void launch_ddm_cholesky(const DdmLevelSolver &lv, int *d_fail, hipStream_t s);
 int launch_ddm_solve(const DdmLevelSolver &lv, const double *d_values, double *d_out, bool all_points, hipStream_t s);
+// one large domain, after a successful Cholesky: lv.d_binv = inverses of the factor's 1024 x 1024 diagonal blocks
+constexpr int kBigSolveBlock = 1024;
+void launch_ddm_big_block_inverses(const DdmLevelSolver &lv, hipStream_t s);
 // packed lower triangle (column by column) -> full symmetric m x m column-major
 void launch_ddm_unpack_symmetric(const double *packed, int m, double *full, hipStream_t s);
 // gamma = (Q^T A Q)^-1 y through the LU factors of a large domain (y, gamma: m doubles on the device, in place)
