@@ -290,13 +290,19 @@ def roofline_of(stats, K, per_launch, world, launches=None):
     dominant = max(kern, key=lambda k: per_launch[k])
     kd = kern[dominant]
     dur = per_launch[dominant] * 1e-3
-    achieved = kd["work"] / dur * kd["scale"] if dur > 0 and world == 1 else None
-    return dominant, {
+    # N > 1: rank 0's launch against ITS share of the job's algorithmic work, taken as 1 / world (the partition balances
+    # a work proxy; the halo a rank computes beyond its share is not algorithmic work and lowers the figure)
+    work = kd["work"] / world
+    achieved = work / dur * kd["scale"] if dur > 0 else None
+    out = {
         "kernel": dominant, "bound": kd["bound"], "achieved": achieved, "peak": kd["peak"],
         "unit": kd["unit"], "frac": (achieved / kd["peak"]) if achieved else None,
-        "traffic": None, "avg_launch_ms": per_launch[dominant], "algorithmic_work_per_launch": kd["work"],
+        "traffic": None, "avg_launch_ms": per_launch[dominant], "algorithmic_work_per_launch": work,
         "launches_per_step": (launches or {}).get(dominant, 1),
     }
+    if world > 1:
+        out["work_share"] = "rank 0's launch; algorithmic work = the job's / %d" % world
+    return dominant, out
 
 
 # Arithmetic of one kernel evaluation in the reference's pair loops (bbfmm.rs:1162-1251 with distance_sq
