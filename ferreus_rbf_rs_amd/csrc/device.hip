@@ -1158,7 +1158,8 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, W
                                                                const double *__restrict__ centers,
                                                                const double *__restrict__ lengths, Xyz src,
                                                                const double *__restrict__ ws, const double *__restrict__ M,
-                                                               double *__restrict__ L, double *__restrict__ out) {
+                                                               double *__restrict__ L, double *__restrict__ out, int out_off,
+                                                               int out_n) {
     __shared__ SymTile tile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1219,7 +1220,10 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, W
     for (int r = 0; r < SYM_TR; ++r) {
         if (r < nr) {
             const double s = wave_sum(racc[r]);
-            if (lane == 0) unsafeAtomicAdd(&out[r_lo + r], s);
+            // (a partition's output holds its own rows only: out_off = first owned row; the rows of a leaf outside are
+            // here for their column sums -- P2L into the partition's cells -- alone)
+            const int o = r_lo + r - out_off;
+            if (lane == 0 && o >= 0 && o < out_n) unsafeAtomicAdd(&out[o], s);
         }
     }
 }
@@ -1893,13 +1897,13 @@ int wx_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
 void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
                    const int64_t *w_range, const int32_t *w_cells, const double *centers, const double *lengths,
                    const double *const *src_xyz, const double *w_sorted, const double *M, double *L, double *out_sorted,
-                   hipStream_t s) {
+                   int out_off, int out_n, hipStream_t s) {
     if (n_jobs == 0) return;
     const WxJobs jobs{n_jobs, tgt_begin, tgt_end, w_range, w_cells};
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
         hipLaunchKernelGGL((wx_sym_kernel<ID>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, ch.dev, centers, lengths,
-                           make_xyz(src_xyz), w_sorted, M, L, out_sorted);
+                           make_xyz(src_xyz), w_sorted, M, L, out_sorted, out_off, out_n);
     });
 }
 

@@ -162,7 +162,7 @@ int wx_sym_rows_per_job();
 // W list, w_range their ranges in w_cells; row sums go to out_sorted (M2P), column sums to L (P2L), both atomically.
 void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
                    const int64_t *w_range, const int32_t *w_cells, const double *centers, const double *lengths,
-                   const double *const *src_xyz, const double *w_sorted, const double *M, double *L, double *out_sorted,
+                   const double *const *src_xyz, const double *w_sorted, const double *M, double *L, double *out_sorted, int out_off, int out_n,
                    hipStream_t s);
 // M2P: sources are the Chebyshev nodes of the W-list cells, weights their multipoles.  Job i
 // covers targets [tgt_begin[i], tgt_end[i]) and the W cells w_cells[w_begin[i] .. w_end[i]).

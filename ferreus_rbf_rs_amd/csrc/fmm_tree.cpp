@@ -1674,7 +1674,8 @@ int FmmTree::build_source_target_set() {
 // sorted sources [pb, pe): the leaf itself and the U points outside [pb, pe) one-sided, the U points after
 // the leaf inside the range two-sided; the U points before the leaf inside the range belong to those leaves'
 // own jobs.  (U lists are symmetric: linear_tree.rs:295-364 collects adjacent leaves from both sides.)
-int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe) {
+int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe,
+                            const std::vector<uint8_t> *part_active) {
     const HostTree &t = tree_;
     // Two kinds of jobs over the same run lists: a leaf of at most p2p_sym_wave_rows() rows is ONE job of the
     // wave-per-job kernel (no barriers, columns in registers: faster where a leaf's work is small); bigger leaves go
@@ -1753,13 +1754,25 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
         }
     }
     ts->n_wx_jobs = 0;
-    if (pb == 0 && pe == t.n_points && !t.w.idx.empty() &&
-        static_cast<int64_t>(t.n_cells()) * cheb_.n_pad < (int64_t(1) << 31)) { // whole source set: M2P + P2L fused
+    const bool whole = pb == 0 && pe == t.n_points;
+    if ((whole || part_active) && !t.w.idx.empty() &&
+        static_cast<int64_t>(t.n_cells()) * cheb_.n_pad < (int64_t(1) << 31)) { // M2P + P2L fused
+        // Whole source set: every leaf with a W list.  A partition: its own leaves (row sums = M2P of its targets; the
+        // column sums that fall on cells outside its subtree are never read) and the leaves outside whose W list holds
+        // a cell of its subtree (column sums = P2L into that cell; their row sums are dropped by the kernel's output
+        // window).  X = W^T (linear_tree.rs:388-392), so this covers the X lists of the partition's cells.
         std::vector<int32_t> wtb, wte;
         std::vector<int64_t> wr;
-        for (size_t j = 0; j < job_cells.size(); ++j) {
-            const int32_t c = job_cells[j];
+        const std::vector<int32_t> &cand = whole ? job_cells : src_leaves_;
+        for (size_t j = 0; j < cand.size(); ++j) {
+            const int32_t c = cand[j];
             if (t.w.ptr[c + 1] == t.w.ptr[c]) continue;
+            if (!whole) {
+                const bool own = t.pt_begin[c] >= pb && t.pt_begin[c] < pe;
+                bool feeds = false;
+                for (int64_t q = t.w.ptr[c]; q < t.w.ptr[c + 1] && !own && !feeds; ++q) feeds = (*part_active)[static_cast<size_t>(t.w.idx[q])] != 0;
+                if (!own && !feeds) continue;
+            }
             // jobs = (row chunk of the leaf) x (chunk of its W list): a nearly uniform tree has a few dozen coarse
             // leaves with long W lists (10M uniform points: 90 leaves of 250 points, about 100 W cells each), and whole-list
             // jobs would be a handful of long workgroups (0.96 ms for 0.6e9 kernel evaluations); both sums are atomic
@@ -2157,7 +2170,8 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     phase_begin();
     if (t.adaptive && wx) { // targets = all sources, one rhs: P2L and M2P share their kernel evaluations (X = W^T)
         launch_wx_sym(kernel_, cheb_, wx->n_wx_jobs, wx->wx_tb.p, wx->wx_te.p, wx->wx_range.p, d_w_idx_.p, d_centers_.p,
-                      d_lengths_.p, src_ptr_, d_w_sorted_.p, d_M_.p, d_L_.p, wx->out.p, stream_);
+                      d_lengths_.p, src_ptr_, d_w_sorted_.p, d_M_.p, d_L_.p, wx->out.p, wx->sym_off, static_cast<int>(wx->m),
+                      stream_);
     } else if (t.adaptive) {
         if (dp)
             launch_p2l(kernel_, cheb_, dp->n_x_jobs, dp->d_x_cells.p, dp->d_x_ptr.p, dp->d_x_runs.p, d_centers_.p,
@@ -2460,8 +2474,16 @@ int FmmTree::partition_finish_core(const double *d_coarse, hipStream_t comm_stre
                               static_cast<size_t>(cnt) * sizeof(double), hipMemcpyDeviceToDevice, stream_));
     phase_end(kPhM2M);
     const TargetSet &ts = part_targets_;
-    CHK(downward(k, &part_plan_));
-    CHK(leaf_pass_near(ts, k, false, stream_, 2)); // M2P (the outputs were zeroed and P2P ran in the first half)
+    static const bool wx_on = [] {
+        const char *e = std::getenv("BBFMM_WX_FUSED"); // 0: separate P2L and M2P kernels
+        const char *e2 = std::getenv("BBFMM_P2P_SYM");
+        return (!e || std::atoi(e) != 0) && (!e2 || std::atoi(e2) != 0);
+    }();
+    // one rhs: M2P of the owned targets and P2L into the subtree's cells share their kernel evaluations, as in the
+    // unpartitioned matvec (the outputs were zeroed and P2P ran in the first half; the fused pass adds to them)
+    const bool wx = wx_on && !deterministic_ && k == 1 && ts.sym && ts.n_wx_jobs > 0;
+    CHK(downward(k, &part_plan_, wx ? &ts : nullptr));
+    CHK(leaf_pass_near(ts, k, false, stream_, 2, wx)); // M2P unless the fused pass has done it
     CHK(leaf_pass_far(ts, k, false));
     *k_out = k;
     return BBFMM_OK;
@@ -3200,7 +3222,7 @@ int FmmTree::set_partition(int rank, int world) {
     CHK(dupload(&ts.w_begin, wb));
     CHK(dupload(&ts.w_end, we));
     CHK(dalloc(&ts.out, static_cast<size_t>(std::max(k_cap_, 1)) * std::max<int64_t>(ts.m, 1)));
-    CHK(build_sym_runs(&ts, jc, pb, pe));
+    CHK(build_sym_runs(&ts, jc, pb, pe, &part_plan_.active));
     have_part_ = true;
     return BBFMM_OK;
 }

@@ -236,7 +236,7 @@ class FmmTree {
     int build_target_set_host(const double *x, int64_t m, int64_t ldx, TargetSet *ts, int64_t *bad_point_index,
                               std::vector<int32_t> *leaves_out);
     int build_source_target_set();
-    int build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe);
+    int build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe, const std::vector<uint8_t> *part_active = nullptr);
     void free_target_set(TargetSet *ts);
     int upload_weights(const double *w, int64_t rows, int k, int64_t ldw);
     void phase_begin();
