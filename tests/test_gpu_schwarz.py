@@ -158,6 +158,32 @@ def test_reference_sized_domains_and_a_large_coarse_domain(kid):
         assert np.abs(z - zo).max() < 1e-8 * np.abs(zo).max(), f"level {lv}"
 
 
+@pytest.mark.parametrize("n", [16600, 20500, 24900, 33500])
+def test_large_coarse_domain_block_substitutions_at_block_edges(n):
+    """The one large coarse domain is solved in blocks of 1,024 columns with the diagonal blocks' inverses
+    (ddm_kernels.hip).  Coarse sizes 2,080 (a third block of 32 columns), 2,592 (mid-block), 3,136 and 4,224 (short fourth /
+    fifth blocks) against numpy's solve of the same domain."""
+    rng = np.random.default_rng(n)
+    dim, kid = 3, 0
+    pts = rng.random((n, dim))
+    prm = (1024, 0.5, 0.125, 6000)
+    st = InterpolantSettings(kid, dim)
+    ost = D.InterpolantSettings(kid, dim)
+    tree = F.FmmTree(pts, 5, F.KernelParams(F.KernelType(kid)), True, True)
+    pre = SchwarzPreconditioner(tree, pts, st, DDMParams(*prm))
+    levels = D.build_ddm_tree(pts, ost, D.DDMParams(*prm))
+    assert pre.num_levels == len(levels) == 2
+    m = len(levels[1].point_indices)
+    assert m > 2048, m
+    tr, sc = D.cheb_cube_scaling_factors(pts)
+    _, ortho = D.orthonormal_poly(pts, ost, tr, sc)
+    r = rng.standard_normal(n + ost.basis_size)
+    r[n:] = 0.0
+    z = pre.debug_level_solve(1, r, True)
+    zo = _oracle_level_solve(levels, 1, r, n, ost, ortho)
+    assert np.abs(z - zo).max() < 1e-8 * np.abs(zo).max(), (n, m)
+
+
 def test_large_coarse_domain_that_is_not_positive_definite_takes_the_pivoted_lu():
     """domain.rs:60-68 for the one large coarse domain (> 2,048 points, factorised and solved as launch sequences
     over the whole chip): a negative nugget makes Q^T A Q indefinite, the blocked Cholesky reports the failure and
