@@ -15,13 +15,15 @@ rank holds the whole tree and owns a contiguous Morton range of target leaves (s
 the total work is one matvec over all points); the owned potentials are exchanged with one RCCL
 all-gather over xGMI per step.
 
-Rank 0 prints ONE JSON line (see the prompt's contract) with `roofline`, `phase_roofline` and -- at N = 1 --
-`cpu_baseline`; at every world size the line carries `dense_rows_rel_err` (32 rows of the dense sum computed
-in plain torch on rank 0 after the exchange) and `configs`: at N = 1 the other single-GPU configurations of
-BASELINE.json (1M Spheroidal3 / multiquadric, the 10M thin-plate-spline p = 9 operator of config 3, 10M x 8 rhs),
-at N > 1 config 5 (40M Spheroidal3, partitioned over the same ranks), each with its own step time, rooflines and
-sampled dense-row error.  `--configs` adds opt-in entries: `solve` = config 3 end to end (10M thin-plate spline +
-linear drift, FGMRES 20 x 5 + Schwarz), `extensions` = the labelled extensions beyond the reference's arithmetic.
+Rank 0 prints ONE JSON line of under 4 KB (`compact_line`): the contract's keys, `roofline` of the dominant kernel,
+`cpu_baseline` (N = 1), `dense_rows_rel_err` (32 rows of the dense sum computed in plain torch on rank 0 after the
+exchange), `source_hash`, and per extra configuration only its step time, dense-row error and the dominant kernel's
+roofline kernel / bound / frac.  Everything else -- per-phase rooflines, instruction-issue figures, tree statistics,
+microbenchmarks, the prose of the CPU sample -- goes to `bench_detail.json` beside this file and to stderr.
+`configs`: at N = 1 the other single-GPU configurations of BASELINE.json (1M Spheroidal3 / multiquadric, the 10M
+thin-plate-spline p = 9 operator of config 3, 10M x 8 rhs), at N > 1 config 5 (40M Spheroidal3, partitioned over the
+same ranks).  `--configs` adds opt-in entries: `solve` = config 3 end to end (10M thin-plate spline + linear drift,
+FGMRES 20 x 5 + Schwarz), `extensions` = the labelled extensions beyond the reference's arithmetic.
 """
 from __future__ import annotations
 
@@ -75,13 +77,12 @@ EXTENSION_CONFIGS = [
 CONFIG5 = {"name": "config5_spheroidal3_40M", "points": 40_000_000, "kernel": "Spheroidal3Rbf", "order": 7, "nrhs": 1,
            "base_range": 0.1, "total_sill": 0.1}
 
-# measured at the full 10M points (scripts/cpu_port_full_size.py): round 3 49.1 s per matvec on 256 threads
-# (profiles/r03_cpu_port_full_10M.json), round 2 46.9 s (profiles/r02_cpu_port_full_10M.json)
-CPU_PORT_FULL_SIZE = {"value_full_size": 0.0204, "full_size_threads": 256, "full_size_from": "profiles/r03_cpu_port_full_10M.json"}
-
 # FP64 vector issue peak: 256 CUs x 4 SIMDs, one wave64 FP64 instruction per 4 cycles, at the 2.4 GHz AMD's
 # 78.6 TFLOP/s assumes (= 78.6e12 / 2 lane-FMAs per second)
 FP64_VALU_LANE_INSTR_PEAK = 78.6e12 / 2.0
+
+# the driver extracts the line from a bounded tail of stdout: round 3's 20.7 KB line came back unparsed
+LINE_LIMIT = 4096
 
 
 def parse():
@@ -96,7 +97,7 @@ def parse():
     ap.add_argument("--base-range", type=float, default=1.0)
     ap.add_argument("--total-sill", type=float, default=1.0)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
-    ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU sample (0: points/64)")
+    ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU sample (0: points/8)")
     ap.add_argument("--configs", default="auto",
                     help="comma list of: auto (with the default workload: the other single-GPU configs at N = 1, "
                          "config 5 = 40M Spheroidal3 at N > 1), off, solve (config 3 end to end: 10M thin-plate spline "
@@ -106,6 +107,8 @@ def parse():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"],
                     help="gloo: CPU-staged exchange; ranks may then share a GPU (LOCAL_RANK modulo the device "
                          "count) -- for exercising the N > 1 path on a one-GPU box, never a scaling number")
+    ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the full record goes (the stdout line is the compact one)")
     return ap.parse_args()
 
 
@@ -224,85 +227,60 @@ def dense_rows_torch(torch, kernel, br, sill, x, pts, w):
 
 
 def cpu_baseline(args, kernel_id):
-    """Times the CPU restatement of the reference algorithm (oracle/, kind "port": C + OpenMP
-    passes over a Python-built tree) on a bounded sample: a cloud 64x smaller than the workload,
-    which has the same leaf occupancy and list structure two levels shallower; the BBFMM matvec
-    is O(N), so the rate is scaled by the point ratio.  The sample is run at the host's full thread
-    count and at a half and a quarter of it (small problems do not always like every hardware thread);
-    the fastest is reported with its thread count.  `value_full_size` is the same code measured once at the
-    full 10M points (49.1 s per matvec on 256 threads): the scaled sample flatters the CPU (caches), which only
-    makes `value` conservative for the GPU."""
+    """Times the CPU restatement of the reference algorithm (oracle/, kind "port": C + OpenMP passes over a
+    Python-built tree) in THIS run, on a bounded sample: a cloud 8x smaller than the workload (10M -> 1.25M points:
+    the same leaf occupancy, one level shallower); the BBFMM matvec is O(N), so the rate is scaled by the point
+    ratio.  ONE measured number: `value`.  The thread count is chosen first on a 64x smaller cloud (full / half /
+    quarter of the host's threads; small problems do not always like every hardware thread), the sample then runs at
+    that count: one warm-up, then matvecs until two are done and about 15 s are spent (at most five), median.  The
+    oracle's Python tree build is timed separately (`tree_build_s`; not part of a matvec).  The port's M2L is plain
+    per-pair loops where the reference calls faer GEMMs (bbfmm.rs:953-960): a baseline only, never the target.
+    Returns (entry for the line, detail for bench_detail.json)."""
     from oracle import bbfmm_oracle as O
-    n_cpu = args.cpu_points or max(20000, args.points // 64)
-    rng = np.random.default_rng(42)
-    pts = rng.random((n_cpu, 3))
-    w = np.random.default_rng(43).random((n_cpu, args.nrhs))
-    tree = O.FmmTree(pts, args.order, kernel_id, True, True, base_range=args.base_range,
-                     total_sill=args.total_sill)
     hw = int(O.lib().oracle_num_threads())
-    best = None
-    for threads in sorted({hw, max(hw // 2, 1), max(hw // 4, 1)}, reverse=True):
-        O.lib().oracle_set_num_threads(threads)
-        tree.set_weights(w)                      # warm-up
-        tree.evaluate(w, pts)
-        times = []
-        t_end = time.time() + 8.0
-        while len(times) < 5 and (len(times) < 2 or time.time() < t_end):
-            t0 = time.time()
-            tree.set_weights(w)
+
+    def sample(n, threads_list, budget_s, max_reps):
+        pts = np.random.default_rng(42).random((n, 3))
+        w = np.random.default_rng(43).random((n, args.nrhs))
+        t0 = time.time()
+        tree = O.FmmTree(pts, args.order, kernel_id, True, True, base_range=args.base_range, total_sill=args.total_sill)
+        t_tree = time.time() - t0
+        res = []
+        for threads in threads_list:
+            O.lib().oracle_set_num_threads(threads)
+            tree.set_weights(w)                      # warm-up
             tree.evaluate(w, pts)
-            times.append(time.time() - t0)
-        t = float(np.median(times))
-        if best is None or t < best[0]:
-            best = (t, threads, len(times))
-    O.lib().oracle_set_num_threads(hw)
-    t, threads, reps = best
+            times = []
+            t_end = time.time() + budget_s
+            while len(times) < max_reps and (len(times) < 2 or time.time() < t_end):
+                t0 = time.time()
+                tree.set_weights(w)
+                tree.evaluate(w, pts)
+                times.append(time.time() - t0)
+            res.append((float(np.median(times)), threads, len(times)))
+        O.lib().oracle_set_num_threads(hw)
+        return res, t_tree
+
+    n_pick = max(20000, args.points // 64)
+    n_cpu = args.cpu_points or max(20000, args.points // 8)
+    picks, _ = sample(n_pick, sorted({hw, max(hw // 2, 1), max(hw // 4, 1)}, reverse=True), 2.0, 3)
+    threads = min(picks)[1]
+    res, t_tree = sample(n_cpu, [threads], 15.0, 5)
+    t, threads, reps = res[0]
     scale = n_cpu / float(args.points)
-    full = dict(CPU_PORT_FULL_SIZE) if (args.points, args.kernel, args.order, args.nrhs) == (10_000_000, "LinearRbf", 7, 1) else {}
-    return {
-        "value": (1.0 / t) * scale,
-        "unit": "matvecs/s",
-        "cores": threads,
-        "kind": "port",
-        **full,
-        "sample": (f"CPU restatement of the reference algorithm (not the Rust binary): median of "
-                   f"{reps} matvecs on {n_cpu} uniform points ({t:.3f} s each on {threads} of {hw} threads, the "
-                   f"fastest of full / half / quarter thread counts; same kernel/order/nrhs, same leaf occupancy as "
-                   f"the {args.points}-point workload), rate scaled by {n_cpu}/{args.points} (O(N) algorithm)"),
+    entry = {
+        "value": (1.0 / t) * scale, "unit": "matvecs/s", "cores": threads, "kind": "port",
+        "sample": (f"median of {reps} matvecs on {n_cpu} uniform points ({t:.2f} s each, {threads} of {hw} threads), "
+                   f"rate x {n_cpu}/{args.points}; naive-loop port of the algorithm, not the Rust binary"),
     }
-
-
-def roofline_of(stats, K, per_launch, world, launches=None):
-    """Roofline entry of the dominant kernel (largest time per matvec among the M2L stages and the pair phases);
-    algorithmic work as DESIGN.md section 5 defines it.  `per_launch` holds the time of ALL launches of a phase in one
-    matvec (one launch when the M2L intermediate is a single batch and all right-hand sides go in one pass -- the
-    headline; otherwise `launches_per_step` of them, and work and time are both the sums over those launches)."""
-    m2l_stage_flops = stats.m2l_flops_k1 * K / 2.0          # each stage does 2*n*r per pair
-    p2p_tile_bytes = stats.p2p_tile_bytes_k1 + (K - 1) * 8 * (stats.p2p_tile_bytes_k1 // 32)
-    kern = {
-        "M2L_stage1": {"bound": "mfma", "work": m2l_stage_flops, "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "scale": 1e-12},
-        "M2L_stage2": {"bound": "mfma", "work": m2l_stage_flops, "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "scale": 1e-12},
-        "P2P": {"bound": "hbm", "work": float(p2p_tile_bytes), "unit": "GB/s", "peak": HBM_PEAK_GBPS, "scale": 1e-9},
-        # the adaptive-list kernels (M2P + P2L; fused into the P2L phase for one rhs): FP64-VALU bound like P2P,
-        # quoted against HBM with their tile traffic (points of the leaf + nodes, multipoles and locals of the W cell)
-        "P2L": {"bound": "hbm", "work": float(stats.wx_tile_bytes_k1 * K), "unit": "GB/s", "peak": HBM_PEAK_GBPS, "scale": 1e-9},
+    detail = {
+        **entry, "seconds_per_matvec_on_sample": t, "sample_points": n_cpu, "host_threads": hw, "oracle_tree_build_s": t_tree,
+        "thread_pick": [{"points": n_pick, "threads": th, "seconds_per_matvec": tt} for tt, th, _ in picks],
+        "note": ("CPU restatement of the reference algorithm (oracle/passes.c, C + OpenMP over the oracle's Python-built "
+                 "tree), same kernel / order / nrhs and the same leaf occupancy as the workload; its M2L is per-pair loops "
+                 "where the reference calls faer GEMMs (bbfmm.rs:953-960), so it understates the Rust binary: baseline only"),
     }
-    dominant = max(kern, key=lambda k: per_launch[k])
-    kd = kern[dominant]
-    dur = per_launch[dominant] * 1e-3
-    # N > 1: rank 0's launch against ITS share of the job's algorithmic work, taken as 1 / world (the partition balances
-    # a work proxy; the halo a rank computes beyond its share is not algorithmic work and lowers the figure)
-    work = kd["work"] / world
-    achieved = work / dur * kd["scale"] if dur > 0 else None
-    out = {
-        "kernel": dominant, "bound": kd["bound"], "achieved": achieved, "peak": kd["peak"],
-        "unit": kd["unit"], "frac": (achieved / kd["peak"]) if achieved else None,
-        "traffic": None, "avg_launch_ms": per_launch[dominant], "algorithmic_work_per_launch": work,
-        "launches_per_step": (launches or {}).get(dominant, 1),
-    }
-    if world > 1:
-        out["work_share"] = "rank 0's launch; algorithmic work = the job's / %d" % world
-    return dominant, out
+    return entry, detail
 
 
 # Arithmetic of one kernel evaluation in the reference's pair loops (bbfmm.rs:1162-1251 with distance_sq
@@ -311,10 +289,28 @@ def roofline_of(stats, K, per_launch, world, launches=None):
 PAIR_FLOPS = {"LinearRbf": 3 * 3 - 1 + 1 + 1 + 2, "ThinPlateSplineRbf": 3 * 3 - 1 + 1 + 3 + 2, "CubicRbf": 3 * 3 - 1 + 1 + 2 + 2,
               "Spheroidal3Rbf": 3 * 3 - 1 + 1 + 6 + 2, "MultiquadricExt": 3 * 3 - 1 + 1 + 2 + 2}
 
+# right-hand sides the unordered-pair kernels (near field; fused M2P + P2L) take in one pass: beyond these the
+# ordered-pair kernels run (fmm_tree.cpp)
+SYM_P2P_MAX_RHS = 1
+SYM_WX_MAX_RHS = 1
+
+
+def pair_probe_hash() -> str:
+    """The inlined arithmetic of every pair kernel lives in csrc/kernels.hpp; scripts/pair_probe.hip wraps one
+    evaluation of it.  The ISA counts are stamped with the hash of these two files only."""
+    h = hashlib.sha256()
+    for f in (os.path.join(ROOT, "ferreus_rbf_rs_amd", "csrc", "kernels.hpp"), os.path.join(ROOT, "scripts", "pair_probe.hip")):
+        try:
+            with open(f, "rb") as fh:
+                h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+        except OSError:
+            h.update(b"missing")
+    return h.hexdigest()[:16]
+
 
 def committed_pair_instructions():
     """FP64 VALU instructions per kernel evaluation of the pair kernels, counted from the ISA of these very sources
-    (scripts/pair_instruction_counts.py -> profiles/r*_pair_instruction_counts.json, stamped with the source hash)."""
+    (scripts/pair_instruction_counts.py -> profiles/r*_pair_instruction_counts.json, stamped with `pair_probe_hash`)."""
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pair_instruction_counts.json"))):
         try:
@@ -322,13 +318,83 @@ def committed_pair_instructions():
                 j = json.load(fh)
         except (OSError, ValueError):
             continue
-        if j.get("source_hash") == source_hash():
+        if j.get("pair_probe_hash") == pair_probe_hash():
             best = j
             best["file"] = os.path.relpath(f, ROOT)
     return best
 
 
-def phase_roofline(stats, N, K, order, kernel, per_step_ms, sym_pairs):
+def pair_issue(stats, N, K, kernel, phase):
+    """(kernel evaluations executed, FP64 VALU instructions per evaluation, instruction-count file) of a pair phase
+    -- P2P, P2L (fused with M2P when the unordered kernel runs), M2P -- or None.  Unordered kernels evaluate every
+    pair once and feed the row sum and the column sum of each right-hand side from it (2K multiply-adds); ordered
+    kernels feed the K row sums (K multiply-adds).  The count of the probe is for one rhs, both sums (2)."""
+    instr = committed_pair_instructions()
+    if not instr or kernel not in instr.get("kernels", {}):
+        return None
+    sym = (phase == "P2P" and K <= SYM_P2P_MAX_RHS) or (phase == "P2L" and K <= SYM_WX_MAX_RHS)
+    key = {"P2P": "p2p_sym" if sym else "p2p", "P2L": "wx_sym" if sym else "p2l", "M2P": "m2p"}[phase]
+    ipp = instr["kernels"][kernel][key]["fp64_valu_per_pair"]
+    if sym:
+        evals = (stats.p2p_pairs + N) / 2.0 if phase == "P2P" else float(stats.wx_pairs)
+        per_eval = ipp - 2 + 2 * K
+    else:
+        evals = float(stats.p2p_pairs) if phase == "P2P" else float(stats.wx_pairs)
+        per_eval = ipp - 2 + K
+    return evals, per_eval, instr["file"]
+
+
+def roofline_of(stats, N, K, kernel, per_launch, world, launches=None, valu_lane_rate=None):
+    """Roofline entry of the dominant kernel (largest time per matvec among the M2L stages and the pair phases);
+    algorithmic work as DESIGN.md section 5 defines it.  `per_launch` holds the time of ALL launches of a phase in one
+    matvec (one launch when the M2L intermediate is a single batch and all right-hand sides go in one pass -- the
+    headline; otherwise `launches_per_step` of them, and work and time are both the sums over those launches).
+
+    Rule: a phase is quoted against the roof that binds it.  The M2L stages against the FP64
+    matrix peak (78.6 TFLOP/s) with their algorithmic flops.  The pair phases (P2P; P2L = M2P + P2L) are FP64
+    vector-instruction bound: `achieved` = kernel evaluations executed x FP64 VALU instructions per evaluation (ISA
+    count) per second, `peak` = the FP64 lane-instruction rate the same device sustained in this run's FMA
+    microbenchmark (nominal 78.6e12 / 2 if it was not run); the HBM figure the north-star asks for -- tile bytes
+    against 8 TB/s -- stays beside it as `frac_hbm`."""
+    m2l_stage_flops = stats.m2l_flops_k1 * K / 2.0          # each stage does 2*n*r per pair
+    p2p_tile_bytes = stats.p2p_tile_bytes_k1 + (K - 1) * 8 * (stats.p2p_tile_bytes_k1 // 32)
+    kern = {
+        "M2L_stage1": {"bound": "mfma", "work": m2l_stage_flops, "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "scale": 1e-12},
+        "M2L_stage2": {"bound": "mfma", "work": m2l_stage_flops, "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "scale": 1e-12},
+        "P2P": {"bound": "fp64_valu", "bytes": float(p2p_tile_bytes)},
+        "P2L": {"bound": "fp64_valu", "bytes": float(stats.wx_tile_bytes_k1 * K)},
+    }
+    dominant = max(kern, key=lambda k: per_launch[k])
+    kd = kern[dominant]
+    dur = per_launch[dominant] * 1e-3
+    extra = {}
+    if kd["bound"] == "fp64_valu":
+        pi = pair_issue(stats, N, K, kernel, dominant)
+        peak = valu_lane_rate or FP64_VALU_LANE_INSTR_PEAK
+        if pi:
+            work, unit, scale = pi[0] * pi[1], "Tinstr/s", 1e-12
+            extra = {"fp64_valu_instr_per_evaluation": pi[1], "counted_from": pi[2]}
+        else:   # no ISA count for these sources: the reference's flop count per evaluation against the FP64 rate
+            work, unit, scale = (stats.p2p_pairs if dominant == "P2P" else stats.wx_pairs) * PAIR_FLOPS.get(kernel, 14) * K / 2.0, "Tinstr/s", 1e-12
+        extra["peak_is"] = "measured v_fma_f64 lane rate of this run" if valu_lane_rate else "nominal 78.6e12 / 2"
+        extra["frac_hbm"] = (kd["bytes"] / world / dur * 1e-9 / HBM_PEAK_GBPS) if dur > 0 else None
+        kd = {"bound": "fp64_valu", "work": work, "unit": unit, "peak": peak * 1e-12, "scale": scale}
+    # N > 1: rank 0's launch against ITS share of the job's algorithmic work, taken as 1 / world (the partition balances
+    # a work proxy; the halo a rank computes beyond its share is not algorithmic work and lowers the figure)
+    work = kd["work"] / world
+    achieved = work / dur * kd["scale"] if dur > 0 else None
+    out = {
+        "kernel": dominant, "bound": kd["bound"], "achieved": achieved, "peak": kd["peak"],
+        "unit": kd["unit"], "frac": (achieved / kd["peak"]) if achieved else None,
+        "traffic": None, "avg_launch_ms": per_launch[dominant], "algorithmic_work_per_launch": work,
+        "launches_per_step": (launches or {}).get(dominant, 1), **extra,
+    }
+    if world > 1:
+        out["work_share"] = "rank 0's launch; algorithmic work = the job's / %d" % world
+    return dominant, out
+
+
+def phase_roofline(stats, N, K, order, kernel, per_step_ms, valu_lane_rate=None):
     """per phase the algorithmic bytes and flops of one matvec, the achieved GB/s and TFLOP/s, the
     fractions of the HBM (8 TB/s) and FP64 (78.6 TFLOP/s) peaks, and which of the two binds the phase (the larger
     of bytes / peak-bandwidth and flops / peak-rate).  Bytes: what the phase has to move once (tile traffic for the
@@ -352,7 +418,6 @@ def phase_roofline(stats, N, K, order, kernel, per_step_ms, sym_pairs):
         "L2P": (N * (8.0 * d + 8 * K) + leaves * n * 8.0 * K, (2.0 + d) * N * n * K),
         "scatter": (N * K * 16.0 + N * 4.0, 0.0),
     }
-    instr = committed_pair_instructions()
     out = {}
     for ph, (nbytes, flops) in work.items():
         ms = per_step_ms.get(ph, 0.0)
@@ -360,7 +425,7 @@ def phase_roofline(stats, N, K, order, kernel, per_step_ms, sym_pairs):
             continue
         if ph in ("P2L", "M2P") and stats.n_w == 0:
             continue
-        if ph == "M2P" and sym_pairs and K == 1:
+        if ph == "M2P" and K <= SYM_WX_MAX_RHS:
             continue                                     # fused with P2L into one kernel (timed under P2L)
         sec = ms * 1e-3
         t_hbm, t_fp = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (FP64_MFMA_PEAK_TFLOPS * 1e12)
@@ -369,19 +434,14 @@ def phase_roofline(stats, N, K, order, kernel, per_step_ms, sym_pairs):
              "bound": "hbm" if t_hbm >= t_fp else ("mfma" if ph.startswith("M2L") else "fp64_valu")}
         # FP64 instruction issue of the pair kernels: kernel evaluations actually executed (every unordered pair once
         # in the symmetric kernels) x FP64 VALU instructions per evaluation (ISA count) against the issue peak
-        key = {"P2P": "p2p_sym" if sym_pairs else "p2p", "P2L": "wx_sym" if (sym_pairs and K == 1) else "p2l",
-               "M2P": "m2p"}.get(ph)
-        if key and instr and key in instr.get("kernels", {}).get(kernel, {}):
-            ipp = instr["kernels"][kernel][key]["fp64_valu_per_pair"]     # distance + phi + the row and the column FMA
-            if key.endswith("_sym"):                     # one rhs, every pair once, both sums from one evaluation
-                evals = (stats.p2p_pairs + N) / 2.0 if ph == "P2P" else float(stats.wx_pairs)
-                per_eval = ipp
-            else:                                        # ordered pairs: one evaluation serves the K row sums
-                evals = float(stats.p2p_pairs) if ph == "P2P" else float(stats.wx_pairs)
-                per_eval = ipp - 2 + K
+        pi = pair_issue(stats, N, K, kernel, ph) if ph in ("P2P", "P2L", "M2P") else None
+        if pi:
+            evals, per_eval, src = pi
             e["valu_issue"] = {"kernel_evaluations": evals, "fp64_valu_instr_per_evaluation": per_eval,
                                "achieved_lane_instr_per_s": evals * per_eval / sec, "peak_lane_instr_per_s": FP64_VALU_LANE_INSTR_PEAK,
-                               "frac": evals * per_eval / sec / FP64_VALU_LANE_INSTR_PEAK, "counted_from": instr["file"]}
+                               "frac": evals * per_eval / sec / FP64_VALU_LANE_INSTR_PEAK, "counted_from": src}
+            if valu_lane_rate:
+                e["valu_issue"]["frac_of_measured_fma_rate"] = evals * per_eval / sec / valu_lane_rate
         out[ph] = e
     return out
 
@@ -434,7 +494,7 @@ def dense_rows_err(torch, dev, cfg_kernel, br, sill, pts, w, out, rows=32):
     return float((out[:, idx].T - yd).abs().max() / yd.abs().max())
 
 
-def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None):
+def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None, valu_lane_rate=None):
     """One configuration beside the headline: step time, phases, rooflines, sampled dense rows.  world > 1: the
     same partitioned step as the headline (every rank calls this; rank 0 reports)."""
     N, K = cfg["points"], cfg["nrhs"]
@@ -466,7 +526,8 @@ def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None):
         return None
     # a phase interval brackets all launches of the phase (rhs chunks, column chunks): per interval = per pass
     per_step_total = {k: phases[k] / steps for k in phases}
-    _, roof = roofline_of(stats, K, per_step_total, world, {k: counts[k] // max(steps, 1) for k in counts})
+    _, roof = roofline_of(stats, N, K, cfg["kernel"], per_step_total, world, {k: counts[k] // max(steps, 1) for k in counts},
+                          valu_lane_rate)
     err = dense_rows_err(torch, dev, cfg["kernel"], cfg["base_range"], cfg["total_sill"], pts, w, out)
     ext = {}
     if cfg.get("direct_small_w_leaves"):
@@ -486,8 +547,68 @@ def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None):
                  "n_w": stats.n_w, "p2p_pairs": stats.p2p_pairs, "build_s": t_build},
     }
     if world == 1 and not ext:
-        res["phase_roofline"] = phase_roofline(stats, N, K, cfg["order"], cfg["kernel"], per_step_total, sym_pairs=K == 1)
+        res["phase_roofline"] = phase_roofline(stats, N, K, cfg["order"], cfg["kernel"], per_step_total, valu_lane_rate)
     return res
+
+
+def _sig(x, digits=5):
+    """Floats of the printed line at five significant digits (the detail file keeps full precision)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def compact_line(detail: dict) -> dict:
+    """The ONE stdout line: the driver has to parse it, so it stays under 4 KB whatever the run carried.  Keeps the
+    contract's keys, the dominant kernel's roofline, the CPU baseline, the dense-row check and the source hash; of
+    every extra configuration only its step time, dense-row error and roofline kernel / bound / frac (config 3's
+    solve: iterations, seconds, final residual, converged).  The full record is `detail_file`."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    line = {k: _sig(detail[k], 7) for k in keep if k in detail}
+    cfg = detail.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "points", "kernel", "order", "nrhs", "parallelism") if k in cfg}
+    roof = detail.get("roofline") or {}
+    line["roofline"] = {k: _sig(roof.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                         "avg_launch_ms", "mfma_util_pct")}
+    if roof.get("frac_hbm") is not None:
+        line["roofline"]["frac_hbm"] = _sig(roof["frac_hbm"])
+    p2p = (detail.get("phase_roofline") or {}).get("P2P")
+    if p2p:          # the north-star's near-field figure, whatever the dominant kernel is
+        vi = p2p.get("valu_issue", {})
+        line["p2p"] = {"ms": _sig(p2p["ms"]), "frac_hbm": _sig(p2p["frac_hbm"]),
+                       "frac_fp64_valu": _sig(vi.get("frac_of_measured_fma_rate", vi.get("frac")))}
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample")}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:200]
+    line["dense_rows_rel_err"] = _sig(detail.get("dense_rows_rel_err"))
+    if detail.get("partition_covers_every_row_once") is not None:
+        line["partition_covers_every_row_once"] = detail["partition_covers_every_row_once"]
+    line["source_hash"] = detail.get("source_hash")
+    cfgs = {}
+    for name, c in (detail.get("configs") or {}).items():
+        if not isinstance(c, dict):
+            continue
+        if "error" in c:
+            cfgs[name] = {"error": str(c["error"])[:120]}
+        elif "roofline" in c:
+            r = c["roofline"]
+            cfgs[name] = {"ms_per_step": _sig(c.get("ms_per_step")), "dense_rows_rel_err": _sig(c.get("dense_rows_rel_err")),
+                          "roofline": {"kernel": r.get("kernel"), "bound": r.get("bound"), "frac": _sig(r.get("frac"))}}
+        else:                                            # config 3 end to end
+            cfgs[name] = {}
+            for label in ("for_points", "reference_defaults"):
+                e = c.get(label)
+                if e:
+                    hist = e.get("residual_history") or [None]
+                    cfgs[name][label] = {"iterations": e.get("iterations"), "solve_s": _sig(e.get("solve_s")),
+                                         "setup_s": _sig(e.get("setup_s")), "converged": e.get("converged"),
+                                         "stagnated": e.get("stagnated"), "final_residual": hist[-1]}
+    if cfgs:
+        line["configs"] = cfgs
+    line["detail_file"] = detail.get("detail_file", "bench_detail.json")
+    return line
 
 
 def run_config3_solve(F, points=10_000_000):
@@ -529,6 +650,29 @@ def run_config3_solve(F, points=10_000_000):
                       "residual_history": [float("%.3e" % r) for r in res], "max_fit_error_on_sample": fit}
         del pre, op
     return out
+
+
+def write_outputs(detail, stdout_fd, path=None):
+    """The full record to `bench_detail.json` beside this file (best effort: a read-only tree only loses the file) and to
+    stderr; the compact line -- one line, under 4 KB -- to the real stdout."""
+    path = path or os.path.join(ROOT, "bench_detail.json")
+    detail["detail_file"] = os.path.relpath(path, ROOT) if path.startswith(ROOT + os.sep) else path
+    text = json.dumps(detail, indent=1)
+    try:
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        detail["detail_file"] = f"stderr only ({e.__class__.__name__})"
+    sys.stderr.write("[bench detail] " + json.dumps(detail) + "\n")
+    sys.stderr.flush()
+    line = compact_line(detail)
+    out = json.dumps(line)
+    for drop in ("configs", "p2p"):          # never reached with the configurations above; a line must stay parseable
+        if len(out) >= LINE_LIMIT:
+            line.pop(drop, None)
+            out = json.dumps(line)
+    sys.stdout.flush()
+    os.write(stdout_fd, (out + "\n").encode())
 
 
 def main():
@@ -600,12 +744,27 @@ def main():
     default_workload = (N, args.kernel, args.order, K) == (10_000_000, "LinearRbf", 7, 1)
 
     line = None
+    valu_lane_rate = None
     if rank == 0:
         per_launch = {k: phases[k] / args.steps for k in phases}
         n = stats.n_nodes
         C = stats.n_cells
+        micro = {}
+        try:  # what the vector pipe sustains on this device (the pair kernels' issue roofline) and at which clock
+            vtf, vmhz = F.fp64_valu_selftest()
+            valu_lane_rate = vtf * 1e12 / 2.0
+            micro["fp64_valu_microbench"] = {"tflops": vtf, "clock_mhz": vmhz, "lane_instr_per_s": valu_lane_rate}
+        except Exception:  # noqa: BLE001
+            micro["fp64_valu_microbench"] = None
+        if world == 1:
+            try:
+                tf, errs = F.mfma_f64_selftest()
+                micro["fp64_mfma_microbench_tflops"] = tf
+            except Exception:  # noqa: BLE001
+                micro["fp64_mfma_microbench_tflops"] = None
         # algorithmic work per launch (this rank; at N=1 the whole matvec) -- DESIGN.md section 5
-        dominant, roofline = roofline_of(stats, K, per_launch, world, {k: counts[k] // max(args.steps, 1) for k in counts})
+        dominant, roofline = roofline_of(stats, N, K, args.kernel, per_launch, world,
+                                         {k: counts[k] // max(args.steps, 1) for k in counts}, valu_lane_rate)
         # HBM-side bytes and MFMA-pipe utilisation of the dominant kernel from the committed PMC passes of this
         # same command on these same sources (FETCH_SIZE x2 (gfx950 correction for 16-B/lane reads) +
         # WRITE_SIZE, KiB -> bytes, per launch; derived metrics MfmaUtil, MfmaFlopsF64); null otherwise.
@@ -627,9 +786,9 @@ def main():
                                    f"{K} rhs, adaptive sparse tree, ACA eps=1e-{args.order}, "
                                    "set_weights + evaluate at the sources",
                        "points": N, "kernel": args.kernel, "order": args.order, "nrhs": K,
-                       "parallelism": (f"target-subtree partition x{world}: own-subtree upward pass + all-reduce of "
-                                       f"{pm.count * 8 * K / 1e6:.1f} MB of coarse multipoles, owned potentials all-gathered, "
-                                       f"over {args.exchange}") if world > 1 else "single GPU"},
+                       "parallelism": (f"target-subtree partition x{world}: all-reduce of {pm.count * 8 * K / 1e6:.1f} MB "
+                                       f"coarse multipoles + all-gather of owned potentials, {args.exchange}")
+                       if world > 1 else "single GPU"},
             "roofline": roofline,
             "achieved_hbm_gbps_compulsory": compulsory_bytes / (elapsed / args.steps) * 1e-9,
             "phase_ms_per_step": {k: phases[k] / args.steps for k in phases},
@@ -637,28 +796,15 @@ def main():
                      "p2p_pairs": stats.p2p_pairs, "m2l_flops_k1": stats.m2l_flops_k1,
                      "build_s": t_build},
             "source_hash": source_hash(),
+            "partition_covers_every_row_once": True if world > 1 else None,     # asserted above on every rank
+            **micro,
         }
         if world == 1:
             line["phase_roofline"] = phase_roofline(stats, N, K, args.order, args.kernel, line["phase_ms_per_step"],
-                                                    sym_pairs=K == 1)
+                                                    valu_lane_rate)
         # the result every rank now holds, against 32 rows of the dense sum (plain torch on rank 0) -- at every world size
         line["dense_rows_rel_err"] = dense_rows_err(torch, dev, args.kernel, args.base_range, args.total_sill, pts, w, out)
         line["dense_rows"] = 32
-        if world == 1:
-            try:
-                tf, errs = F.mfma_f64_selftest()
-                line["fp64_mfma_microbench_tflops"] = tf
-            except Exception:  # noqa: BLE001
-                line["fp64_mfma_microbench_tflops"] = None
-            try:  # what the vector pipe sustains on this device (the pair kernels' issue roofline) and at which clock
-                vtf, vmhz = F.fp64_valu_selftest()
-                line["fp64_valu_microbench"] = {"tflops": vtf, "clock_mhz": vmhz,
-                                                "lane_instr_per_s": vtf * 1e12 / 2.0}
-                for e in line.get("phase_roofline", {}).values():
-                    if "valu_issue" in e:
-                        e["valu_issue"]["frac_of_measured_fma_rate"] = e["valu_issue"]["achieved_lane_instr_per_s"] / (vtf * 1e12 / 2.0)
-            except Exception:  # noqa: BLE001
-                line["fp64_valu_microbench"] = None
 
     extra = {}
     if world == 1 and default_workload and want & {"auto", "extensions", "solve"}:
@@ -673,7 +819,7 @@ def main():
                 tree = w = out = stream = None
                 torch.cuda.empty_cache()
             try:
-                extra[cfg["name"]] = run_config(torch, dist, F, dev, cfg, 1, 0, args.exchange, reuse)
+                extra[cfg["name"]] = run_config(torch, dist, F, dev, cfg, 1, 0, args.exchange, reuse, valu_lane_rate)
             except Exception as e:  # noqa: BLE001
                 extra[cfg["name"]] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
@@ -693,7 +839,7 @@ def main():
         torch.cuda.empty_cache()
         cfg = dict(CONFIG5, points=args.config5_points)
         try:
-            res = run_config(torch, dist, F, dev, cfg, world, rank, args.exchange)
+            res = run_config(torch, dist, F, dev, cfg, world, rank, args.exchange, None, valu_lane_rate)
         except Exception as e:  # noqa: BLE001
             res = {"error": f"{type(e).__name__}: {e}"}
         if rank == 0:
@@ -702,9 +848,12 @@ def main():
         if extra:
             line["configs"] = extra
         if world == 1 and args.cpu_baseline != "off":
-            line["cpu_baseline"] = cpu_baseline(args, kernel_id)
-        sys.stdout.flush()
-        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+            try:
+                line["cpu_baseline"], line["cpu_baseline_detail"] = cpu_baseline(args, kernel_id)
+            except Exception as e:  # noqa: BLE001  (a missing C compiler on the box must not cost the GPU line)
+                line["cpu_baseline"] = {"value": None, "unit": "matvecs/s", "cores": None, "kind": "port",
+                                        "sample": f"not measured: {type(e).__name__}: {e}"}
+        write_outputs(line, real_stdout, args.detail_file)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

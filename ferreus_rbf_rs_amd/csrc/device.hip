@@ -1670,10 +1670,17 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
 static Xyz make_xyz(const double *const *p) { return Xyz{p[0], p[1], p[2]}; }
 
 // Dynamic LDS above the 64 KB default needs the function attribute, per device (3-D orders 14-16 of the general
-// M2M / L2L kernels).  Called from launchers only; cheap when nothing is to do.
-static void allow_large_dynamic_lds(const void *fn, size_t bytes) {
-    if (bytes <= 64 * 1024) return;
-    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+// M2M / L2L kernels): set once per (kernel, device) -- `done` is that kernel's flag word, as in m2l_gemm_launch --
+// and a failure is returned to the caller instead of surfacing later as a generic launch error.
+static hipError_t allow_large_dynamic_lds(const void *fn, size_t bytes, std::atomic<uint64_t> *done) {
+    if (bytes <= 64 * 1024) return hipSuccess;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool cached = dev >= 0 && dev < 256;
+    if (cached && ((done[dev >> 6].load(std::memory_order_acquire) >> (dev & 63)) & 1)) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess && cached) done[dev >> 6].fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
+    return e;
 }
 
 template <int P, int D>
@@ -1716,14 +1723,14 @@ void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w
 #undef P2M_CASE
 }
 
-void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents, const int64_t *child_ptr,
-                const int32_t *child_idx, const int32_t *octant, double *M, hipStream_t s) {
-    if (n_parents == 0) return;
+int launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents, const int64_t *child_ptr,
+               const int32_t *child_idx, const int32_t *octant, double *M, hipStream_t s) {
+    if (n_parents == 0) return 0;
 #define M2M3_CASE(PP)                                                                                              \
     case PP:                                                                                                       \
         hipLaunchKernelGGL((m2m3_kernel<PP>), dim3(n_parents), dim3(512), 0, s, ch.dev, K, C, parents, child_ptr,  \
                            child_idx, octant, M);                                                                  \
-        return;
+        return 0;
     if (ch.d == 3) switch (ch.p) { // wave-per-child register kernels (8 x P^3 doubles of LDS)
             M2M3_CASE(2) M2M3_CASE(3) M2M3_CASE(4) M2M3_CASE(5) M2M3_CASE(6) M2M3_CASE(7) M2M3_CASE(8) M2M3_CASE(9)
             M2M3_CASE(10)
@@ -1731,19 +1738,21 @@ void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int
         }
 #undef M2M3_CASE
     const size_t lds = sizeof(double) * (3 * (size_t)ch.n + 2 * ch.p * ch.p);
-    allow_large_dynamic_lds(reinterpret_cast<const void *>(&m2m_kernel), lds);
+    static std::atomic<uint64_t> attr_set[4] = {{0}, {0}, {0}, {0}};
+    if (const hipError_t e = allow_large_dynamic_lds(reinterpret_cast<const void *>(&m2m_kernel), lds, attr_set)) return static_cast<int>(e);
     hipLaunchKernelGGL(m2m_kernel, dim3(n_parents), dim3(256), lds, s, ch.dev, K, C, parents, child_ptr, child_idx,
                        octant, M);
+    return 0;
 }
 
-void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_cells, const int32_t *parent,
-                const int32_t *octant, const uint8_t *active, double *L, hipStream_t s) {
-    if (n_cells == 0) return;
+int launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_cells, const int32_t *parent,
+               const int32_t *octant, const uint8_t *active, double *L, hipStream_t s) {
+    if (n_cells == 0) return 0;
 #define L2L3_CASE(PP)                                                                                              \
     case PP:                                                                                                       \
         hipLaunchKernelGGL((l2l3_kernel<PP>), dim3((n_cells + XFER_WAVES - 1) / XFER_WAVES), dim3(64 * XFER_WAVES),  \
                            0, s, ch.dev, K, C, cells, n_cells, parent, octant, active, L);                         \
-        return;
+        return 0;
     if (ch.d == 3) switch (ch.p) {
             L2L3_CASE(2) L2L3_CASE(3) L2L3_CASE(4) L2L3_CASE(5) L2L3_CASE(6) L2L3_CASE(7) L2L3_CASE(8) L2L3_CASE(9)
             L2L3_CASE(10) L2L3_CASE(11) L2L3_CASE(12)
@@ -1751,8 +1760,10 @@ void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n
         }
 #undef L2L3_CASE
     const size_t lds = sizeof(double) * (2 * (size_t)ch.n + 2 * ch.p * ch.p);
-    allow_large_dynamic_lds(reinterpret_cast<const void *>(&l2l_kernel), lds);
+    static std::atomic<uint64_t> attr_set[4] = {{0}, {0}, {0}, {0}};
+    if (const hipError_t e = allow_large_dynamic_lds(reinterpret_cast<const void *>(&l2l_kernel), lds, attr_set)) return static_cast<int>(e);
     hipLaunchKernelGGL(l2l_kernel, dim3(n_cells), dim3(256), lds, s, ch.dev, K, C, cells, parent, octant, active, L);
+    return 0;
 }
 
 template <int P, int D>
@@ -2409,10 +2420,17 @@ int valu_f64_selftest(double *tflops, double *mhz) {
     double *sink = nullptr;
     unsigned long long *dS = nullptr;
     if (hipMalloc(&sink, 64) != hipSuccess) return 1;
-    if (hipMalloc(&dS, sizeof(unsigned long long) * 2 * 4 * blocks) != hipSuccess) return 1;
-    hipEvent_t e0, e1;
-    (void)hipEventCreate(&e0);
-    (void)hipEventCreate(&e1);
+    if (hipMalloc(&dS, sizeof(unsigned long long) * 2 * 4 * blocks) != hipSuccess) {
+        (void)hipFree(sink);
+        return 1;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+        if (e0) (void)hipEventDestroy(e0);
+        (void)hipFree(sink);
+        (void)hipFree(dS);
+        return 1;
+    }
     hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, 64, nullptr); // warm-up
     (void)hipEventRecord(e0, 0);
     hipLaunchKernelGGL(valu_peak_kernel, dim3(blocks), dim3(256), 0, 0, sink, iters, dS);

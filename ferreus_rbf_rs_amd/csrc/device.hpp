@@ -90,12 +90,13 @@ void launch_p2m(const ChebRef &ch, const double *const *src_xyz, const double *w
                 int K, int64_t C, const int32_t *leaf_cells, int n_leaves, const int32_t *pt_begin,
                 const int32_t *pt_end, const double *centers, const double *lengths, double *M,
                 hipStream_t s);
-void launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents,
-                const int64_t *child_ptr, const int32_t *child_idx, const int32_t *octant, double *M,
-                hipStream_t s);
-void launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_cells,
-                const int32_t *parent, const int32_t *octant, const uint8_t *active, double *L,
-                hipStream_t s);
+// (both return 0 or the hipError_t of a refused function attribute: dynamic LDS above 64 KB at 3-D orders 14-16)
+int launch_m2m(const ChebRef &ch, int K, int64_t C, const int32_t *parents, int n_parents,
+               const int64_t *child_ptr, const int32_t *child_idx, const int32_t *octant, double *M,
+               hipStream_t s);
+int launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_cells,
+               const int32_t *parent, const int32_t *octant, const uint8_t *active, double *L,
+               hipStream_t s);
 
 // tile_idx: NULL, or for tiles with pad != 0 the class positions of the tile's cells
 // (tile.first indexes tile_idx; a partition's compact source tiles)

@@ -127,11 +127,8 @@ FmmTree::~FmmTree() {
     for (hipEvent_t e : ev_out_) (void)hipEventDestroy(e);
     if (h_pin_) (void)hipHostFree(h_pin_);
     free_dev_tree_points(&dev_points_);
-    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
-    if (ev_join_) (void)hipEventDestroy(ev_join_);
     if (ev_pack_) (void)hipEventDestroy(ev_pack_);
     if (ev_comm_) (void)hipEventDestroy(ev_comm_);
-    if (stream2_) (void)hipStreamDestroy(stream2_);
     if (stream_) (void)hipStreamDestroy(stream_);
 }
 
@@ -337,9 +334,6 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
             device_ = dev;
         }
         HIPCHK(hipStreamCreate(&stream_));
-        HIPCHK(hipStreamCreate(&stream2_));
-        HIPCHK(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_pack_, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_comm_, hipEventDisableTiming));
         timer.lap("device, streams");
@@ -645,7 +639,15 @@ int FmmTree::build_m2l_tables() {
                     }
                     if (worst <= budget) break;
                 }
-            G = std::min(G, ncls);
+            if (G >= ncls) { // one group per class is the finest cut there is: the largest class may still not fit
+                G = ncls;
+                int64_t worst = 0;
+                for (int64_t v : class_len[level]) worst = std::max(worst, v);
+                if (worst > budget && std::getenv("BBFMM_VERBOSE"))
+                    std::fprintf(stderr, "[bbfmm] warning: level %d needs %.1f MB of M2L intermediate per right-hand side even "
+                                         "with one batch per target class; the budget of %.1f MB (BBFMM_M2L_CBUF_MB) is exceeded\n",
+                                 level, worst * 8.0 / 1048576.0, m2l_budget_bytes_ / 1048576.0);
+            }
             level_groups[level] = G;
             if (G == 1 && !m2l_batches_.empty() && m2l_batches_.back().groups == 1 && cur_len + len <= budget) {
                 m2l_batches_.back().level_hi = level; // shares the batch of the level above
@@ -2095,12 +2097,11 @@ int FmmTree::upward(int k, const DownwardPlan *dp) {
     phase_end(kPhP2M);
     phase_begin();
     for (int level = t.depth - 1; level >= 1; --level) { // (1..depth).rev(), bbfmm.rs:675
-        if (part)
-            launch_m2m(cheb_, k, C, dp->d_up_parents[level].p, static_cast<int>(dp->up_parents_h[level].size()),
-                       dp->d_part_child_ptr.p, dp->d_part_child_idx.p, d_octant_.p, d_M_.p, stream_);
-        else
-            launch_m2m(cheb_, k, C, d_m2m_parents_[level].p, static_cast<int>(m2m_parents_[level].size()), d_child_ptr_.p,
-                       d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
+        const int rc = part ? launch_m2m(cheb_, k, C, dp->d_up_parents[level].p, static_cast<int>(dp->up_parents_h[level].size()),
+                                         dp->d_part_child_ptr.p, dp->d_part_child_idx.p, d_octant_.p, d_M_.p, stream_)
+                            : launch_m2m(cheb_, k, C, d_m2m_parents_[level].p, static_cast<int>(m2m_parents_[level].size()),
+                                         d_child_ptr_.p, d_child_idx_.p, d_octant_.p, d_M_.p, stream_);
+        if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "M2M: dynamic LDS attribute");
     }
     phase_end(kPhM2M);
     HIPCHK(hipGetLastError());
@@ -2183,9 +2184,11 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
     }
     phase_end(kPhP2L);
     phase_begin();
-    for (int level = 2; level <= t.depth; ++level) // children of level-1.. cells (bbfmm.rs:834-856)
-        launch_l2l(cheb_, k, C, d_level_cells_[level].p, static_cast<int>(level_cells_[level].size()), d_parent_.p,
-                   d_octant_.p, dp ? dp->d_active.p : d_active_.p, d_L_.p, stream_);
+    for (int level = 2; level <= t.depth; ++level) { // children of level-1.. cells (bbfmm.rs:834-856)
+        const int rc = launch_l2l(cheb_, k, C, d_level_cells_[level].p, static_cast<int>(level_cells_[level].size()), d_parent_.p,
+                                  d_octant_.p, dp ? dp->d_active.p : d_active_.p, d_L_.p, stream_);
+        if (rc != 0) return hip_fail(static_cast<hipError_t>(rc), "L2L: dynamic LDS attribute");
+    }
     phase_end(kPhL2L);
     HIPCHK(hipGetLastError());
     have_locals_ = dp == nullptr; // the whole-tree expansions are in L
@@ -2247,6 +2250,7 @@ int FmmTree::leaf_pass_far(const TargetSet &ts, int k, bool with_grads) {
 
 int FmmTree::set_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     CHK(upload_weights(w, rows, k, ldw));
     nrhs_ = k; // bbfmm.rs:384
     have_locals_ = locals_requested_ = false; // the stored local expansions belong to the old weights
@@ -2257,6 +2261,7 @@ int FmmTree::set_weights(const double *w, int64_t rows, int k, int64_t ldw) {
 
 int FmmTree::set_local_coefficients(const double *w, int64_t rows, int k, int64_t ldw) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     if (nrhs_ == 0) return fail(BBFMM_BAD_ARGUMENT, "set_weights must be called first");
     if (k != nrhs_) return fail(BBFMM_BAD_ARGUMENT, "weights must have the column count given to set_weights");
     CHK(upload_weights(w, rows, k, ldw));
@@ -2270,6 +2275,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
                       double *out, int64_t ldo, double *grad, int64_t ldg, bool with_grads, bool leaves_only,
                       int64_t *bad_point_index) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     if (nrhs_ == 0) return fail(BBFMM_BAD_ARGUMENT, "set_weights must be called first");
     if (k != nrhs_) return fail(BBFMM_BAD_ARGUMENT, "weights must have the column count given to set_weights");
     if (m < 0 || (m > 0 && (!x || !out || ldx < m || ldo < m))) return fail(BBFMM_BAD_ARGUMENT, "bad target/output arrays");
@@ -2348,6 +2354,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
 
 int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out, int64_t ldo, bool sync) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     const int64_t N = tree_.n_points;
     if (!d_w || !d_out || k < 1 || ldw < N || ldo < N) return fail(BBFMM_BAD_ARGUMENT, "bad device matvec arguments");
     CHK(ensure_rhs_capacity(k));
@@ -2361,48 +2368,19 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
     }
     const TargetSet &ts = have_part_ ? part_targets_ : src_targets_;
     const DownwardPlan *plan = have_part_ ? &part_plan_ : nullptr;
-    static const int overlap = [] {
-        const char *e = std::getenv("BBFMM_OVERLAP");
-        return e ? std::atoi(e) : 0;
+    static const bool wx_on = [] {
+        const char *e = std::getenv("BBFMM_WX_FUSED"); // 0: separate P2L and M2P kernels
+        const char *e2 = std::getenv("BBFMM_P2P_SYM");
+        return (!e || std::atoi(e) != 0) && (!e2 || std::atoi(e2) != 0);
     }();
-    if (overlap == 2) {
-        // P2P starts beside the (latency-bound) upward pass on a second stream
-        HIPCHK(hipEventRecord(ev_fork_, stream_));
-        HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-        CHK(leaf_pass_near(ts, k, false, stream2_, 1));
-        CHK(upward(k, nullptr));
-        HIPCHK(hipEventRecord(ev_fork_, stream_));
-        HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-        CHK(leaf_pass_near(ts, k, false, stream2_, 2));
-        HIPCHK(hipEventRecord(ev_join_, stream2_));
-        CHK(downward(k, plan));
-        HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
-        CHK(leaf_pass_far(ts, k, false));
-    } else if (overlap == 1) {
-        CHK(upward(k, nullptr));
-        // near field (FP64 VALU) on a second stream beside the far field (FP64 MFMA)
-        HIPCHK(hipEventRecord(ev_fork_, stream_));
-        HIPCHK(hipStreamWaitEvent(stream2_, ev_fork_, 0));
-        CHK(leaf_pass_near(ts, k, false, stream2_, 3));
-        HIPCHK(hipEventRecord(ev_join_, stream2_));
-        CHK(downward(k, plan));
-        HIPCHK(hipStreamWaitEvent(stream_, ev_join_, 0));
-        CHK(leaf_pass_far(ts, k, false));
-    } else {
-        static const bool wx_on = [] {
-            const char *e = std::getenv("BBFMM_WX_FUSED"); // 0: separate P2L and M2P kernels
-            const char *e2 = std::getenv("BBFMM_P2P_SYM");
-            return (!e || std::atoi(e) != 0) && (!e2 || std::atoi(e2) != 0);
-        }();
-        const bool wx = wx_on && !deterministic_ && k == 1 && !have_part_ && ts.sym && ts.n_wx_jobs > 0;
-        // (a partitioned handle called on its own, without the exchange of matvec_partition_upward / _finish,
-        // needs every multipole: the whole upward pass)
-        CHK(upward(k, nullptr));
-        if (wx) HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(ts.m) * sizeof(double), stream_));
-        CHK(downward(k, plan, wx ? &ts : nullptr));
-        CHK(leaf_pass_near(ts, k, false, stream_, 3, wx));
-        CHK(leaf_pass_far(ts, k, false));
-    }
+    const bool wx = wx_on && !deterministic_ && k == 1 && !have_part_ && ts.sym && ts.n_wx_jobs > 0;
+    // (a partitioned handle called on its own, without the exchange of matvec_partition_upward / _finish,
+    // needs every multipole: the whole upward pass)
+    CHK(upward(k, nullptr));
+    if (wx) HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(ts.m) * sizeof(double), stream_));
+    CHK(downward(k, plan, wx ? &ts : nullptr));
+    CHK(leaf_pass_near(ts, k, false, stream_, 3, wx));
+    CHK(leaf_pass_far(ts, k, false));
     phase_begin();
     launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out, ldo, 0, stream_);
     phase_end(kPhScatter);
@@ -2563,6 +2541,7 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
                                         const int64_t *target_indices, int64_t n_target_indices, const double *poly,
                                         int64_t ldp, double nugget, double *result) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     const int64_t N = tree_.n_points;
     if (!w || !result || basis_size < 0 || rows != N + basis_size)
         return fail(BBFMM_BAD_ARGUMENT, "weights must have N + basis_size rows");
@@ -3118,6 +3097,7 @@ int FmmTree::register_subset(const int64_t *idx, int64_t n_idx, int *id_out) {
 // (IterativeSolver::matvec_partial, rbf.rs:119-133, without the nugget / polynomial terms), all on the device.
 int FmmTree::matvec_subset_device(int id, const double *d_w, double *d_y, bool sync) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     const int64_t N = tree_.n_points;
     if (!d_w || !d_y) return fail(BBFMM_BAD_ARGUMENT, "bad device matvec arguments");
     if (id == -1) return matvec_device(d_w, N, 1, d_y, N, sync);
@@ -3364,8 +3344,12 @@ int FmmTree::debug_apply_m2l_tables_host(const double *M, double *L) const {
     // every source cell of a level with M2L work belongs to exactly one stage-1 tile per batch of its level
     for (const HostM2lClass &hc : m2l_host_)
         for (int32_t c : hc.cells) {
-            const M2lBatch &mb = m2l_batches_[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(&hc - m2l_host_.data())])];
-            if (seen[c] != mb.groups) return BBFMM_BAD_ARGUMENT;
+            // (on a level cut into groups a class has one operator per group its transfer vectors reach -- a class
+            // whose vectors miss a group has none for it, as build_downward_plan anticipates)
+            const size_t lc = static_cast<size_t>(&hc - m2l_host_.data());
+            const M2lBatch &mb = m2l_batches_[static_cast<size_t>(m2l_batch_of_class_[lc])];
+            const int want = mb.groups == 1 || m2l_group_ops_[lc].empty() ? mb.groups : static_cast<int>(m2l_group_ops_[lc].size());
+            if (seen[c] != want) return BBFMM_BAD_ARGUMENT;
         }
     return BBFMM_OK;
 }

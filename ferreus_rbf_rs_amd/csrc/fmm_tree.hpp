@@ -311,8 +311,7 @@ class FmmTree {
     std::vector<std::unique_ptr<SubsetPlan>> registered_plans_; // bbfmm_target_subset_create: kept for the handle's life
 
     // ---- device state
-    hipStream_t stream_ = nullptr, stream2_ = nullptr;
-    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    hipStream_t stream_ = nullptr;
     hipEvent_t ev_pack_ = nullptr, ev_comm_ = nullptr; // partitioned matvec: packed multipoles ready / all-reduce done
     struct PendingPhase {
         int phase;

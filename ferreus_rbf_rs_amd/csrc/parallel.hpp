@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <cstdint>
 #include <cstdlib>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -120,7 +121,10 @@ private:
     int wanted_ = 0, running_ = 0;
 };
 
-// fn(begin, end) is called on disjoint chunks.
+// fn(begin, end) is called on disjoint chunks.  An exception thrown by fn on any thread (bad_alloc from a push_back,
+// say) never leaves that thread's worker: the first one is kept, the remaining chunks are dropped, every thread
+// finishes its current chunk, and the exception is rethrown on the caller once all of them are back -- the pool's
+// job lock is released and no helper is left running on a dead stack frame.
 template <class F> void parallel_for_chunks(int64_t n, int64_t chunk, F &&fn) {
     if (n <= 0) return;
     const int nt = static_cast<int>(std::min<int64_t>(host_threads(), (n + chunk - 1) / chunk));
@@ -129,19 +133,28 @@ template <class F> void parallel_for_chunks(int64_t n, int64_t chunk, F &&fn) {
         return;
     }
     std::atomic<int64_t> next{0};
-    auto worker = [&]() {
-        while (true) {
-            const int64_t b = next.fetch_add(chunk);
-            if (b >= n) break;
-            fn(b, std::min(n, b + chunk));
+    std::atomic<bool> failed{false};
+    std::exception_ptr error;
+    auto worker = [&]() noexcept {
+        try {
+            while (true) {
+                const int64_t b = next.fetch_add(chunk);
+                if (b >= n) break;
+                fn(b, std::min(n, b + chunk));
+            }
+        } catch (...) {
+            if (!failed.exchange(true)) error = std::current_exception();
+            next.store(n); // nobody starts another chunk
         }
     };
-    if (HostPool::get()->run(nt - 1, worker)) return;
-    std::vector<std::thread> threads;
-    threads.reserve(nt - 1);
-    for (int i = 0; i < nt - 1; ++i) threads.emplace_back(worker);
-    worker();
-    for (auto &t : threads) t.join();
+    if (!HostPool::get()->run(nt - 1, worker)) {
+        std::vector<std::thread> threads;
+        threads.reserve(nt - 1);
+        for (int i = 0; i < nt - 1; ++i) threads.emplace_back(worker);
+        worker();
+        for (auto &t : threads) t.join();
+    }
+    if (failed.load()) std::rethrow_exception(error);
 }
 
 template <class F> void parallel_for(int64_t n, int64_t chunk, F &&fn) {

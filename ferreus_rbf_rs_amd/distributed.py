@@ -125,6 +125,15 @@ class PartitionedMatvec:
         # the all-reduce runs on its own stream: the library makes it wait for the packed multipoles only, so that the
         # collective overlaps the near field queued behind the pack, and makes its own stream wait for it in `finish`
         self.comm = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+        if device.type == "cuda":
+            # the buffers above were created (zero-filled) on torch's current stream; the handle's stream and the
+            # communication stream write to them from now on: order both behind the fills explicitly
+            cur = torch.cuda.current_stream(device)
+            self.stream.wait_stream(cur)
+            self.comm.wait_stream(cur)
+        if self.split and not always_exchange and not self.check_partition():
+            raise ValueError("the handle's partition does not match the group: rank %d of %d holds part %d, bounds %s, "
+                             "row counts %s" % (self.rank, self.world, tree.partition_rank(), self.bounds, self.counts))
 
     def check_partition(self) -> bool:
         """True when the ranks' shares are the parts of the handle's partition, in order, and cover every row once."""

@@ -1,7 +1,8 @@
 #!/bin/bash
 # One GPU job that produces every measurement the bench line quotes, named by round:
 #   bash scripts/gpu_round_profiles.sh r02_b          (run through gpurun; outputs under gpurun_out/, copy to profiles/)
-#  1. python bench.py (default: headline + the other single-GPU configs + cpu_baseline)      -> <tag>_bench.json
+#  1. python bench.py (default: headline + the other single-GPU configs + cpu_baseline)      -> <tag>_bench.json (the <4 KB line)
+#                                                                                              + <tag>_bench_detail.json (full record)
 #  2. rocprofv3 --kernel-trace --stats of the same command (headline only)                    -> <tag>_kernel_stats.csv
 #  3. PMC passes, one counter / derived metric per pass, no tracing domains besides kernel-trace:
 #     FETCH_SIZE, WRITE_SIZE (HBM-side bytes; FETCH_SIZE x2 on gfx950 for 16-B/lane reads, KiB units),
@@ -10,8 +11,9 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 ROOT=$GRAFT_REPO_ROOT
 TAG=${1:-r02_x}
-python3 bench.py --steps 20 --warmup 3 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
-tail -2 gpurun_out/${TAG}_bench.err; cut -c1-400 gpurun_out/${TAG}_bench.json
+python3 bench.py --steps 20 --warmup 5 --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+wc -c gpurun_out/${TAG}_bench.json
+grep -v "bench detail" gpurun_out/${TAG}_bench.err | tail -2; cut -c1-400 gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/prof_$TAG
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-baseline off --configs off > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>$ROOT/gpurun_out/prof_${TAG}.err

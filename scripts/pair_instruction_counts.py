@@ -8,7 +8,8 @@ coordinates, kernel_value_r2<KID> of csrc/kernels.hpp, row and column accumulati
 unrolled; it is compiled for gfx950 with the library's flags, emitted as assembly (-S), and the instructions of
 the loop body (the block that ends in the backward branch) are counted by class.  bench.py multiplies the count by the
 kernel evaluations a phase executes and divides by the FP64 instruction-issue peak (`valu_issue`); the file is stamped
-with the hash of csrc/ so that counts are only quoted for the sources they were taken on.  Runs without a GPU."""
+with the hash of csrc/kernels.hpp + scripts/pair_probe.hip (the only sources the count depends on) so that counts are
+only quoted for the arithmetic they were taken on.  Runs without a GPU."""
 import collections
 import json
 import os
@@ -27,7 +28,7 @@ TRANS = re.compile(r"^v_(rsq|rcp|sqrt|log|exp|frexp_mant|ldexp)\w*_f64")
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03_x"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     tmp = tempfile.mkdtemp(prefix="pair_probe_")
     asm_path = os.path.join(tmp, "probe.s")
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -76,7 +77,7 @@ def main():
                  "select_compare_per_pair": cls["select_compare"], "other_valu_in_probe_loop": cls["other_valu"]}
         # the same inlined arithmetic in every pair kernel
         out[name] = {k: entry for k in ("p2p_sym", "p2p", "wx_sym", "p2l", "m2p")}
-    res = {"source_hash": bench.source_hash(), "kernels": out,
+    res = {"pair_probe_hash": bench.pair_probe_hash(), "kernels": out,
            "note": "v_*_f64 instructions of one kernel evaluation incl. the distance and the two accumulations "
                    "(scripts/pair_probe.hip, loop body between the backward branch and its target); transcendental seeds "
                    "(v_rsq_f64 / v_rcp_f64, about two FMA issue slots each on MI355X, scripts/rsq_rate.hip) are counted once"}

@@ -62,17 +62,109 @@ def test_extra_configs_name_baseline_json_configs():
         assert c["total_sill"] <= c["base_range"]      # KernelParamsBuilder::build asserts this (kernel_helpers.rs:69-70)
 
 
+class _HeadlineStats:  # the fields of bbfmm_tree_stats bench.py reads (10M-point headline values)
+    n_nodes, n_cells, d, n_leaves, n_w, depth, n_v = 343, 298905, 3, 261542, 9216, 6, 52151874
+    m2l_flops_k1, wx_tile_bytes_k1, wx_pairs = 1.7298e12, 5.0e8, 1.2e8
+    p2p_tile_bytes_k1, p2p_pairs = 9_990_000_000, 10_080_000_000
+    m2l_basis_rank = m2l_basis_len = 0
+
+
+_HEADLINE_MS = {"gather": 0.05, "P2M": 1.06, "M2M": 0.43, "M2L_stage1": 17.3, "M2L_stage2": 15.8, "P2L": 0.2, "L2L": 0.3,
+                "P2P": 5.5, "M2P": 0.0, "L2P": 0.95, "scatter": 0.05}
+
+
 def test_phase_roofline_accounts_every_phase_and_names_the_bound():
-    class S:  # the fields of bbfmm_tree_stats the function reads (10M-point headline values)
-        n_nodes, n_cells, d, n_leaves, n_w = 343, 298905, 3, 261542, 9216
-        m2l_flops_k1, wx_tile_bytes_k1, wx_pairs = 1.7298e12, 5.0e8, 1.2e8
-        p2p_tile_bytes_k1, p2p_pairs = 9.99e9, 1.008e10
-    ms = {"gather": 0.05, "P2M": 1.06, "M2M": 0.43, "M2L_stage1": 17.3, "M2L_stage2": 15.8, "P2L": 0.2, "L2L": 0.3,
-          "P2P": 5.5, "M2P": 0.0, "L2P": 0.95, "scatter": 0.05}
-    pr = bench.phase_roofline(S, 10_000_000, 1, 7, "LinearRbf", ms, sym_pairs=True)
+    S, ms = _HeadlineStats, _HEADLINE_MS
+    pr = bench.phase_roofline(S, 10_000_000, 1, 7, "LinearRbf", ms, 3.1e13)
     assert set(pr) == set(ms) - {"M2P"}                                   # phases that took no time are left out
     assert pr["M2L_stage1"]["bound"] == "mfma" and abs(pr["M2L_stage1"]["frac_fp64"] - 0.636) < 0.01
     assert pr["P2P"]["bound"] == "fp64_valu" and abs(pr["P2P"]["frac_hbm"] - 0.227) < 0.01
     assert pr["gather"]["bound"] == "hbm" and pr["gather"]["flops"] == 0.0
     for e in pr.values():
         assert e["gbps"] > 0 and 0 <= e["frac_hbm"] < 1.5 and 0 <= e["frac_fp64"] < 1.0
+    vi = pr["P2P"]["valu_issue"]                                          # every unordered pair once, 17 instructions
+    assert vi["fp64_valu_instr_per_evaluation"] == 17 and abs(vi["kernel_evaluations"] - 5.045e9) < 1e7
+    assert abs(vi["frac_of_measured_fma_rate"] - 5.045e9 * 17 / 5.5e-3 / 3.1e13) < 1e-3
+
+
+def test_pair_phases_are_quoted_against_the_fp64_vector_roof():
+    """a pair phase that dominates (config 2: fused M2P + P2L) reports bound fp64_valu with the
+    instruction-issue fraction, and keeps the HBM tile-bytes figure beside it as frac_hbm."""
+    S = _HeadlineStats
+    ms = dict(_HEADLINE_MS, P2L=40.0)
+    dom, r = bench.roofline_of(S, 1_000_000, 1, "Spheroidal3Rbf", ms, 1, None, 3.1e13)
+    assert dom == "P2L" and r["bound"] == "fp64_valu" and r["unit"] == "Tinstr/s"
+    assert abs(r["frac"] - 1.2e8 * 28 / 40e-3 / 3.1e13) < 1e-6 and abs(r["peak"] - 31.0) < 1e-9
+    assert abs(r["frac_hbm"] - 5.0e8 / 40e-3 / 8e12) < 1e-9
+    dom, r = bench.roofline_of(S, 10_000_000, 1, "LinearRbf", _HEADLINE_MS, 1)
+    assert dom == "M2L_stage1" and r["bound"] == "mfma" and abs(r["frac"] - 0.636) < 0.01 and "frac_hbm" not in r
+    # ordered pairs with K right-hand sides: one evaluation, K row multiply-adds
+    assert bench.pair_issue(S, 10_000_000, 8, "LinearRbf", "P2P")[:2] == (float(S.p2p_pairs), 17 - 2 + 8) or \
+        bench.SYM_P2P_MAX_RHS >= 8
+    assert bench.pair_probe_hash() == bench.committed_pair_instructions()["pair_probe_hash"]   # counts belong to kernels.hpp
+
+
+def _synthetic_detail(world=1):
+    """A full detail record as main() builds it, from synthetic statistics: headline + every extra configuration +
+    config 3's solve + config 5, with the long fields real runs carry."""
+    S, ms = _HeadlineStats, _HEADLINE_MS
+    _, roof = bench.roofline_of(S, 10_000_000, 1, "LinearRbf", ms, world, {k: 1 for k in ms}, 3.1e13)
+    roof.update(traffic=42384990805.333336, mfma_util_pct=71.48968633333332, counters_from="profiles/r04_final_counters.json")
+    cfgs = {}
+    for c in bench.EXTRA_CONFIGS + bench.EXTENSION_CONFIGS + [bench.CONFIG5]:
+        _, r = bench.roofline_of(S, c["points"], c["nrhs"], c["kernel"], dict(ms, P2L=40.0), world, None, 3.1e13)
+        cfgs[c["name"]] = {"workload": "x" * 80, "ms_per_step": 14.312587000313215, "roofline": r, "phase_ms_per_step": ms,
+                           "dense_rows_rel_err": 9.955587767114334e-07,
+                           "phase_roofline": bench.phase_roofline(S, c["points"], c["nrhs"], 7, c["kernel"], ms, 3.1e13)}
+    solve = {"ddm_params": {}, "levels": 4, "setup_s": 2.612345678, "solve_s": 3.1923456, "iterations": 5, "converged": True,
+             "stagnated": False, "residual_history": [6.12e-5, 9.97e-6, 2.69e-6, 1.11e-6, 6.96e-7], "max_fit_error_on_sample": 4e-6}
+    cfgs["config3_solve_tps_10M_fgmres_schwarz"] = {"workload": "y" * 100, "for_points": solve,
+                                                     "reference_defaults": dict(solve, converged=False, stagnated=True)}
+    cfgs["broken"] = {"error": "RuntimeError: " + "z" * 500}
+    return {"metric": "BBFMM matvecs/s", "value": 24.108183244653507, "unit": "matvecs/s", "n_gpus": world, "steps": 20,
+            "warmup": 5, "ms_per_step": 41.479691350104986, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "10000000 uniform 3D points, LinearRbf, order 7, 1 rhs, adaptive sparse tree, ACA eps=1e-7, "
+                                   "set_weights + evaluate at the sources", "points": 10_000_000, "kernel": "LinearRbf",
+                       "order": 7, "nrhs": 1, "parallelism": "single GPU" if world == 1 else "p" * 150},
+            "roofline": roof, "phase_ms_per_step": ms, "tree": {"depth": 6}, "source_hash": bench.source_hash(),
+            "phase_roofline": bench.phase_roofline(S, 10_000_000, 1, 7, "LinearRbf", ms, 3.1e13),
+            "dense_rows_rel_err": 9.390407276931204e-09, "configs": cfgs,
+            "cpu_baseline": {"value": 0.03216402327044833, "unit": "matvecs/s", "cores": 128, "kind": "port", "sample": "s" * 400},
+            "cpu_baseline_detail": {"note": "n" * 600}}
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_the_stdout_line_stays_under_4_kb_and_round_trips(world, tmp_path, monkeypatch):
+    """round 3's 20.7 KB line came back from the driver unparsed.  The printed line is built by
+    compact_line from the full record; whatever the record carries, the line is one line of < 4096 bytes that
+    json.loads reads back, with the contract's keys, `roofline` and `cpu_baseline`."""
+    detail = _synthetic_detail(world)
+    assert len(json.dumps(detail)) > 20000                                # the record that broke the driver's parser
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    r, wfd = os.pipe()
+    bench.write_outputs(detail, wfd)
+    os.close(wfd)
+    text = os.read(r, 1 << 20).decode()
+    os.close(r)
+    assert text.endswith("\n") and text.count("\n") == 1 and len(text) < 4096
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "dense_rows_rel_err", "source_hash"):
+        assert k in line, k
+    assert line["n_gpus"] == world and line["config"]["workload"].startswith("10000000 uniform")
+    assert set(line["roofline"]) >= {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "mfma_util_pct"}
+    assert abs(line["value"] - detail["value"]) < 1e-5 * detail["value"]
+    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 200
+    assert line["p2p"]["frac_hbm"] < 0.5 and 0 < line["p2p"]["frac_fp64_valu"] < 1
+    for name, c in line["configs"].items():
+        if name == "broken":
+            assert len(c["error"]) <= 120
+        elif name.startswith("config3_solve"):
+            assert c["for_points"]["iterations"] == 5 and c["reference_defaults"]["stagnated"] is True
+        else:
+            assert set(c) == {"ms_per_step", "dense_rows_rel_err", "roofline"} and set(c["roofline"]) == {"kernel", "bound", "frac"}
+    # the full record went to the side file, untouched
+    with open(tmp_path / "bench_detail.json") as f:
+        full = json.load(f)
+    assert full["configs"]["config2_spheroidal3_1M"]["phase_roofline"] and full["cpu_baseline_detail"]["note"]

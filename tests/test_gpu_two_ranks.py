@@ -57,24 +57,56 @@ def test_two_ranks_over_rccl_one_gpu_each():
     _run_two_ranks("nccl")
 
 
+def _bench_ranks(world, points, config5_points, tmp_path):
+    """`python bench.py --gpus N` with no launcher around it on the one GPU of the box (gloo exchange): returns the
+    parsed stdout line, the raw line and the full record of the side file."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    detail = str(tmp_path / "bench_detail.json")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--exchange", "gloo",
+                        "--points", str(points), "--steps", "3", "--warmup", "1", "--cpu-baseline", "off",
+                        "--configs", "config5", "--config5-points", str(config5_points), "--detail-file", detail],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1100)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, [len(ln) for ln in lines]       # ONE line the driver can parse
+    with open(detail) as f:
+        full = json.load(f)
+    return json.loads(lines[0]), lines[0], full
+
+
 @pytest.mark.timeout(900)
-def test_bench_launches_its_own_ranks():
+def test_bench_launches_its_own_ranks(tmp_path):
     """`python bench.py --gpus 2` with no launcher around it: the parent starts two rank processes before
     touching the GPU and relays rank 0's line (here with the gloo exchange so that both fit one GPU)."""
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--exchange", "gloo",
-                        "--points", "400000", "--steps", "3", "--warmup", "1", "--cpu-baseline", "off",
-                        "--configs", "config5", "--config5-points", "300000"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
-    assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    j = json.loads(lines[0])
+    j, _, full = _bench_ranks(2, 400000, 300000, tmp_path)
     assert j["n_gpus"] == 2 and j["steps"] == 3 and j["value"] > 0 and j["scaling"] == "strong"
     assert "target-subtree partition x2" in j["config"]["parallelism"]
     # the N > 1 line is a checked claim: dense rows of the exchanged result, and config 5's workload on the same ranks
     assert j["dense_rows_rel_err"] is not None and j["dense_rows_rel_err"] < 1e-6
+    assert j["partition_covers_every_row_once"] is True
     c5 = j["configs"]["config5_spheroidal3_40M"]
     assert "error" not in c5, c5
-    assert c5["n_gpus"] == 2 and c5["ms_per_step"] > 0 and c5["dense_rows_rel_err"] < 1e-5
-    assert "Spheroidal3Rbf" in c5["workload"] and c5["workload"].startswith("300000 ")
+    assert c5["ms_per_step"] > 0 and c5["dense_rows_rel_err"] < 1e-5 and c5["roofline"]["frac"] > 0
+    f5 = full["configs"]["config5_spheroidal3_40M"]
+    assert f5["n_gpus"] == 2 and "Spheroidal3Rbf" in f5["workload"] and f5["workload"].startswith("300000 ")
+
+
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_rehearsal_on_one_gpu(tmp_path):
+    """The driver's 8-GPU run has no retry, so the 8-rank path is rehearsed here first: eight
+    fresh rank processes on the one GPU, exchange over gloo -- NEVER a scaling number.  rc 0, one line under 4 KB,
+    n_gpus == 8, both workloads checked against dense rows (2M LinearRbf; config 5's Spheroidal3 at 1M points, whose
+    BBFMM accuracy at order 7 is itself 1e-6: bound 2e-6), every row owned exactly once (bench.py asserts
+    `check_partition` on every rank before timing and records it).  The split rehearsed: bbfmm.rs:383-401, 444-507."""
+    j, raw, full = _bench_ranks(8, 2_000_000, 1_000_000, tmp_path)
+    assert j["n_gpus"] == 8 and j["steps"] == 3 and j["value"] > 0
+    assert "target-subtree partition x8" in j["config"]["parallelism"]
+    assert j["partition_covers_every_row_once"] is True
+    assert j["dense_rows_rel_err"] < 1e-6
+    c5 = j["configs"]["config5_spheroidal3_40M"]
+    assert "error" not in c5 and c5["dense_rows_rel_err"] < 2e-6 and c5["ms_per_step"] > 0
+    assert full["configs"]["config5_spheroidal3_40M"]["n_gpus"] == 8
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):                          # kept for profiles/ (labelled: never a scaling number)
+        with open(os.path.join(out, "bench_8ranks_gloo_one_gpu.json"), "w") as f:
+            f.write(raw + "\n")
