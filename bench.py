@@ -289,10 +289,18 @@ def cpu_baseline(args, kernel_id):
 PAIR_FLOPS = {"LinearRbf": 3 * 3 - 1 + 1 + 1 + 2, "ThinPlateSplineRbf": 3 * 3 - 1 + 1 + 3 + 2, "CubicRbf": 3 * 3 - 1 + 1 + 2 + 2,
               "Spheroidal3Rbf": 3 * 3 - 1 + 1 + 6 + 2, "MultiquadricExt": 3 * 3 - 1 + 1 + 2 + 2}
 
-# right-hand sides the unordered-pair kernels (near field; fused M2P + P2L) take in one pass: beyond these the
-# ordered-pair kernels run (fmm_tree.cpp)
-SYM_P2P_MAX_RHS = 1
-SYM_WX_MAX_RHS = 1
+# right-hand sides the unordered-pair kernels (near field; fused M2P + P2L) take in one pass (device.hpp kSymMaxRhs);
+# kernel instances exist for 1, 2, 4 and 8 -- 3 and 5-7 run the next instance up with idle slots
+SYM_MAX_RHS = 8
+
+
+def sym_instances(K):
+    """Kernel instances (rhs slots) of the passes that serve K right-hand sides."""
+    out = []
+    for k0 in range(0, K, SYM_MAX_RHS):
+        kb = min(SYM_MAX_RHS, K - k0)
+        out.append(1 if kb == 1 else 2 if kb == 2 else 4 if kb <= 4 else 8)
+    return out
 
 
 def pair_probe_hash() -> str:
@@ -326,20 +334,20 @@ def committed_pair_instructions():
 
 def pair_issue(stats, N, K, kernel, phase):
     """(kernel evaluations executed, FP64 VALU instructions per evaluation, instruction-count file) of a pair phase
-    -- P2P, P2L (fused with M2P when the unordered kernel runs), M2P -- or None.  Unordered kernels evaluate every
-    pair once and feed the row sum and the column sum of each right-hand side from it (2K multiply-adds); ordered
-    kernels feed the K row sums (K multiply-adds).  The count of the probe is for one rhs, both sums (2)."""
+    of the matvec -- P2P, P2L (= M2P + P2L fused) -- or None.  The unordered kernels evaluate every pair once per
+    pass of up to eight right-hand sides and feed the row sum and the column sum of each rhs slot from it; the count
+    of the probe is for one rhs, both sums (2)."""
     instr = committed_pair_instructions()
     if not instr or kernel not in instr.get("kernels", {}):
         return None
-    sym = (phase == "P2P" and K <= SYM_P2P_MAX_RHS) or (phase == "P2L" and K <= SYM_WX_MAX_RHS)
-    key = {"P2P": "p2p_sym" if sym else "p2p", "P2L": "wx_sym" if sym else "p2l", "M2P": "m2p"}[phase]
+    sym = phase in ("P2P", "P2L")             # the matvec (targets = sources): unordered pairs, whatever K
+    key = {"P2P": "p2p_sym", "P2L": "wx_sym", "M2P": "m2p"}[phase]
     ipp = instr["kernels"][kernel][key]["fp64_valu_per_pair"]
-    if sym:
+    if sym:      # per pass: one evaluation, a row and a column multiply-add per rhs slot of the kernel instance
         evals = (stats.p2p_pairs + N) / 2.0 if phase == "P2P" else float(stats.wx_pairs)
-        per_eval = ipp - 2 + 2 * K
+        per_eval = sum(ipp - 2 + 2 * kb for kb in sym_instances(K))
     else:
-        evals = float(stats.p2p_pairs) if phase == "P2P" else float(stats.wx_pairs)
+        evals = float(stats.wx_pairs)
         per_eval = ipp - 2 + K
     return evals, per_eval, instr["file"]
 
@@ -425,7 +433,7 @@ def phase_roofline(stats, N, K, order, kernel, per_step_ms, valu_lane_rate=None)
             continue
         if ph in ("P2L", "M2P") and stats.n_w == 0:
             continue
-        if ph == "M2P" and K <= SYM_WX_MAX_RHS:
+        if ph == "M2P":
             continue                                     # fused with P2L into one kernel (timed under P2L)
         sec = ms * 1e-3
         t_hbm, t_fp = nbytes / (HBM_PEAK_GBPS * 1e9), flops / (FP64_MFMA_PEAK_TFLOPS * 1e12)
@@ -611,7 +619,7 @@ def compact_line(detail: dict) -> dict:
     return line
 
 
-def run_config3_solve(F, points=10_000_000):
+def run_config3_solve(F, points=10_000_000, defaults_outer=4):
     """BASELINE.json config 3 end to end (opt-in, `--configs solve`): thin-plate spline, order 9, linear drift, smooth
     values, FGMRES 20 x 5 to 1e-6 relative, right-preconditioned by the multi-level Schwarz sweep -- with
     DDMParams.for_points (the extension that keeps three fine levels; it converges) and with the reference's default
@@ -629,7 +637,7 @@ def run_config3_solve(F, points=10_000_000):
     rhs = np.concatenate([vals, np.zeros(st.basis_size)])
     out = {"workload": f"{n} uniform 3D points, ThinPlateSplineRbf, order 9, linear drift, FGMRES 20 x 5 + Schwarz, "
                        "tolerance 1e-6 relative", "fmm_tree_build_s": t_tree}
-    for label, params, max_outer in (("for_points", DDMParams.for_points(n), 20), ("reference_defaults", DDMParams(), 4)):
+    for label, params, max_outer in (("for_points", DDMParams.for_points(n), 20), ("reference_defaults", DDMParams(), defaults_outer)):
         t0 = time.time()
         pre = SchwarzPreconditioner(tree, pts, st, params)
         t_ddm = time.time() - t0

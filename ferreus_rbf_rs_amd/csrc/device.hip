@@ -781,10 +781,15 @@ __global__ __launch_bounds__(256) void p2p_kernel(KernelSpec ks, int d, DirectJo
 // tiles and are reduced across the wave once, column sums go to an LDS accumulator by ds_add_f64 (distinct
 // addresses inside a wave) and from there to HBM with one f64 atomic per source and tile.  One right-hand
 // side per launch (more rhs take the ordered-pair kernel above).
+// KB right-hand sides in one pass (round 4): one kernel evaluation feeds KB row and KB column sums; the rows of a wave
+// go by in passes of sym_rows_pass<KB>() (their weights are SGPR operands), the tile shrinks with KB so that its
+// weights and column accumulators stay under 64 KB of LDS.  rhs k reads ws + k * ldw and adds to out + k * ldo.
 constexpr int SYM_TILE = 768;
 constexpr int SYM_TR = 6;
 constexpr int SYM_WAVES = 8;
 constexpr int SYM_SEG = 64; // runs packed into one tile at most
+template <int KB> constexpr int sym_tile() { return KB <= 2 ? SYM_TILE : (KB <= 4 ? SYM_TILE / 2 : SYM_TILE / 3); }
+template <int KB> constexpr int sym_rows_pass() { return KB == 1 ? SYM_TR : (KB <= 4 ? 3 : 2); }
 
 struct SymJobs {
     int n_jobs;
@@ -794,9 +799,10 @@ struct SymJobs {
     int32_t tgt_off;                    // sorted source index of target position 0
 };
 
-struct SymTile {
-    double x[SYM_TILE], y[SYM_TILE], z[SYM_TILE], w[SYM_TILE], col[SYM_TILE];
-    int32_t cidx[SYM_TILE]; // target position of a two-sided column, -1 for a one-sided one
+template <int KB> struct SymTile {
+    static constexpr int T = sym_tile<KB>();
+    double x[T], y[T], z[T], w[KB][T], col[KB][T];
+    int32_t cidx[T]; // target position of a two-sided column, -1 for a one-sided one
     int32_t seg_src[SYM_SEG], seg_off[SYM_SEG], seg_two[SYM_SEG]; // runs packed into the tile
     int32_t fill, nseg, next_pos;
     int64_t next_q;
@@ -808,11 +814,13 @@ __device__ inline double wave_sum(double v) {
     return v;
 }
 
-template <int KID>
+template <int KID, int KB>
 __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, SymJobs jobs, Xyz src,
-                                                                const double *__restrict__ ws,
-                                                                double *__restrict__ out) {
-    __shared__ SymTile tile;
+                                                                const double *__restrict__ ws, int64_t ldw, int kb,
+                                                                double *__restrict__ out, int64_t ldo) {
+    constexpr int T = sym_tile<KB>();
+    constexpr int TRP = sym_rows_pass<KB>();
+    __shared__ SymTile<KB> tile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int job = blockIdx.x;
@@ -820,19 +828,17 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
     const int rpw = (t1 - t0 + SYM_WAVES - 1) / SYM_WAVES; // rows per wave, <= SYM_TR
     const int r_lo = min(t0 + wave * rpw, t1);
     const int nr = min(rpw, t1 - r_lo);
-    double tx[SYM_TR], ty[SYM_TR], tz[SYM_TR], tw[SYM_TR], racc[SYM_TR];
+    double racc[SYM_TR][KB];
 #pragma unroll
-    for (int r = 0; r < SYM_TR; ++r) {
-        const int g = jobs.tgt_off + min(r_lo + min(r, max(nr - 1, 0)), t1 - 1); // sorted source index of the target (wave-uniform)
-        tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g], tw[r] = ws[g];
-        racc[r] = 0.0;
-    }
+    for (int r = 0; r < SYM_TR; ++r)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) racc[r][k] = 0.0;
     int64_t q = jobs.run_range[2 * job];
     const int64_t q1 = jobs.run_range[2 * job + 1];
     int pos = 0; // points of run q already staged
     while (q < q1) {
         __syncthreads(); // the previous tile has been read and its columns flushed
-        // The tile's segment table: up to SYM_SEG runs packed back to back until SYM_TILE columns are full.  One
+        // The tile's segment table: up to SYM_SEG runs packed back to back until T columns are full.  One
         // wave reads the run triples in one go and scans their lengths; then every thread finds the run of its
         // column by bisection in LDS, so that all source loads of the tile leave in one batch (one memory round
         // trip for the table, one for the columns, whatever the number of runs).
@@ -851,7 +857,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
                 if (lane >= d) incl += up;
             }
             const int excl = incl - len;
-            const int take = min(len, max(SYM_TILE - excl, 0));
+            const int take = min(len, max(T - excl, 0));
             tile.seg_src[lane] = b;
             tile.seg_off[lane] = excl;
             tile.seg_two[lane] = two;
@@ -880,38 +886,70 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
             tile.x[j] = src.x[g];
             tile.y[j] = src.y[g];
             tile.z[j] = src.z[g];
-            tile.w[j] = ws[g];
-            tile.col[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                tile.w[k][j] = k < kb ? ws[k * ldw + g] : 0.0;
+                tile.col[k][j] = 0.0;
+            }
             tile.cidx[j] = tile.seg_two[lo] ? g - jobs.tgt_off : -1;
         }
         __syncthreads();
-        if (nr > 0) {
-            for (int j = lane; j < fill; j += 64) {
-                const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j], wj = tile.w[j];
-                double csum = 0.0;
 #pragma unroll
-                for (int r = 0; r < SYM_TR; ++r) {
-                    if (r < nr) { // wave-uniform
-                        const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
-                        const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
-                        racc[r] += v * wj;
-                        csum += v * tw[r];
+        for (int p = 0; p < SYM_TR; p += TRP) {
+            if (p < nr) { // wave-uniform
+                double tx[TRP], ty[TRP], tz[TRP], tw[TRP][KB];
+#pragma unroll
+                for (int r = 0; r < TRP; ++r) { // sorted source index of the target (wave-uniform: scalar loads)
+                    const int g = jobs.tgt_off + min(r_lo + min(p + r, nr - 1), t1 - 1);
+                    tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) tw[r][k] = (p + r < nr && k < kb) ? ws[k * ldw + g] : 0.0;
+                }
+                for (int j = lane; j < fill; j += 64) {
+                    const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j];
+                    double wj[KB], csum[KB];
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) wj[k] = tile.w[k][j], csum[k] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < TRP; ++r) {
+                        if (p + r < SYM_TR) { // (rows past nr are clamped copies with weight 0; their row sums are dropped)
+                            const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
+                            const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) {
+                                racc[p + r < SYM_TR ? p + r : 0][k] += v * wj[k];
+                                csum[k] += v * tw[r][k];
+                            }
+                        }
+                    }
+                    if (tile.cidx[j] >= 0) {
+#pragma unroll
+                        for (int k = 0; k < KB; ++k)
+                            if (k < kb) unsafeAtomicAdd(&tile.col[k][j], csum[k]);
                     }
                 }
-                if (tile.cidx[j] >= 0) unsafeAtomicAdd(&tile.col[j], csum);
             }
         }
         __syncthreads();
         for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
             const int c = tile.cidx[j];
-            if (c >= 0) unsafeAtomicAdd(&out[c], tile.col[j]);
+            if (c >= 0) {
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                    if (k < kb) unsafeAtomicAdd(&out[k * ldo + c], tile.col[k][j]);
+            }
         }
     }
 #pragma unroll
     for (int r = 0; r < SYM_TR; ++r) {
         if (r < nr) {
-            const double s = wave_sum(racc[r]);
-            if (lane == 0) unsafeAtomicAdd(&out[r_lo + r], s);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (k < kb) {
+                    const double s = wave_sum(racc[r][k]);
+                    if (lane == 0) unsafeAtomicAdd(&out[k * ldo + r_lo + r], s);
+                }
+            }
         }
     }
 }
@@ -929,26 +967,36 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
 //   * column sums stay in registers over all rows of the leaf and leave with one atomic per source and tile; row sums
 //     are reduced per (tile, chunk) through a 4 KB wave-private transpose (8 ds_write_b64, 4 ds_read_b128, 3 DPP
 //     steps) and one atomic per row.
-constexpr int SYM2_R = 8;
+//
+// KB right-hand sides in one pass (round 4; config 4's near field): one kernel evaluation feeds the KB row sums and the
+// KB column sums (15 + 2 KB FP64 instructions per unordered pair for LinearRbf against 2 x (15 + KB) of the ordered-pair
+// kernel) -- the reference evaluates the kernel once per rhs (bbfmm.rs:1162-1251: loop order rhs, target, source); the
+// values are the same, the sums differ in order only.  A column's KB weights and KB sums live in registers like its
+// coordinates; the rows' weights are wave-uniform (SGPR operands), which bounds rows-per-chunk x KB: 8 rows for one
+// rhs, 4 for 2-4, 2 for 5-8.  rhs k reads ws + k * ldw and adds to out + k * ldo; kb <= KB of them are live.
 constexpr int SYM2_CG = 4;
 constexpr int SYM2_WAVES = 4;
 constexpr int SYM2_MAX_ROWS = 256;
+template <int KB> constexpr int sym2_rows() { return KB == 1 ? 8 : (KB <= 4 ? 4 : 2); }
 
-struct Sym2Wave { // wave-private
-    double red[SYM2_R][64];
+template <int NV> struct Sym2Wave { // wave-private
+    double red[NV][64];
     int32_t seg_src[64], seg_off[64], seg_two[64];
 };
 
-template <int KID>
+template <int KID, int KB>
 __global__ __launch_bounds__(64 * SYM2_WAVES) void p2p_sym2_kernel(KernelSpec ks, SymJobs jobs, Xyz src,
-                                                                  const double *__restrict__ ws,
-                                                                  double *__restrict__ out) {
-    __shared__ Sym2Wave lds[SYM2_WAVES];
+                                                                  const double *__restrict__ ws, int64_t ldw, int kb,
+                                                                  double *__restrict__ out, int64_t ldo) {
+    constexpr int R = sym2_rows<KB>();
+    constexpr int NV = R * KB;        // row sums per (tile, chunk): 8 or 16
+    constexpr int LPV = 64 / NV;      // lanes that share the final sum of one of them
+    __shared__ Sym2Wave<NV> lds[SYM2_WAVES];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int job = blockIdx.x * SYM2_WAVES + wave;
     if (job >= jobs.n_jobs) return; // whole wave; no workgroup barrier below
-    Sym2Wave &W = lds[wave];
+    Sym2Wave<NV> &W = lds[wave];
     const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
     int64_t q = jobs.run_range[2 * job];
     const int64_t q1 = jobs.run_range[2 * job + 1];
@@ -987,14 +1035,15 @@ __global__ __launch_bounds__(64 * SYM2_WAVES) void p2p_sym2_kernel(KernelSpec ks
             if (nseg == 0) break; // (empty runs only: cannot happen with the host's lists; never spin)
         }
         // the tile's columns into registers
-        double cx[SYM2_CG], cy[SYM2_CG], cz[SYM2_CG], cw[SYM2_CG], csum[SYM2_CG];
+        double cx[SYM2_CG], cy[SYM2_CG], cz[SYM2_CG], cw[SYM2_CG][KB], csum[SYM2_CG][KB];
         int cidx[SYM2_CG];
 #pragma unroll
         for (int cg = 0; cg < SYM2_CG; ++cg) {
             const int j = cg * 64 + lane;
-            cx[cg] = cy[cg] = cz[cg] = cw[cg] = 0.0; // a padding column: weight 0, its sums are dropped
+            cx[cg] = cy[cg] = cz[cg] = 0.0; // a padding column: weight 0, its sums are dropped
             cidx[cg] = -1;
-            csum[cg] = 0.0;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) cw[cg][k] = csum[cg][k] = 0.0;
             if (j < fill) {
                 int lo = 0, hi = nseg;
                 while (hi - lo > 1) {
@@ -1006,47 +1055,65 @@ __global__ __launch_bounds__(64 * SYM2_WAVES) void p2p_sym2_kernel(KernelSpec ks
                 cx[cg] = src.x[g];
                 cy[cg] = src.y[g];
                 cz[cg] = src.z[g];
-                cw[cg] = ws[g];
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                    if (k < kb) cw[cg][k] = ws[k * ldw + g];
                 cidx[cg] = W.seg_two[lo] ? g - jobs.tgt_off : -1;
             }
         }
         const int ncg = (fill + 63) >> 6; // wave-uniform
-        for (int rb = t0; rb < t1; rb += SYM2_R) {
-            double tx[SYM2_R], ty[SYM2_R], tz[SYM2_R], tw[SYM2_R], racc[SYM2_R];
+        for (int rb = t0; rb < t1; rb += R) {
+            double tx[R], ty[R], tz[R], tw[R][KB], racc[R][KB];
 #pragma unroll
-            for (int r = 0; r < SYM2_R; ++r) {
+            for (int r = 0; r < R; ++r) {
                 const int g = jobs.tgt_off + min(rb + r, t1 - 1); // wave-uniform: scalar loads
                 tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
-                tw[r] = rb + r < t1 ? ws[g] : 0.0;
-                racc[r] = 0.0;
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    tw[r][k] = (rb + r < t1 && k < kb) ? ws[k * ldw + g] : 0.0;
+                    racc[r][k] = 0.0;
+                }
             }
 #pragma unroll
             for (int cg = 0; cg < SYM2_CG; ++cg) {
                 if (cg < ncg) {
 #pragma unroll
-                    for (int r = 0; r < SYM2_R; ++r) {
+                    for (int r = 0; r < R; ++r) {
                         const double dx = tx[r] - cx[cg], dy = ty[r] - cy[cg], dz = tz[r] - cz[cg];
                         const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
-                        racc[r] += v * cw[cg];
-                        csum[cg] += v * tw[r];
+#pragma unroll
+                        for (int k = 0; k < KB; ++k) {
+                            racc[r][k] += v * cw[cg][k];
+                            csum[cg][k] += v * tw[r][k];
+                        }
                     }
                 }
             }
-            // row sums: transpose through the wave's slice, lane l adds 8 of the 64 partial sums of row l >> 3
+            // row sums: transpose through the wave's slice; LPV lanes share one of the NV sums, each adds NV of its 64
+            // partial sums (NV / 2 16-byte reads)
 #pragma unroll
-            for (int r = 0; r < SYM2_R; ++r) W.red[r][lane] = racc[r];
-            const double2 *pr = reinterpret_cast<const double2 *>(&W.red[lane >> 3][(lane & 7) * 8]);
-            const double2 a0 = pr[0], a1 = pr[1], a2 = pr[2], a3 = pr[3];
-            double sum = ((a0.x + a0.y) + (a1.x + a1.y)) + ((a2.x + a2.y) + (a3.x + a3.y));
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 4, 64);
-            const int row = rb + (lane >> 3);
-            if ((lane & 7) == 0 && row < t1) unsafeAtomicAdd(&out[row], sum);
+            for (int r = 0; r < R; ++r)
+#pragma unroll
+                for (int k = 0; k < KB; ++k) W.red[r * KB + k][lane] = racc[r][k];
+            const double2 *pr = reinterpret_cast<const double2 *>(&W.red[lane / LPV][(lane % LPV) * NV]);
+            double sum = 0.0;
+#pragma unroll
+            for (int i = 0; i < NV / 2; i += 2) {
+                const double2 a0 = pr[i], a1 = pr[i + 1];
+                sum += (a0.x + a0.y) + (a1.x + a1.y);
+            }
+#pragma unroll
+            for (int off = 1; off < LPV; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            const int v = lane / LPV, row = rb + v / KB, k = v % KB;
+            if (lane % LPV == 0 && row < t1 && k < kb) unsafeAtomicAdd(&out[k * ldo + row], sum);
         }
 #pragma unroll
         for (int cg = 0; cg < SYM2_CG; ++cg)
-            if (cg < ncg && cidx[cg] >= 0) unsafeAtomicAdd(&out[cidx[cg]], csum[cg]);
+            if (cg < ncg && cidx[cg] >= 0) {
+#pragma unroll
+                for (int k = 0; k < KB; ++k)
+                    if (k < kb) unsafeAtomicAdd(&out[k * ldo + cidx[cg]], csum[cg][k]);
+            }
     }
 }
 
@@ -1153,14 +1220,19 @@ struct WxJobs {
     const int32_t *w_cells;
 };
 
-template <int KID>
+// KB right-hand sides per pass like p2p_sym_kernel: rhs k reads ws + k * ldw and M + k * C * n_pad, adds to
+// out + k * ldo and L + k * C * n_pad.
+template <int KID, int KB>
 __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, WxJobs jobs, const DevCheb *__restrict__ chp,
                                                                const double *__restrict__ centers,
                                                                const double *__restrict__ lengths, Xyz src,
-                                                               const double *__restrict__ ws, const double *__restrict__ M,
-                                                               double *__restrict__ L, double *__restrict__ out, int out_off,
-                                                               int out_n) {
-    __shared__ SymTile tile;
+                                                               const double *__restrict__ ws, int64_t ldw, int kb,
+                                                               const double *__restrict__ M, double *__restrict__ L,
+                                                               int64_t ld_ml, double *__restrict__ out, int64_t ldo,
+                                                               int out_off, int out_n) {
+    constexpr int T = sym_tile<KB>();
+    constexpr int TRP = sym_rows_pass<KB>();
+    __shared__ SymTile<KB> tile;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int job = blockIdx.x;
@@ -1171,17 +1243,15 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, W
     const int rpw = (t1 - t0 + SYM_WAVES - 1) / SYM_WAVES;
     const int r_lo = min(t0 + wave * rpw, t1);
     const int nr = min(rpw, t1 - r_lo);
-    double tx[SYM_TR], ty[SYM_TR], tz[SYM_TR], tw[SYM_TR], racc[SYM_TR];
+    double racc[SYM_TR][KB];
 #pragma unroll
-    for (int r = 0; r < SYM_TR; ++r) {
-        const int g = min(r_lo + min(r, max(nr - 1, 0)), t1 - 1);
-        tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g], tw[r] = ws[g];
-        racc[r] = 0.0;
-    }
+    for (int r = 0; r < SYM_TR; ++r)
+#pragma unroll
+        for (int k = 0; k < KB; ++k) racc[r][k] = 0.0;
     const int64_t q0 = jobs.w_range[2 * job], q1 = jobs.w_range[2 * job + 1];
     const int64_t total = (q1 - q0) * n;
-    for (int64_t base = 0; base < total; base += SYM_TILE) {
-        const int fill = static_cast<int>(min<int64_t>(SYM_TILE, total - base));
+    for (int64_t base = 0; base < total; base += T) {
+        const int fill = static_cast<int>(min<int64_t>(T, total - base));
         __syncthreads();
         for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
             const int64_t P = base + j;
@@ -1192,38 +1262,68 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, W
             tile.x[j] = centers[cell * 3] + half * chp->nodes[i0];
             tile.y[j] = d > 1 ? centers[cell * 3 + 1] + half * chp->nodes[i1] : 0.0;
             tile.z[j] = d > 2 ? centers[cell * 3 + 2] + half * chp->nodes[i2] : 0.0;
-            tile.w[j] = M[static_cast<int64_t>(cell) * n_pad + I];
-            tile.col[j] = 0.0;
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                tile.w[k][j] = k < kb ? M[k * ld_ml + static_cast<int64_t>(cell) * n_pad + I] : 0.0;
+                tile.col[k][j] = 0.0;
+            }
             tile.cidx[j] = cell * n_pad + I;
         }
         __syncthreads();
-        if (nr > 0) {
-            for (int j = lane; j < fill; j += 64) {
-                const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j], wj = tile.w[j];
-                double csum = 0.0;
 #pragma unroll
-                for (int r = 0; r < SYM_TR; ++r) {
-                    if (r < nr) {
-                        const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
-                        const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
-                        racc[r] += v * wj;
-                        csum += v * tw[r];
-                    }
+        for (int pp = 0; pp < SYM_TR; pp += TRP) {
+            if (pp < nr) { // wave-uniform
+                double tx[TRP], ty[TRP], tz[TRP], tw[TRP][KB];
+#pragma unroll
+                for (int r = 0; r < TRP; ++r) {
+                    const int g = min(r_lo + min(pp + r, nr - 1), t1 - 1);
+                    tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) tw[r][k] = (pp + r < nr && k < kb) ? ws[k * ldw + g] : 0.0;
                 }
-                unsafeAtomicAdd(&tile.col[j], csum);
+                for (int j = lane; j < fill; j += 64) {
+                    const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j];
+                    double wj[KB], csum[KB];
+#pragma unroll
+                    for (int k = 0; k < KB; ++k) wj[k] = tile.w[k][j], csum[k] = 0.0;
+#pragma unroll
+                    for (int r = 0; r < TRP; ++r) {
+                        if (pp + r < SYM_TR) { // (rows past nr: clamped copies with weight 0, their row sums are dropped)
+                            const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
+                            const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
+#pragma unroll
+                            for (int k = 0; k < KB; ++k) {
+                                racc[pp + r < SYM_TR ? pp + r : 0][k] += v * wj[k];
+                                csum[k] += v * tw[r][k];
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < KB; ++k)
+                        if (k < kb) unsafeAtomicAdd(&tile.col[k][j], csum[k]);
+                }
             }
         }
         __syncthreads();
-        for (int j = tid; j < fill; j += 64 * SYM_WAVES) unsafeAtomicAdd(&L[tile.cidx[j]], tile.col[j]);
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
+#pragma unroll
+            for (int k = 0; k < KB; ++k)
+                if (k < kb) unsafeAtomicAdd(&L[k * ld_ml + tile.cidx[j]], tile.col[k][j]);
+        }
     }
 #pragma unroll
     for (int r = 0; r < SYM_TR; ++r) {
         if (r < nr) {
-            const double s = wave_sum(racc[r]);
             // (a partition's output holds its own rows only: out_off = first owned row; the rows of a leaf outside are
             // here for their column sums -- P2L into the partition's cells -- alone)
             const int o = r_lo + r - out_off;
-            if (lane == 0 && o >= 0 && o < out_n) unsafeAtomicAdd(&out[o], s);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) {
+                if (k < kb) {
+                    const double s = wave_sum(racc[r][k]);
+                    if (lane == 0 && o >= 0 && o < out_n) unsafeAtomicAdd(&out[k * ldo + o], s);
+                }
+            }
         }
     }
 }
@@ -1402,11 +1502,6 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
     // 2 x { operator [e][ng][k*16 + col], IN tile [wave][tg][eh][k][j] x 2 }; stage 1 adds the slot
     // lookups of the current column block, [wave][cell 0..15][slot_t] int32
     extern __shared__ double lds[];
-    // experiment switches of stage 1 ride in the high bits of slot_t (profiles/: where the store tail goes)
-    const bool s1_no_store = STAGE == 1 && (slot_t & (1 << 30)) != 0, s1_nt_store = STAGE == 1 && (slot_t & (1 << 29)) != 0;
-    // timing-only switches of the per-step synchronisation (wrong results): no wait for the DMA / no workgroup barrier
-    const bool dbg_nowait = (slot_t & (1 << 28)) != 0, dbg_nobar = (slot_t & (1 << 27)) != 0;
-    slot_t &= 0xffff;
     const M2lTileDesc tile = tiles[blockIdx.x];
     const M2lClass cls = classes[tile.level_class];
     const int kr = blockIdx.y;
@@ -1606,21 +1701,13 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                         const int sl = srow[max(pk[pr] >> 24, 0)];
                         const int okm = (spv ? -1 : 0) & ~(pk[pr] | sl); // sign bit set: valid cell, row, slot
                         double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[pr] & 0xffffff) : dump;
-                        if (s1_nt_store) {
-                            typedef double d2v __attribute__((ext_vector_type(2)));
-                            d2v val;
-                            val.x = acc[tg][2 * pr];
-                            val.y = acc[tg][2 * pr + 1];
-                            __builtin_nontemporal_store(val, reinterpret_cast<d2v *>(dst));
-                        } else if (!s1_no_store) {
-                            *reinterpret_cast<double2 *>(dst) = make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
-                        }
+                        *reinterpret_cast<double2 *>(dst) = make_double2(acc[tg][2 * pr], acc[tg][2 * pr + 1]);
                     }
                     if (NS) {
                         const int sl = srow[max(pk[NP] >> 24, 0)];
                         const int okm = (spv ? -1 : 0) & ~(pk[NP] | sl);
                         double *dst = okm < 0 ? cb + (int64_t)sl * 2 + (pk[NP] & 0xffffff) : dump;
-                        if (!s1_no_store) *dst = acc[tg][NG16 - 1];
+                        *dst = acc[tg][NG16 - 1];
                     }
                 }
             } else if (STAGE >= 2) {
@@ -1660,9 +1747,7 @@ __global__ __launch_bounds__(512, MINW) void m2l_gemm_k4(const M2lClass *__restr
                 continue;
             }
         }
-        if (dbg_nowait) __syncthreads();
-        else if (dbg_nobar) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else wait_dma_and_barrier();
+        wait_dma_and_barrier();
     }
 }
 
@@ -1871,21 +1956,34 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
     });
 }
 
+// K right-hand sides in passes of at most eight (kernel instances for 1, 2, 4 and 8; three, and five to seven, run
+// the next instance up with the spare slots idle).
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
                     const int64_t *run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
                     const int64_t *w_run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
-                    const double *w_sorted, double *out_sorted, hipStream_t s) {
+                    const double *w_sorted, int64_t ldw, int K, double *out_sorted, int64_t ldo, hipStream_t s) {
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
-        if (n_wave_jobs > 0) {
-            const SymJobs jobs{n_wave_jobs, w_tgt_begin, w_tgt_end, w_run_range, runs3, tgt_off};
-            hipLaunchKernelGGL((p2p_sym2_kernel<ID>), dim3((n_wave_jobs + SYM2_WAVES - 1) / SYM2_WAVES), dim3(64 * SYM2_WAVES), 0, s,
-                               ks, jobs, make_xyz(src_xyz), w_sorted, out_sorted);
-        }
-        if (n_jobs > 0) {
-            const SymJobs jobs{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
-            hipLaunchKernelGGL((p2p_sym_kernel<ID>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, make_xyz(src_xyz),
-                               w_sorted, out_sorted);
+        for (int k0 = 0; k0 < K; k0 += kSymMaxRhs) {
+            const int kb = std::min(kSymMaxRhs, K - k0);
+            const double *w = w_sorted + static_cast<int64_t>(k0) * ldw;
+            double *o = out_sorted + static_cast<int64_t>(k0) * ldo;
+            const SymJobs wj{n_wave_jobs, w_tgt_begin, w_tgt_end, w_run_range, runs3, tgt_off};
+            const SymJobs gj{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
+#define SYM_GO(KBV)                                                                                                   \
+    do {                                                                                                              \
+        if (n_wave_jobs > 0)                                                                                          \
+            hipLaunchKernelGGL((p2p_sym2_kernel<ID, KBV>), dim3((n_wave_jobs + SYM2_WAVES - 1) / SYM2_WAVES),          \
+                               dim3(64 * SYM2_WAVES), 0, s, ks, wj, make_xyz(src_xyz), w, ldw, kb, o, ldo);           \
+        if (n_jobs > 0)                                                                                               \
+            hipLaunchKernelGGL((p2p_sym_kernel<ID, KBV>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, gj,            \
+                               make_xyz(src_xyz), w, ldw, kb, o, ldo);                                                \
+    } while (0)
+            if (kb == 1) SYM_GO(1);
+            else if (kb == 2) SYM_GO(2);
+            else if (kb <= 4) SYM_GO(4);
+            else SYM_GO(8);
+#undef SYM_GO
         }
     });
 }
@@ -1907,14 +2005,25 @@ int wx_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
 
 void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
                    const int64_t *w_range, const int32_t *w_cells, const double *centers, const double *lengths,
-                   const double *const *src_xyz, const double *w_sorted, const double *M, double *L, double *out_sorted,
-                   int out_off, int out_n, hipStream_t s) {
+                   const double *const *src_xyz, const double *w_sorted, int64_t ldw, int K, const double *M, double *L,
+                   int64_t ld_ml, double *out_sorted, int64_t ldo, int out_off, int out_n, hipStream_t s) {
     if (n_jobs == 0) return;
     const WxJobs jobs{n_jobs, tgt_begin, tgt_end, w_range, w_cells};
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
-        hipLaunchKernelGGL((wx_sym_kernel<ID>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, ch.dev, centers, lengths,
-                           make_xyz(src_xyz), w_sorted, M, L, out_sorted, out_off, out_n);
+        for (int k0 = 0; k0 < K; k0 += kSymMaxRhs) {
+            const int kb = std::min(kSymMaxRhs, K - k0);
+#define WX_GO(KBV)                                                                                                    \
+    hipLaunchKernelGGL((wx_sym_kernel<ID, KBV>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, ch.dev, centers,    \
+                       lengths, make_xyz(src_xyz), w_sorted + static_cast<int64_t>(k0) * ldw, ldw, kb,                 \
+                       M + static_cast<int64_t>(k0) * ld_ml, L + static_cast<int64_t>(k0) * ld_ml, ld_ml,               \
+                       out_sorted + static_cast<int64_t>(k0) * ldo, ldo, out_off, out_n)
+            if (kb == 1) WX_GO(1);
+            else if (kb == 2) WX_GO(2);
+            else if (kb <= 4) WX_GO(4);
+            else WX_GO(8);
+#undef WX_GO
+        }
     });
 }
 
@@ -1975,38 +2084,17 @@ static void m2l_gemm_launch(const M2lClass *classes, const M2lTileDesc *tiles, i
         if (dev >= 0 && dev < 256) attr_set[dev >> 6].fetch_or(uint64_t(1) << (dev & 63), std::memory_order_release);
     }
     const int zdim = STAGE == 2 && slot_t > 1 ? n_colblocks * slot_t : n_colblocks; // stage 2: slot_t = parts of the contraction
-    // BBFMM_M2L_DEBUG_SYNC=nowait | nobar: the per-step DMA wait / workgroup barrier left out (timing only, wrong results)
-    static const int sync_flags = [] {
-        const char *e = std::getenv("BBFMM_M2L_DEBUG_SYNC");
-        if (!e) return 0;
-        return std::string(e) == "nowait" ? (1 << 28) : std::string(e) == "nobar" ? (1 << 27) : 0;
-    }();
     hipLaunchKernelGGL((m2l_gemm_k4<NG16, STAGE, MINW>), dim3(n_tiles, K, zdim), dim3(512), lds, s, classes,
-                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t | sync_flags, tile_idx);
+                       tiles, n_pad, g16_0, C, in, in_len, out, out_len, qlist, slot_t, tile_idx);
 }
 
 // Column-chunk plan: 16-column groups per workgroup.  Stage 1 walks column blocks of kM2lS1Block =
 // 11 groups (44 accumulators per lane; 22 spills in the persistent walk).  Stage 2 covers the n_pad
 // output nodes with 22-group chunks (88 accumulators, one workgroup per CU), measured faster there
-// than 11 or 8; BBFMM_M2L_NG16_S2 overrides for experiments.
-template <int STAGE> static int m2l_chunk_pref() {
-    if (STAGE == 1) return kM2lS1Block / 16;
-    static const int v = [] {
-        const char *e = std::getenv("BBFMM_M2L_NG16_S2");
-        const int x = e ? std::atoi(e) : 22;
-        return (x == 8 || x == 11 || x == 22) ? x : 22;
-    }();
-    return v;
-}
+// than 11 or 8.
 
-static int m2l_s2_ksplit_fill() { // workgroups per CU up to which stage 2 keeps splitting the contraction
-    static const int v = [] {
-        const char *e = std::getenv("BBFMM_M2L_S2_KSPLIT_FILL");
-        const int x = e ? std::atoi(e) : 4;
-        return x >= 1 && x <= 64 ? x : 4;
-    }();
-    return v;
-}
+template <int STAGE> constexpr int m2l_chunk_pref() { return STAGE == 1 ? kM2lS1Block / 16 : 22; }
+constexpr int kM2lS2KsplitFill = 4; // workgroups per CU up to which stage 2 keeps splitting the contraction
 
 template <int STAGE>
 static void m2l_dispatch_chunks(int total_groups, const M2lClass *classes, const M2lTileDesc *tiles, int n_tiles,
@@ -2088,37 +2176,24 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
     while (slot_t < max_slot_t) slot_t *= 2;
     // every workgroup walks its share of the column blocks; splitting the walk over gridDim.z
     // workgroups shortens the last, partially filled round of the launch
-    static const int zsplit_env = [] {
-        const char *e = std::getenv("BBFMM_M2L_ZSPLIT");
-        const int v = e ? std::atoi(e) : 0;
-        return v >= 1 && v <= 16 ? v : 0;
-    }();
     const int n_cu = device_cu_count();
     // One workgroup per CU at a time: n_tiles * z workgroups take ceil(n_tiles * z / CUs) rounds of 1/z of the
     // column-block walk each; z is chosen so that the last, partially filled round is short (a per-workgroup
     // overhead of about half a percent of a walk keeps z small).  Measured at 10M points (2,336 tiles): z = 2 18.2 ms,
     // 3 18.0, 4 17.75, 7 18.0, 13 18.3.
-    int zsplit = zsplit_env;
-    if (zsplit == 0) {
-        double best = 1e300;
-        for (int z = 1; z <= 8; ++z) {
-            const double rounds = std::ceil(static_cast<double>(n_tiles) * z / n_cu);
-            const double cost = rounds / z * (1.0 + 0.005 * z);
-            if (cost < best - 1e-12) {
-                best = cost;
-                zsplit = z;
-            }
+    int zsplit = 1;
+    double best = 1e300;
+    for (int z = 1; z <= 8; ++z) {
+        const double rounds = std::ceil(static_cast<double>(n_tiles) * z / n_cu);
+        const double cost = rounds / z * (1.0 + 0.005 * z);
+        if (cost < best - 1e-12) {
+            best = cost;
+            zsplit = z;
         }
     }
     const int n_colblocks = own_blocks ? 1 : zsplit; // tiles that name their own blocks are not split further
-    // BBFMM_M2L_S1_STORES=off | nt: experiments on the scatter stores (off: results are wrong; for timing only)
-    static const int store_flags = [] {
-        const char *e = std::getenv("BBFMM_M2L_S1_STORES");
-        if (!e) return 0;
-        return std::string(e) == "off" ? (1 << 30) : std::string(e) == "nt" ? (1 << 29) : 0;
-    }();
     m2l_dispatch_chunks<1>(kM2lS1Block / 16, classes, tiles, n_tiles, n_pad, n_colblocks, K, C, M, 0, cbuf, cbuf_len, nullptr,
-                           slot_t | store_flags, tile_idx, s);
+                           slot_t, tile_idx, s);
 }
 
 // Stage 2: the output nodes (n_pad, in groups of 16; n_pad is a multiple of 32) in column chunks.
@@ -2152,7 +2227,7 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
         const int n_cu = device_cu_count();
         const int64_t wgs = static_cast<int64_t>(n_tiles) * z * K;
         ksplit = 1;
-        while (ksplit < 16 && wgs * ksplit * 2 <= static_cast<int64_t>(m2l_s2_ksplit_fill()) * n_cu) ksplit *= 2;
+        while (ksplit < 16 && wgs * ksplit * 2 <= static_cast<int64_t>(kM2lS2KsplitFill) * n_cu) ksplit *= 2;
     }
     m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, z, K, C, cbuf, cbuf_len, L, 0, qlist, ksplit > 1 ? ksplit : 0, tile_idx, s);
 }

@@ -1041,11 +1041,6 @@ int FmmTree::build_m2l_tables() {
     // launch lists, batch by batch: stage 1 from the per-batch lists, stage 2 = the class tiles (classes of a batch
     // are consecutive) with the tail of every batch split
     m2l_tiles2_h_.clear();
-    const bool unrestricted_blocks = [] {
-        const char *e = std::getenv("BBFMM_M2L_S1_BLOCK_TILES");
-        return e && std::atoi(e) != 0;
-    }();
-    m2l_s1_block_tiles_ = unrestricted_blocks;
     {
         size_t next = 0;
         for (size_t b = 0; b < m2l_batches_.size(); ++b) {
@@ -1053,25 +1048,7 @@ int FmmTree::build_m2l_tables() {
             mb.t1_first = static_cast<int32_t>(m2l_tiles1_h_.size());
             for (M2lTileDesc td : tiles1_of_batch[b]) {
                 if (td.level_class < 0) td.level_class = static_cast<int32_t>(m2l_host_.size()) + (-1 - td.level_class);
-                if (!unrestricted_blocks) {
-                    m2l_tiles1_h_.push_back(td);
-                    continue;
-                }
-                // experiment (BBFMM_M2L_S1_BLOCK_TILES=1): one tile per column block instead of one persistent walk
-                const bool variant = static_cast<size_t>(td.level_class) >= m2l_host_.size();
-                const HostM2lClass &hc = variant ? m2l_variants_[static_cast<size_t>(td.level_class) - m2l_host_.size()]
-                                                 : m2l_host_[static_cast<size_t>(td.level_class)];
-                if (td.pad == 0) { // contiguous positions: spell them out
-                    const int32_t first = td.first;
-                    td.first = static_cast<int32_t>(m2l_tile_idx1_h_.size());
-                    for (int32_t q = 0; q < td.count; ++q) m2l_tile_idx1_h_.push_back(first + q);
-                }
-                td.pad = 2;
-                td.q_count = 1;
-                for (int zb = 0; zb < hc.r_pad16 / kM2lS1Block; ++zb) {
-                    td.q_first = zb;
-                    m2l_tiles1_h_.push_back(td);
-                }
+                m2l_tiles1_h_.push_back(td);
             }
             mb.t1_count = static_cast<int32_t>(m2l_tiles1_h_.size()) - mb.t1_first;
             std::vector<M2lTileDesc> part;
@@ -1539,10 +1516,6 @@ int FmmTree::build_shared_basis(std::vector<DevBuf<double>> *d_level_ops) {
     if (max_rank == 0) return fail(BBFMM_BAD_ARGUMENT, "shared basis: no M2L level");
     basis_pad_ = round_up(max_rank, 16);
     if (((basis_pad_ / 16) & 1) && basis_pad_ / 16 != 7) basis_pad_ += 16; // column-group plans: even counts, or 7
-    if (const char *e = std::getenv("BBFMM_BASIS_PAD")) { // experiments: a wider (zero-padded) coordinate vector
-        const int v = std::atoi(e);
-        if (v >= basis_pad_ && v % 32 == 0) basis_pad_ = v;
-    }
     basis_pad_ = std::min(basis_pad_, n_pad);
     if (basis_pad_ * 5 > n_pad * 3) { // the union of the operators fills most of the node space (e.g. Spheroidal3 with a
         // short range): the stages would not get cheaper -- the handle keeps the reference's arithmetic
@@ -2151,7 +2124,7 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
                                   m2l_len, m2l_slot_t_, kb, C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, true);
             } else
                 launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p + t1_first, d_tile_idx1_.p, t1_count, m2l_len, m2l_slot_t_, kb, C,
-                                  m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, m2l_s1_block_tiles_);
+                                  m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, false);
             phase_end(kPhM2L1);
             phase_begin();
             if (dp)
@@ -2169,10 +2142,10 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
         phase_end(kPhM2L2);
     }
     phase_begin();
-    if (t.adaptive && wx) { // targets = all sources, one rhs: P2L and M2P share their kernel evaluations (X = W^T)
+    if (t.adaptive && wx) { // targets = all sources: P2L and M2P share their kernel evaluations (X = W^T)
         launch_wx_sym(kernel_, cheb_, wx->n_wx_jobs, wx->wx_tb.p, wx->wx_te.p, wx->wx_range.p, d_w_idx_.p, d_centers_.p,
-                      d_lengths_.p, src_ptr_, d_w_sorted_.p, d_M_.p, d_L_.p, wx->out.p, wx->sym_off, static_cast<int>(wx->m),
-                      stream_);
+                      d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, d_M_.p, d_L_.p, C * cheb_.n_pad, wx->out.p,
+                      static_cast<int64_t>(wx->m), wx->sym_off, static_cast<int>(wx->m), stream_);
     } else if (t.adaptive) {
         if (dp)
             launch_p2l(kernel_, cheb_, dp->n_x_jobs, dp->d_x_cells.p, dp->d_x_ptr.p, dp->d_x_runs.p, d_centers_.p,
@@ -2218,9 +2191,9 @@ int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStre
             return !e || std::atoi(e) != 0;
         }();
         if (timed) phase_begin();
-        if (ts.sym && sym_on && !deterministic_ && !with_grads && k == 1) // targets = sources, one rhs: every unordered pair once
+        if (ts.sym && sym_on && !deterministic_ && !with_grads) // targets = sources: every unordered pair once, for all rhs
             launch_p2p_sym(kernel_, ts.n_sym_jobs, ts.sym_tb.p, ts.sym_te.p, ts.sym_ptr.p, ts.n_symw_jobs, ts.symw_tb.p, ts.symw_te.p,
-                           ts.symw_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_, d_w_sorted_.p, ts.out.p, st);
+                           ts.symw_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, ts.m, st);
         else
             launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
         if (timed) phase_end(kPhP2P);
@@ -2373,11 +2346,11 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
         const char *e2 = std::getenv("BBFMM_P2P_SYM");
         return (!e || std::atoi(e) != 0) && (!e2 || std::atoi(e2) != 0);
     }();
-    const bool wx = wx_on && !deterministic_ && k == 1 && !have_part_ && ts.sym && ts.n_wx_jobs > 0;
+    const bool wx = wx_on && !deterministic_ && !have_part_ && ts.sym && ts.n_wx_jobs > 0;
     // (a partitioned handle called on its own, without the exchange of matvec_partition_upward / _finish,
     // needs every multipole: the whole upward pass)
     CHK(upward(k, nullptr));
-    if (wx) HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(ts.m) * sizeof(double), stream_));
+    if (wx) HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), stream_));
     CHK(downward(k, plan, wx ? &ts : nullptr));
     CHK(leaf_pass_near(ts, k, false, stream_, 3, wx));
     CHK(leaf_pass_far(ts, k, false));
@@ -2459,7 +2432,7 @@ int FmmTree::partition_finish_core(const double *d_coarse, hipStream_t comm_stre
     }();
     // one rhs: M2P of the owned targets and P2L into the subtree's cells share their kernel evaluations, as in the
     // unpartitioned matvec (the outputs were zeroed and P2P ran in the first half; the fused pass adds to them)
-    const bool wx = wx_on && !deterministic_ && k == 1 && ts.sym && ts.n_wx_jobs > 0;
+    const bool wx = wx_on && !deterministic_ && ts.sym && ts.n_wx_jobs > 0;
     CHK(downward(k, &part_plan_, wx ? &ts : nullptr));
     CHK(leaf_pass_near(ts, k, false, stream_, 2, wx)); // M2P unless the fused pass has done it
     CHK(leaf_pass_far(ts, k, false));
@@ -2762,16 +2735,11 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
     // 5.34 / 2.94; per-block tiles throughout 9.75 / 6.72 / 5.12 / 2.72 -- thousands of short tiles leave no launch
     // tail, and a persistent walk over the blocks buys almost nothing (the unrestricted 10M-point stage 1 as per-block
     // tiles: 17.25 against 17.14 ms).  The analysis runs for partitions and for target sets under half of the cells;
-    // denser sets take whole operators.  BBFMM_M2L_SPARSE_RATIO = r: cells needing at least r of their blocks go
-    // into whole-operator tiles (0: whole operators only; default 2 = per-block tiles only).
+    // denser sets take whole operators.
     std::vector<std::vector<M2lTileDesc>> t1s(nb); // per-block tiles
     int64_t n_active = 0;
     for (uint8_t a : active) n_active += a;
-    static const double full_ratio = [] {
-        const char *e = std::getenv("BBFMM_M2L_SPARSE_RATIO");
-        return e ? std::atof(e) : 2.0;
-    }();
-    const bool analyse = full_ratio > 0.0 && (restrict_upward || n_active * 2 < C);
+    const bool analyse = restrict_upward || n_active * 2 < C;
     if (!analyse) {
         for (const SrcOp &so : sops)
             add_tiles(needed, so.bit, so.dev_class, so.h->cells, &t1b[static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(so.dev_class)])]);
@@ -2812,32 +2780,12 @@ int FmmTree::build_downward_plan(const std::vector<int32_t> &target_leaves, Down
             const int64_t nc = static_cast<int64_t>(hs.cells.size());
             const int n_blk = hs.r_pad16 / kM2lS1Block;
             const size_t bidx = static_cast<size_t>(m2l_batch_of_class_[static_cast<size_t>(sops[si].dev_class)]);
-            // whole-operator cells
-            std::vector<uint8_t> whole(static_cast<size_t>(nc), 0);
-            const size_t start_full = dp->tile_idx_h.size();
-            for (int64_t i = 0; i < nc; ++i) {
-                int cnt = 0;
-                for (int zb = 0; zb < n_blk; ++zb) cnt += bm[static_cast<size_t>(bm_off[si] + zb * nc + i)];
-                if (cnt > 0 && static_cast<double>(cnt) >= full_ratio * n_blk) {
-                    whole[static_cast<size_t>(i)] = 1;
-                    dp->tile_idx_h.push_back(static_cast<int32_t>(i));
-                }
-            }
-            for (size_t fst = start_full; fst < dp->tile_idx_h.size(); fst += kM2lTile) {
-                M2lTileDesc td;
-                std::memset(&td, 0, sizeof td);
-                td.level_class = sops[si].dev_class;
-                td.first = static_cast<int32_t>(fst);
-                td.count = static_cast<int32_t>(std::min<size_t>(kM2lTile, dp->tile_idx_h.size() - fst));
-                td.pad = 1;
-                t1b[bidx].push_back(td);
-            }
-            // the rest, block by block
+            // one tile per (column block, up to 128 of the sources that need it)
             for (int zb = 0; zb < n_blk; ++zb) {
                 const size_t start = dp->tile_idx_h.size();
                 const uint8_t *f = &bm[static_cast<size_t>(bm_off[si] + zb * nc)];
                 for (int64_t i = 0; i < nc; ++i)
-                    if (f[i] && !whole[static_cast<size_t>(i)]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
+                    if (f[i]) dp->tile_idx_h.push_back(static_cast<int32_t>(i));
                 for (size_t fst = start; fst < dp->tile_idx_h.size(); fst += kM2lTile) {
                     M2lTileDesc td;
                     std::memset(&td, 0, sizeof td);

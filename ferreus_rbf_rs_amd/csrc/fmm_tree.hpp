@@ -287,7 +287,6 @@ class FmmTree {
     int64_t cbuf_total_len_ = 0;                       // sum of all slots (what one unbounded buffer would hold)
     int64_t m2l_budget_bytes_ = int64_t(16384) << 20;
     int m2l_rhs_chunk_ = 1;
-    bool m2l_s1_block_tiles_ = false; // experiment: the unrestricted stage 1 as one tile per column block
     double m2l_flops_k1_ = 0;
     int n_cu_ = 256;      // compute units of the device (tail splitting of the tile lists)
     int device_ = -1;     // the HIP device that was current in create(): every entry point binds its thread to it

@@ -252,11 +252,14 @@ def test_independent_operators_on_a_mixed_level_tree(kid, order, br, sill, tol):
 
 
 @pytest.mark.parametrize("kid,d,mpc,nrhs", [(0, 3, 256, 1), (1, 3, 256, 2), (3, 3, 20, 1), (7, 3, 256, 3), (2, 2, 256, 1),
-                                           (0, 1, 64, 1)])
+                                           (0, 1, 64, 1), (0, 3, 256, 5), (0, 3, 40, 8), (3, 3, 256, 8), (1, 3, 64, 11),
+                                           (2, 2, 30, 4)])
 def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs):
     """The matvec evaluates every unordered near-field pair once (launch_p2p_sym); `evaluate` at the same points
     goes through the ordered-pair kernel the reference's loops correspond to (bbfmm.rs:1162-1251).  Leaves of up
-    to 256 points (several register groups per wave, several source tiles per leaf) and of a few points."""
+    to 256 points (several register groups per wave, several source tiles per leaf) and of a few points.  Round 4:
+    up to eight right-hand sides share one kernel evaluation per unordered pair (kernel instances for 1, 2, 4, 8; three
+    and five to seven run the next instance up; eleven = eight + three), in the near field and in the fused M2P + P2L."""
     import torch
     rng = np.random.default_rng(600 + kid + d)
     n = 150000 if d == 3 else 40000
@@ -273,7 +276,7 @@ def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs):
     out = torch.zeros((nrhs, n), dtype=torch.float64, device="cuda")
     t.matvec_device(dw.data_ptr(), n, nrhs, out.data_ptr(), n, True)
     y_sym = out.cpu().numpy().T
-    L_sym = t.debug_get_coefficients("L", nrhs)          # one rhs: P2L ran fused with M2P (X = W^T), atomically into L
+    L_sym = t.debug_get_coefficients("L", nrhs)          # P2L ran fused with M2P (X = W^T), atomically into L
     t.set_weights(w)
     y_ord = t.evaluate(w, pts)
     r.set_weights(w)
