@@ -290,8 +290,8 @@ PAIR_FLOPS = {"LinearRbf": 3 * 3 - 1 + 1 + 1 + 2, "ThinPlateSplineRbf": 3 * 3 - 
               "Spheroidal3Rbf": 3 * 3 - 1 + 1 + 6 + 2, "MultiquadricExt": 3 * 3 - 1 + 1 + 2 + 2}
 
 # right-hand sides the unordered-pair kernels (near field; fused M2P + P2L) take in one pass (device.hpp kSymMaxRhs);
-# kernel instances exist for 1, 2, 4 and 8 -- 3 and 5-7 run the next instance up with idle slots
-SYM_MAX_RHS = 8
+# kernel instances exist for 1, 2 and 4 -- 3 runs the 4-slot instance with an idle slot
+SYM_MAX_RHS = 4
 
 
 def sym_instances(K):
@@ -299,7 +299,7 @@ def sym_instances(K):
     out = []
     for k0 in range(0, K, SYM_MAX_RHS):
         kb = min(SYM_MAX_RHS, K - k0)
-        out.append(1 if kb == 1 else 2 if kb == 2 else 4 if kb <= 4 else 8)
+        out.append(1 if kb == 1 else 2 if kb == 2 else 4)
     return out
 
 
@@ -335,7 +335,7 @@ def committed_pair_instructions():
 def pair_issue(stats, N, K, kernel, phase):
     """(kernel evaluations executed, FP64 VALU instructions per evaluation, instruction-count file) of a pair phase
     of the matvec -- P2P, P2L (= M2P + P2L fused) -- or None.  The unordered kernels evaluate every pair once per
-    pass of up to eight right-hand sides and feed the row sum and the column sum of each rhs slot from it; the count
+    pass of up to four right-hand sides and feed the row sum and the column sum of each rhs slot from it; the count
     of the probe is for one rhs, both sums (2)."""
     instr = committed_pair_instructions()
     if not instr or kernel not in instr.get("kernels", {}):

@@ -788,8 +788,8 @@ constexpr int SYM_TILE = 768;
 constexpr int SYM_TR = 6;
 constexpr int SYM_WAVES = 8;
 constexpr int SYM_SEG = 64; // runs packed into one tile at most
-template <int KB> constexpr int sym_tile() { return KB <= 2 ? SYM_TILE : (KB <= 4 ? SYM_TILE / 2 : SYM_TILE / 3); }
-template <int KB> constexpr int sym_rows_pass() { return KB == 1 ? SYM_TR : (KB <= 4 ? 3 : 2); }
+template <int KB> constexpr int sym_tile() { return KB <= 2 ? SYM_TILE : SYM_TILE / 2; }
+template <int KB> constexpr int sym_rows_pass() { return KB == 1 ? SYM_TR : 3; }
 
 struct SymJobs {
     int n_jobs;
@@ -807,6 +807,10 @@ template <int KB> struct SymTile {
     int32_t fill, nseg, next_pos;
     int64_t next_q;
 };
+
+// The value is loaded whatever the flag says (a load inside `flag ? load : 0` sits behind a branch of its own, and a
+// chunk's dozen scalar loads then wait for one another instead of going out together).
+__device__ inline double keep_if(bool keep, double loaded) { return keep ? loaded : 0.0; }
 
 __device__ inline double wave_sum(double v) {
 #pragma unroll
@@ -888,7 +892,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
             tile.z[j] = src.z[g];
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                tile.w[k][j] = k < kb ? ws[k * ldw + g] : 0.0;
+                tile.w[k][j] = ws[min(k, kb - 1) * ldw + g]; // (idle slots repeat the last rhs; their sums are never stored)
                 tile.col[k][j] = 0.0;
             }
             tile.cidx[j] = tile.seg_two[lo] ? g - jobs.tgt_off : -1;
@@ -903,7 +907,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
                     const int g = jobs.tgt_off + min(r_lo + min(p + r, nr - 1), t1 - 1);
                     tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
 #pragma unroll
-                    for (int k = 0; k < KB; ++k) tw[r][k] = (p + r < nr && k < kb) ? ws[k * ldw + g] : 0.0;
+                    for (int k = 0; k < KB; ++k) tw[r][k] = keep_if(p + r < nr, ws[min(k, kb - 1) * ldw + g]);
                 }
                 for (int j = lane; j < fill; j += 64) {
                     const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j];
@@ -968,16 +972,16 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
 //     are reduced per (tile, chunk) through a 4 KB wave-private transpose (8 ds_write_b64, 4 ds_read_b128, 3 DPP
 //     steps) and one atomic per row.
 //
-// KB right-hand sides in one pass (round 4; config 4's near field): one kernel evaluation feeds the KB row sums and the
-// KB column sums (15 + 2 KB FP64 instructions per unordered pair for LinearRbf against 2 x (15 + KB) of the ordered-pair
-// kernel) -- the reference evaluates the kernel once per rhs (bbfmm.rs:1162-1251: loop order rhs, target, source); the
-// values are the same, the sums differ in order only.  A column's KB weights and KB sums live in registers like its
-// coordinates; the rows' weights are wave-uniform (SGPR operands), which bounds rows-per-chunk x KB: 8 rows for one
-// rhs, 4 for 2-4, 2 for 5-8.  rhs k reads ws + k * ldw and adds to out + k * ldo; kb <= KB of them are live.
+// KB <= 4 right-hand sides in one pass (round 4; config 4's near field): one kernel evaluation feeds the KB row sums and
+// the KB column sums (15 + 2 KB FP64 instructions per unordered pair for LinearRbf against 2 x (15 + KB) of the
+// ordered-pair kernel) -- the reference evaluates the kernel once per rhs (bbfmm.rs:1162-1251: loop order rhs, target,
+// source); the values are the same, the sums differ in order only.  A column's KB weights and KB sums live in registers
+// like its coordinates; the rows' weights are wave-uniform (SGPR operands), which bounds rows-per-chunk x KB: 8 rows for
+// one rhs, 4 for 2-4.  rhs k reads ws + k * ldw and adds to out + k * ldo; kb <= KB of them are live.
 constexpr int SYM2_CG = 4;
 constexpr int SYM2_WAVES = 4;
 constexpr int SYM2_MAX_ROWS = 256;
-template <int KB> constexpr int sym2_rows() { return KB == 1 ? 8 : (KB <= 4 ? 4 : 2); }
+template <int KB> constexpr int sym2_rows() { return KB == 1 ? 8 : 4; }
 
 template <int NV> struct Sym2Wave { // wave-private
     double red[NV][64];
@@ -1056,21 +1060,22 @@ __global__ __launch_bounds__(64 * SYM2_WAVES) void p2p_sym2_kernel(KernelSpec ks
                 cy[cg] = src.y[g];
                 cz[cg] = src.z[g];
 #pragma unroll
-                for (int k = 0; k < KB; ++k)
-                    if (k < kb) cw[cg][k] = ws[k * ldw + g];
+                for (int k = 0; k < KB; ++k) // (idle slots repeat the last rhs; their sums are never stored)
+                    cw[cg][k] = ws[min(k, kb - 1) * ldw + g];
                 cidx[cg] = W.seg_two[lo] ? g - jobs.tgt_off : -1;
             }
         }
         const int ncg = (fill + 63) >> 6; // wave-uniform
         for (int rb = t0; rb < t1; rb += R) {
+            // the rows of a chunk: coordinates and weights are wave-uniform (scalar loads, SGPR operands)
             double tx[R], ty[R], tz[R], tw[R][KB], racc[R][KB];
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const int g = jobs.tgt_off + min(rb + r, t1 - 1); // wave-uniform: scalar loads
+                const int g = jobs.tgt_off + min(rb + r, t1 - 1);
                 tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
 #pragma unroll
                 for (int k = 0; k < KB; ++k) {
-                    tw[r][k] = (rb + r < t1 && k < kb) ? ws[k * ldw + g] : 0.0;
+                    tw[r][k] = keep_if(rb + r < t1, ws[min(k, kb - 1) * ldw + g]);
                     racc[r][k] = 0.0;
                 }
             }
@@ -1104,7 +1109,7 @@ __global__ __launch_bounds__(64 * SYM2_WAVES) void p2p_sym2_kernel(KernelSpec ks
             }
 #pragma unroll
             for (int off = 1; off < LPV; off <<= 1) sum += __shfl_xor(sum, off, 64);
-            const int v = lane / LPV, row = rb + v / KB, k = v % KB;
+            const int vi = lane / LPV, row = rb + vi / KB, k = vi % KB;
             if (lane % LPV == 0 && row < t1 && k < kb) unsafeAtomicAdd(&out[k * ldo + row], sum);
         }
 #pragma unroll
@@ -1264,7 +1269,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, W
             tile.z[j] = d > 2 ? centers[cell * 3 + 2] + half * chp->nodes[i2] : 0.0;
 #pragma unroll
             for (int k = 0; k < KB; ++k) {
-                tile.w[k][j] = k < kb ? M[k * ld_ml + static_cast<int64_t>(cell) * n_pad + I] : 0.0;
+                tile.w[k][j] = M[min(k, kb - 1) * ld_ml + static_cast<int64_t>(cell) * n_pad + I];
                 tile.col[k][j] = 0.0;
             }
             tile.cidx[j] = cell * n_pad + I;
@@ -1279,7 +1284,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, W
                     const int g = min(r_lo + min(pp + r, nr - 1), t1 - 1);
                     tx[r] = src.x[g], ty[r] = src.y[g], tz[r] = src.z[g];
 #pragma unroll
-                    for (int k = 0; k < KB; ++k) tw[r][k] = (pp + r < nr && k < kb) ? ws[k * ldw + g] : 0.0;
+                    for (int k = 0; k < KB; ++k) tw[r][k] = keep_if(pp + r < nr, ws[min(k, kb - 1) * ldw + g]);
                 }
                 for (int j = lane; j < fill; j += 64) {
                     const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j];
@@ -1956,33 +1961,35 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
     });
 }
 
-// K right-hand sides in passes of at most eight (kernel instances for 1, 2, 4 and 8; three, and five to seven, run
-// the next instance up with the spare slots idle).
+// K right-hand sides in passes of at most kSymMaxRhs = 4: kernel instances for 1, 2 and 4 rhs (three run the 4-slot
+// instance).  Measured at 10M points, LinearRbf (scripts/p2p_rhs_sweep.py): 4.4 / 5.1 / 7.3 ms for 1 / 2 / 4 rhs; an
+// 8-slot instance (two rows per chunk, 222 VGPRs, two waves per SIMD; also with point-major weights and software-pipelined
+// row loads) took 16.6 ms per pass against 2 x 7.3: not kept.
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
                     const int64_t *run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
                     const int64_t *w_run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
                     const double *w_sorted, int64_t ldw, int K, double *out_sorted, int64_t ldo, hipStream_t s) {
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
+        const SymJobs wj{n_wave_jobs, w_tgt_begin, w_tgt_end, w_run_range, runs3, tgt_off};
+        const SymJobs gj{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
+        const Xyz src = make_xyz(src_xyz);
         for (int k0 = 0; k0 < K; k0 += kSymMaxRhs) {
             const int kb = std::min(kSymMaxRhs, K - k0);
             const double *w = w_sorted + static_cast<int64_t>(k0) * ldw;
             double *o = out_sorted + static_cast<int64_t>(k0) * ldo;
-            const SymJobs wj{n_wave_jobs, w_tgt_begin, w_tgt_end, w_run_range, runs3, tgt_off};
-            const SymJobs gj{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
 #define SYM_GO(KBV)                                                                                                   \
     do {                                                                                                              \
         if (n_wave_jobs > 0)                                                                                          \
             hipLaunchKernelGGL((p2p_sym2_kernel<ID, KBV>), dim3((n_wave_jobs + SYM2_WAVES - 1) / SYM2_WAVES),          \
-                               dim3(64 * SYM2_WAVES), 0, s, ks, wj, make_xyz(src_xyz), w, ldw, kb, o, ldo);           \
+                               dim3(64 * SYM2_WAVES), 0, s, ks, wj, src, w, ldw, kb, o, ldo);                         \
         if (n_jobs > 0)                                                                                               \
-            hipLaunchKernelGGL((p2p_sym_kernel<ID, KBV>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, gj,            \
-                               make_xyz(src_xyz), w, ldw, kb, o, ldo);                                                \
+            hipLaunchKernelGGL((p2p_sym_kernel<ID, KBV>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, gj, src, w,    \
+                               ldw, kb, o, ldo);                                                                      \
     } while (0)
             if (kb == 1) SYM_GO(1);
             else if (kb == 2) SYM_GO(2);
-            else if (kb <= 4) SYM_GO(4);
-            else SYM_GO(8);
+            else SYM_GO(4);
 #undef SYM_GO
         }
     });
@@ -2011,7 +2018,7 @@ void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const in
     const WxJobs jobs{n_jobs, tgt_begin, tgt_end, w_range, w_cells};
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
-        for (int k0 = 0; k0 < K; k0 += kSymMaxRhs) {
+        for (int k0 = 0; k0 < K; k0 += kSymMaxRhs) { // (an 8-slot instance would be bound by its LDS traffic)
             const int kb = std::min(kSymMaxRhs, K - k0);
 #define WX_GO(KBV)                                                                                                    \
     hipLaunchKernelGGL((wx_sym_kernel<ID, KBV>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, jobs, ch.dev, centers,    \
@@ -2020,8 +2027,7 @@ void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const in
                        out_sorted + static_cast<int64_t>(k0) * ldo, ldo, out_off, out_n)
             if (kb == 1) WX_GO(1);
             else if (kb == 2) WX_GO(2);
-            else if (kb <= 4) WX_GO(4);
-            else WX_GO(8);
+            else WX_GO(4);
 #undef WX_GO
         }
     });

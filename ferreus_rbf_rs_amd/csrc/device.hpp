@@ -154,7 +154,7 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
 // wave-per-job kernel.
 // K right-hand sides (rhs k: weights w_sorted + k * ldw, sums out_sorted + k * ldo) go in passes of at most
 // kSymMaxRhs, one kernel evaluation per unordered pair and pass.
-constexpr int kSymMaxRhs = 8;
+constexpr int kSymMaxRhs = 4;
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
                     const int64_t *run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
                     const int64_t *w_run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,

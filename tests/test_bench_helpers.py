@@ -98,12 +98,12 @@ def test_pair_phases_are_quoted_against_the_fp64_vector_roof():
     assert abs(r["frac_hbm"] - 5.0e8 / 40e-3 / 8e12) < 1e-9
     dom, r = bench.roofline_of(S, 10_000_000, 1, "LinearRbf", _HEADLINE_MS, 1)
     assert dom == "M2L_stage1" and r["bound"] == "mfma" and abs(r["frac"] - 0.636) < 0.01 and "frac_hbm" not in r
-    # K right-hand sides: one evaluation per unordered pair and pass of <= 8, a row and a column multiply-add per slot
+    # K right-hand sides: one evaluation per unordered pair and pass of <= 4, a row and a column multiply-add per slot
     half = (S.p2p_pairs + 10_000_000) / 2.0
-    assert bench.pair_issue(S, 10_000_000, 8, "LinearRbf", "P2P")[:2] == (half, 15 + 16)
-    assert bench.pair_issue(S, 10_000_000, 5, "LinearRbf", "P2P")[:2] == (half, 15 + 16)       # five run the 8-slot instance
-    assert bench.pair_issue(S, 10_000_000, 11, "LinearRbf", "P2P")[:2] == (half, 15 + 16 + 15 + 8)
-    assert bench.sym_instances(3) == [4] and bench.sym_instances(16) == [8, 8] and bench.sym_instances(1) == [1]
+    assert bench.pair_issue(S, 10_000_000, 8, "LinearRbf", "P2P")[:2] == (half, 2 * (15 + 8))
+    assert bench.pair_issue(S, 10_000_000, 3, "LinearRbf", "P2P")[:2] == (half, 15 + 8)        # three run the 4-slot instance
+    assert bench.pair_issue(S, 10_000_000, 6, "LinearRbf", "P2P")[:2] == (half, 15 + 8 + 15 + 4)
+    assert bench.sym_instances(3) == [4] and bench.sym_instances(11) == [4, 4, 4] and bench.sym_instances(1) == [1]
     assert bench.pair_probe_hash() == bench.committed_pair_instructions()["pair_probe_hash"]   # counts belong to kernels.hpp
 
 

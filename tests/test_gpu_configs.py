@@ -258,8 +258,8 @@ def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs):
     """The matvec evaluates every unordered near-field pair once (launch_p2p_sym); `evaluate` at the same points
     goes through the ordered-pair kernel the reference's loops correspond to (bbfmm.rs:1162-1251).  Leaves of up
     to 256 points (several register groups per wave, several source tiles per leaf) and of a few points.  Round 4:
-    up to eight right-hand sides share one kernel evaluation per unordered pair (kernel instances for 1, 2, 4, 8; three
-    and five to seven run the next instance up; eleven = eight + three), in the near field and in the fused M2P + P2L."""
+    up to four right-hand sides share one kernel evaluation per unordered pair (kernel instances for 1, 2, 4; three runs
+    the 4-slot instance; eleven = 4 + 4 + 3), in the near field and in the fused M2P + P2L."""
     import torch
     rng = np.random.default_rng(600 + kid + d)
     n = 150000 if d == 3 else 40000

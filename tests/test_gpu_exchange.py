@@ -40,7 +40,9 @@ def test_single_rank_rccl_exchange_matches_unpartitioned():
                 x.exchange(out)
         torch.cuda.synchronize()
         stream.synchronize()
-        assert torch.equal(out, ref)
+        # (two rhs share one kernel evaluation per unordered near-field pair since round 4: f64 atomics, so the runs
+        # agree to summation order, not bit for bit; BBFMM_FLAG_DETERMINISTIC is the bitwise path)
+        assert (out - ref).abs().max() / ref.abs().max() < 1e-12
         # a 2-way split reassembled through the same exchange object type (ranks run in turn)
         parts = []
         for r in range(2):
