@@ -978,7 +978,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
 // source); the values are the same, the sums differ in order only.  A column's KB weights and KB sums live in registers
 // like its coordinates; the rows' weights are wave-uniform (SGPR operands), which bounds rows-per-chunk x KB: 8 rows for
 // one rhs, 4 for 2-4.  rhs k reads ws + k * ldw and adds to out + k * ldo; kb <= KB of them are live.
-constexpr int SYM2_CG = 4;
+constexpr int SYM2_CG = 4; // column groups of a tile (5 and 6 measured at one rhs: 4.23 against 4.16 ms, one wave less per SIMD)
 constexpr int SYM2_WAVES = 4;
 constexpr int SYM2_MAX_ROWS = 256;
 template <int KB> constexpr int sym2_rows() { return KB == 1 ? 8 : 4; }

@@ -10,7 +10,7 @@
 #     The JSON carries bench.py's source_hash: the bench only quotes counters taken on the sources it runs.
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 ROOT=$GRAFT_REPO_ROOT
-TAG=${1:-r02_x}
+TAG=${1:-r04_final}
 python3 bench.py --steps 20 --warmup 5 --detail-file gpurun_out/${TAG}_bench_detail.json > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 wc -c gpurun_out/${TAG}_bench.json
 grep -v "bench detail" gpurun_out/${TAG}_bench.err | tail -2; cut -c1-400 gpurun_out/${TAG}_bench.json
@@ -39,8 +39,8 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE', 'MfmaUtil', 'MfmaFlopsF64', 'VALUBusy', 'V
             if c == 'MfmaFlopsF64':
                 agg[name]['dur_ns'].append(float(r['End_Timestamp']) - float(r['Start_Timestamp']))
 mean = lambda v: sum(v) / len(v) if v else None
-phase = {'m2l_gemm_k4<11, 1, 1>': 'M2L_stage1', 'm2l_gemm_k4<22, 2, 1>': 'M2L_stage2', 'm2l_gemm_k4<11, 2, 1>': 'M2L_stage2', 'p2p_sym_kernel<0>': 'P2P',
-         'p2p_sym2_kernel<0>': 'P2P', 'p2p_kernel<0, false, 1>': 'P2P', 'wx_sym_kernel<0>': 'P2L'}
+phase = {'m2l_gemm_k4<11, 1, 1>': 'M2L_stage1', 'm2l_gemm_k4<22, 2, 1>': 'M2L_stage2', 'm2l_gemm_k4<11, 2, 1>': 'M2L_stage2', 'p2p_sym_kernel<0, 1>': 'P2P',
+         'p2p_sym2_kernel<0, 1>': 'P2P', 'p2p_kernel<0, false, 1>': 'P2P', 'wx_sym_kernel<0, 1>': 'P2L'}
 per_bytes, per_kernel, lines = {}, {}, []
 for k, v in sorted(agg.items()):
     fb = 2 * mean(v.get('FETCH_SIZE')) * 1024 if v.get('FETCH_SIZE') else None

@@ -1,4 +1,4 @@
-"""The fallbacks DESIGN.md section 10 lists stay alive: every default-on switch flipped in a child process
+"""The fallbacks DESIGN.md section 11 lists stay alive: every default-on switch flipped in a child process
 (the switches are read once per process) against the default path on the same cloud, at 1e-12; and
 BBFMM_FLAG_DETERMINISTIC gives bitwise equal results from run to run (the reference's per-target sums have a fixed
 order; the default path's f64 atomics do not)."""
