@@ -125,6 +125,7 @@ SIGNATURES = {
     "bbfmm_schwarz_basis_size": (c_i64, [c_p]),
     "bbfmm_schwarz_num_levels": (c_i32, [c_p]),
     "bbfmm_schwarz_monomial_matrix": (c_p, [c_p]),
+    "bbfmm_debug_evaluate_monomials": (ctypes.c_int, [c_p, c_i64, c_i32, c_i64, c_i32, c_p, c_p, c_p]),
     "bbfmm_schwarz_apply": (ctypes.c_int, [c_p, c_p, c_p, c_i64]),
     "bbfmm_schwarz_level_size": (c_i64, [c_p, c_i32]),
     "bbfmm_schwarz_level_points": (ctypes.c_int, [c_p, c_i32, c_p]),

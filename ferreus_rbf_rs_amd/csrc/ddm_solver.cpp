@@ -1,5 +1,6 @@
 // See ddm_solver.hpp.
 #include "ddm_solver.hpp"
+#include "ddm_monomials.hpp"
 
 #include <dlfcn.h>
 
@@ -122,15 +123,7 @@ int prepare_domain(const double *pts, int64_t ld, int d, int degree, int basis_s
     for (int i = 0; i < n; ++i) {
         double sx[3] = {0, 0, 0};
         for (int a = 0; a < d; ++a) sx[a] = (loc[static_cast<size_t>(a) * n + i] - out->tr[a]) / out->sc[a];
-        double *row = &mono[static_cast<size_t>(i) * basis_size];
-        row[0] = 1.0;
-        if (degree >= 1)
-            for (int a = 0; a < d; ++a) row[1 + a] = sx[a];
-        if (degree == 2) {
-            int c = 1 + d;
-            for (int a = 0; a < d; ++a)
-                for (int b = a; b < d; ++b) row[c++] = sx[a] * sx[b];
-        }
+        monomial_row(sx, d, degree, &mono[static_cast<size_t>(i) * basis_size], 1);
     }
     // rank and unisolvent columns (domain.rs:186-212)
     std::vector<int> piv;

@@ -23,6 +23,7 @@
 #include "ddm.hpp"
 #include "ddm_solver.hpp"
 #include "device.hpp"
+#include "ddm_monomials.hpp"
 #include "parallel.hpp"
 #include "schwarz_kernels.hpp"
 
@@ -199,8 +200,7 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
     S.degree = settings->polynomial_degree;
     S.nugget = settings->nugget;
     S.ks = make_kernel_spec(settings->kernel_type, settings->base_range, settings->total_sill);
-    const int kk = S.degree + 1; // set_basis_size, interpolant_config.rs:150-178
-    S.basis = S.degree < 0 ? 0 : (d == 1 ? kk : (d == 2 ? kk * (kk + 1) / 2 : kk * (kk + 1) * (kk + 2) / 6));
+    S.basis = monomial_basis_size(d, S.degree);
     DdmParams p;
     if (params) {
         p.leaf_threshold = params->leaf_threshold;
@@ -266,14 +266,7 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
             for (int64_t i = i0; i < i1; ++i) {
                 double sx[3] = {0, 0, 0};
                 for (int a = 0; a < d; ++a) sx[a] = (points[a * ld + i] - tr[a]) / sc[a];
-                S.mono[i] = 1.0;
-                if (S.degree >= 1)
-                    for (int a = 0; a < d; ++a) S.mono[static_cast<size_t>(1 + a) * n + i] = sx[a];
-                if (S.degree == 2) {
-                    int c = 1 + d;
-                    for (int a = 0; a < d; ++a)
-                        for (int b = a; b < d; ++b) S.mono[static_cast<size_t>(c++) * n + i] = sx[a] * sx[b];
-                }
+                monomial_row(sx, d, S.degree, &S.mono[static_cast<size_t>(i)], static_cast<size_t>(n));
             }
         });
         S.ortho.resize(S.mono.size()); // modified Gram-Schmidt, twice
@@ -396,6 +389,17 @@ void bbfmm_schwarz_destroy(bbfmm_schwarz *h) { delete h; }
 
 int64_t bbfmm_schwarz_basis_size(const bbfmm_schwarz *h) { return h ? h->s.basis : -1; }
 int32_t bbfmm_schwarz_num_levels(const bbfmm_schwarz *h) { return h ? static_cast<int32_t>(h->s.ddm.levels.size()) : 0; }
+int bbfmm_debug_evaluate_monomials(const double *points, int64_t n, int32_t d, int64_t ld, int32_t degree,
+                                   const double *translation, const double *scale, double *out) {
+    if (!points || !out || n < 0 || d < 1 || d > 3 || ld < n || degree < 0 || degree > 2) return BBFMM_BAD_ARGUMENT;
+    for (int64_t i = 0; i < n; ++i) {
+        double sx[3] = {0, 0, 0};
+        for (int a = 0; a < d; ++a) sx[a] = (points[a * ld + i] - (translation ? translation[a] : 0.0)) / (scale ? scale[a] : 1.0);
+        bbfmm::monomial_row(sx, d, degree, out + i, static_cast<size_t>(n));
+    }
+    return BBFMM_OK;
+}
+
 const double *bbfmm_schwarz_monomial_matrix(const bbfmm_schwarz *h) { return (h && h->s.basis) ? h->s.mono.data() : nullptr; }
 
 int64_t bbfmm_schwarz_level_size(const bbfmm_schwarz *h, int32_t level) {

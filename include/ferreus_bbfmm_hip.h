@@ -497,6 +497,11 @@ void bbfmm_schwarz_destroy(bbfmm_schwarz *h);
 int64_t bbfmm_schwarz_basis_size(const bbfmm_schwarz *h);           /* InterpolantSettings::basis_size */
 int32_t bbfmm_schwarz_num_levels(const bbfmm_schwarz *h);
 const double *bbfmm_schwarz_monomial_matrix(const bbfmm_schwarz *h); /* N x basis column-major (rbf.rs:485-491) or NULL */
+/* evaluate_monomials (ferreus_rbf/src/polynomials.rs:30-74) as the solver's matrix and the domains' matrices compute it:
+ * out (n x basis column-major, basis = 1 / d + 1 / (d + 1)(d + 2) / 2 for degree 0 / 1 / 2) on (x - translation) / scale
+ * (NULL: 0 and 1).  Host only; the reference's own known answers (polynomials.rs:163-242) are checked through it. */
+int bbfmm_debug_evaluate_monomials(const double *points, int64_t n, int32_t d, int64_t ld, int32_t degree,
+                                   const double *translation, const double *scale, double *out);
 int64_t bbfmm_schwarz_level_size(const bbfmm_schwarz *h, int32_t level);      /* Level::point_indices */
 int bbfmm_schwarz_level_points(const bbfmm_schwarz *h, int32_t level, int64_t *out);
 /* solve_fine_level / solve_coarse_level (schwarz.rs:84-155) of one level for a given residual
