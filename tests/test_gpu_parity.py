@@ -63,6 +63,19 @@ def test_fp64_valu_microbenchmark():
     assert 20.0 < tf < 90.0 and 1000.0 < mhz < 3000.0
 
 
+def test_get_distance_doctest_through_the_device_near_field():
+    """ferreus_rbf_utils/src/utils.rs:263-280: the distance from (1, 2) to (4, 6) is 5.  Two points, linear kernel
+    phi(r) = -r (rbf_kernels.rs:25-36), unit weights: both potentials are -5 -- exactly, the device square root
+    (v_rsq_f64 + Goldschmidt, kernels.hpp) being correctly rounded; through evaluate (ordered pairs) and through the
+    matvec entry point (unordered pairs)."""
+    pts = np.array([[1.0, 2.0], [4.0, 6.0]])
+    w = np.ones((2, 1))
+    t = F.FmmTree(pts, 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True)
+    t.set_weights(w)
+    assert t.evaluate(w, pts)[:, 0].tolist() == [-5.0, -5.0]
+    assert t.fast_matrix_vector_product(w[:, 0].copy()).tolist() == [-5.0, -5.0]
+
+
 def test_config1_50k_linear():
     # BASELINE.json configs[0]: 50k random points, single rhs (reference-native kernel)
     check(np.random.default_rng(1).random((50000, 3)))

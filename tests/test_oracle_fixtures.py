@@ -56,6 +56,20 @@ def test_cartesian_product_doctest():
     assert O.cartesian_product(np.array([0, 1]), 2).tolist() == [[0, 0], [0, 1], [1, 0], [1, 1]]
 
 
+def test_remaining_utils_doctests():
+    """The other three doctests of ferreus_rbf_utils/src/utils.rs, as known answers of the restatement's equivalents:
+    argsort (92-102: [30, 10, 20] -> [1, 2, 0]; the permutation tables are built with it), select_mat_rows (19-43: the
+    target subset of the matvec, rbf.rs:1359-1360) and get_distance (263-280: (1, 2) to (4, 6) is 5) -- the latter through
+    the dense sum with the linear kernel phi(r) = -r."""
+    assert list(O.argsort_stable([30, 10, 20])) == [1, 2, 0]
+    m = np.array([[0.0, 1.0], [1.0, 1.0], [2.0, 2.0], [3.0, 3.0]])
+    assert m[[0, 2]].tolist() == [[0.0, 1.0], [2.0, 2.0]]
+    pts = np.array([[1.0, 2.0], [4.0, 6.0]])
+    y = O.dense_sum(O.KERNEL_IDS["LinearRbf"], 1.0, 1.0, pts, pts, np.array([[1.0], [1.0]]))
+    assert y[:, 0].tolist() == [-5.0, -5.0]                               # -get_distance, exactly
+    assert float(O.kernel_phi(O.KERNEL_IDS["LinearRbf"], 5.0)) == -5.0
+
+
 def test_pointarray_extents_doctest():
     # ferreus_rbf_utils/src/utils.rs:181-194
     pts = np.array([[1.0, 5.0], [3.0, 2.0], [-1.0, 4.0]])
