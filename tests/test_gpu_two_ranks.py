@@ -91,6 +91,26 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert f5["n_gpus"] == 2 and "Spheroidal3Rbf" in f5["workload"] and f5["workload"].startswith("300000 ")
 
 
+@pytest.mark.timeout(900)
+def test_bench_under_the_drivers_launcher(tmp_path):
+    """The driver starts N > 1 as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` (ranks from the environment, no file store): the same two-rank run through
+    that launcher, gloo exchange on the one GPU.  stdout of the whole launch = rank 0's one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    detail = str(tmp_path / "bench_detail.json")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--exchange", "gloo", "--points", "300000", "--steps", "3", "--warmup", "1",
+                        "--cpu-baseline", "off", "--configs", "off", "--detail-file", detail],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1 and len(lines[0]) < 4096, p.stdout.decode()[-1000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 3 and j["warmup"] == 1 and j["value"] > 0
+    assert j["dense_rows_rel_err"] < 1e-6 and j["partition_covers_every_row_once"] is True
+
+
 @pytest.mark.timeout(1200)
 def test_bench_eight_ranks_rehearsal_on_one_gpu(tmp_path):
     """The driver's 8-GPU run has no retry, so the 8-rank path is rehearsed here first: eight
