@@ -290,6 +290,100 @@ __global__ __launch_bounds__((64 * p2m_waves<P, D>())) void p2m_kernel(const Dev
     }
 }
 
+// P2M as a small matrix product on the FP64 matrix pipe (round 4; 3-D, orders up to 10).  Per leaf
+//   M[i0][q] = sum_p (S0[p][i0] w_p) * (S1[p][i1(q)] S2[p][i2(q)]),   q = i1 * P + i2
+// is (P x npts) x (npts x P^2).  The kernel above evaluates it with lane = q and one point at a time: two private and
+// four broadcast LDS reads for nine multiply-adds per point and lane, which keeps the CU's one LDS pipe busy for four
+// waves' worth of arithmetic (VALUBusy 46 %).  Here four points form the contraction of a v_mfma_f64_4x4x4 (four
+// independent 4 x 4 x 4 products per instruction, lanes A: 16 k + 4 b + i, B: 16 k + 4 b + j, D: 16 i + 4 b + j):
+// row block rb holds i0 = 4 rb + i, column group g holds q = 16 g + 4 b + j; per step of four points a lane reads one
+// S0 value per row block and an S1 / S2 pair per column group (private LDS reads, no broadcasts) and issues RB x G
+// matrix instructions.  Points beyond the leaf are zero rows.  Same sums as the kernel above in another order.
+template <int P>
+__global__ __launch_bounds__(64 * P2M_WAVES) void p2m_mfma_kernel(const DevCheb *__restrict__ chp, int n_leaves, Xyz src,
+                                                                 const double *__restrict__ ws, int64_t N, int K, int64_t C,
+                                                                 const int32_t *__restrict__ leaf_cells,
+                                                                 const int32_t *__restrict__ pt_begin,
+                                                                 const int32_t *__restrict__ pt_end,
+                                                                 const double *__restrict__ centers,
+                                                                 const double *__restrict__ lengths, double *__restrict__ M) {
+    constexpr int NPAIR = P * P, RB = (P + 3) / 4, G = (NPAIR + 15) / 16;
+    constexpr int SROW = 3 * P + 2; // per point: S0[P], S1[P], S2[P], w, one spare (rows start 16-byte aligned for even P)
+    __shared__ double s_pts[P2M_WAVES][64][SROW];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // (the node values T_k(node_j) come through the scalar cache as SGPR operands: the same 8 P^2 bytes for every wave;
+    // staged in LDS the compiler kept all P^2 of them in vector registers across the three axes)
+    const double *__restrict__ s_polyn = chp->polyn;
+    const int job = blockIdx.x * P2M_WAVES + wave;
+    if (job >= n_leaves) return; // whole wave; no block barrier below
+    const int n_pad = chp->n_pad;
+    const int cell = leaf_cells[job];
+    const int b = pt_begin[cell], e = pt_end[cell];
+    const double len = lengths[cell];
+    const double cc[3] = {centers[cell * 3 + 0], centers[cell * 3 + 1], centers[cell * 3 + 2]};
+    double(*sp)[SROW] = s_pts[wave];
+    const int hi = lane >> 4, blk = (lane >> 2) & 3, lo = lane & 3;
+    // this lane's column of every group (clamped: columns past P^2 read valid memory and are never stored)
+    int o1[G], o2[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int q = min(16 * g + 4 * blk + lo, NPAIR - 1);
+        o1[g] = P + q / P;
+        o2[g] = 2 * P + q % P;
+    }
+    for (int k = 0; k < K; ++k) {
+        double acc[RB][G];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int g = 0; g < G; ++g) acc[rb][g] = 0.0;
+        for (int base = b; base < e; base += 64) {
+            const int npts = min(64, e - base);
+            if (k == 0 || e - b > 64) { // the factor rows of the batch (kept across right-hand sides when the leaf is one batch)
+                double S[P], dS[P];
+                const int pt = base + min(lane, npts - 1);
+                const bool live = lane < npts;
+                cheb_S_reg<P, false>((src.x[pt] - cc[0]) / (len * 0.5), s_polyn, S, dS); // chebyshev.rs:841-845
+#pragma unroll
+                for (int jx = 0; jx < P; ++jx) sp[lane][jx] = live ? S[jx] : 0.0;
+                cheb_S_reg<P, false>((src.y[pt] - cc[1]) / (len * 0.5), s_polyn, S, dS);
+#pragma unroll
+                for (int jx = 0; jx < P; ++jx) sp[lane][P + jx] = live ? S[jx] : 0.0;
+                cheb_S_reg<P, false>((src.z[pt] - cc[2]) / (len * 0.5), s_polyn, S, dS);
+#pragma unroll
+                for (int jx = 0; jx < P; ++jx) sp[lane][2 * P + jx] = live ? S[jx] : 0.0;
+            }
+            sp[lane][3 * P] = lane < npts ? ws[(int64_t)k * N + base + lane] : 0.0;
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): wave-private slice, in-order LDS
+            const int nsteps = (npts + 3) >> 2;
+            for (int st = 0; st < nsteps; ++st) {
+                const double *row = sp[4 * st + hi];
+                const double wv = row[3 * P];
+                double av[RB], bv[G];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) av[rb] = 4 * rb + lo < P ? row[4 * rb + lo] * wv : 0.0;
+#pragma unroll
+                for (int g = 0; g < G; ++g) bv[g] = row[o1[g]] * row[o2[g]];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int g = 0; g < G; ++g) acc[rb][g] = __builtin_amdgcn_mfma_f64_4x4x4f64(av[rb], bv[g], acc[rb][g], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f); // reads done before the slice is rewritten
+        }
+        double *Mc = M + ((int64_t)k * C + cell) * n_pad;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int i0 = 4 * rb + hi; // D: lane = 16 i + 4 b + j
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+                const int q = 16 * g + 4 * blk + lo;
+                if (i0 < P && q < NPAIR) Mc[i0 * NPAIR + q] = acc[rb][g]; // a leaf is written once
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ M2M / L2L
 // One pass of a sum-factorised transfer along `axis`.  in/out are n-vectors in LDS with
 // index (i0*P1 + i1)*P2 + i2.  FORWARD (M2M): out[.., i, ..] = sum_a xf[a][i] in[.., a, ..];
@@ -540,12 +634,21 @@ __global__ __launch_bounds__((64 * l2p_waves<P, D>())) void l2p_kernel(const Dev
                                                              const double *__restrict__ L,
                                                              double *__restrict__ out, double *__restrict__ grad) {
     constexpr int P1 = D > 1 ? P : 1, P2 = D > 2 ? P : 1, N = P * P1 * P2;
-    __shared__ double s_polyn[P * P];
     constexpr int WAVES = l2p_waves<P, D>();
     __shared__ double s_L[WAVES][N];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < P * P; i += 64 * WAVES) s_polyn[i] = chp->polyn[i];
-    __syncthreads();
+    // Values only: the node values T_k(node_j) come through the scalar cache as SGPR operands -- staged in LDS the
+    // compiler kept all P^2 of them in vector registers across the three axes (166 -> 102 VGPRs at order 7, L2P 0.98 ->
+    // 0.81 ms at 10M points).  With gradients the kernel is out of registers either way and keeps the LDS copy.
+    // (A matrix-pipe version like p2m_mfma_kernel -- sixteen points per v_mfma_f64_4x4x4, the coefficients as B operands
+    // in registers -- was built and measured: 0.92 ms at order 7, 1.84 ms against 1.42 at order 9, ahead only with eight
+    // right-hand sides (4.3 against 5.1 ms).  Not kept.)
+    __shared__ double s_polyn_lds[GRAD ? P * P : 1];
+    if constexpr (GRAD) {
+        for (int i = tid; i < P * P; i += 64 * WAVES) s_polyn_lds[i] = chp->polyn[i];
+        __syncthreads();
+    }
+    const double *__restrict__ s_polyn = GRAD ? s_polyn_lds : chp->polyn;
     const int job = blockIdx.x * WAVES + wave;
     if (job >= n_jobs) return; // whole wave; no block barrier below
     const int n_pad = chp->n_pad;
@@ -1779,6 +1882,11 @@ static void p2m_launch_pd(const ChebRef &ch, Xyz src, const double *w_sorted, in
                           const double *centers, const double *lengths, double *M, hipStream_t s) {
     constexpr int WAVES = p2m_waves<P, D>();
     const int blocks = (n_leaves + WAVES - 1) / WAVES;
+    if constexpr (D == 3 && P >= 4 && P <= 10) { // the matrix-pipe version
+        hipLaunchKernelGGL((p2m_mfma_kernel<P>), dim3((n_leaves + P2M_WAVES - 1) / P2M_WAVES), dim3(64 * P2M_WAVES), 0, s, ch.dev,
+                           n_leaves, src, w_sorted, N, K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
+        return;
+    }
     if (K == 1 || (D == 3 && P > 12)) // (two rhs slots at orders above 12 would spill: one rhs per pass there)
         hipLaunchKernelGGL((p2m_kernel<P, D, 1>), dim3(blocks), dim3(64 * WAVES), 0, s, ch.dev, n_leaves, src,
                            w_sorted, N, K, C, leaf_cells, pt_begin, pt_end, centers, lengths, M);
