@@ -87,7 +87,7 @@ void launch_ddm_unpack_symmetric(const double *packed, int m, double *full, hipS
 // gamma = (Q^T A Q)^-1 y through the LU factors of a large domain (y, gamma: m doubles on the device, in place)
 int big_lu_solve(const DdmLevelSolver &lv, double *d_rhs, hipStream_t s);
 // symmetric eigen-decomposition on the device (rocSOLVER, bound on demand; BBFMM_UNSUPPORTED without it): d_a n x n
-// column-major -> eigenvectors, d_eval ascending.  Used by the shared-basis M2L extension (fmm_tree.cpp).
+// column-major -> eigenvectors, d_eval ascending.  Used by the shared-basis M2L extension (fmm_m2l_tables.cpp).
 int device_symmetric_eigen(int n, double *d_a, double *d_eval, hipStream_t s);
 int big_lu_factor(DdmLevelSolver *lv, hipStream_t s); // lv->d_fac holds the assembled packed matrix
 void big_lu_release(DdmLevelSolver *lv);

@@ -1513,7 +1513,7 @@ __global__ __launch_bounds__(256) void p2l_kernel(KernelSpec ks, const DevCheb *
 // multipole_to_local (bbfmm.rs:864-986) regrouped for the matrix cores.  The reference
 // permutes each V cell's multipoles onto one of 16 reference operators, multiplies by
 // Vt then U, and permutes back.  Here the permutations are folded into per-transfer-
-// vector operators stacked per octant class (host side, fmm_tree.cpp), which turns the
+// vector operators stacked per octant class (host side, fmm_m2l_tables.cpp), which turns the
 // whole level into two dense streamed-operator GEMMs with no data permutation:
 //   stage 1:  Cbuf[target(V,t)][(t,kk)] = sum_m VtAll[(t,kk)][m] * M_V[m]   (X-stationary)
 //   stage 2:  L_B[i]                    = sum_k UAll[i][k] * Cbuf[B][k]     (accumulator-stationary)
@@ -2425,7 +2425,7 @@ void launch_small_gemm(bool trans_a, int M, int N, int Kd, const double *A, int6
 }
 
 // ------------------------------------------------------------------ stacked M2L operators, assembled in HBM
-// fmm_tree.cpp fill_m2l_operator_arrays on the device: the reference operators of a level (16 in 3-D) and the
+// fmm_m2l_tables.cpp fill_m2l_operator_arrays on the device: the reference operators of a level (16 in 3-D) and the
 // symmetry tables go up once (MBs), the stacked per-class operators (GBs) are gathered from them here instead
 // of being filled on the host and sent over PCIe.  VtAll[m][first_row(t) + kk] = Vt_ref(t)[kk][invperm_t[m]]
 // (identity rows when uncompressed); UAll[tgt_off(t) + kk][i] = U_ref(t)[invperm_t[i]][kk].

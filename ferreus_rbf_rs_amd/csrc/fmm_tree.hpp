@@ -268,7 +268,7 @@ class FmmTree {
     std::vector<int32_t> x_cells_;                      // cells with an X list
     // M2L tables (host copies kept for stats / tests)
     std::vector<HostM2lClass> m2l_host_;
-    std::vector<HostM2lClass> m2l_variants_;       // stage-1 boundary variants (fmm_tree.cpp build_m2l_tables)
+    std::vector<HostM2lClass> m2l_variants_;       // stage-1 boundary variants (fmm_m2l_tables.cpp build_m2l_tables)
     std::vector<M2lTileDesc> m2l_tiles1_h_;        // unrestricted stage-1 launch: variant tiles + class tiles over the rest
     std::vector<int32_t> m2l_tile_idx1_h_;         // class positions of the `rest` tiles
     std::vector<M2lClass> m2l_classes_h_;

@@ -363,7 +363,7 @@ int bbfmm_debug_dense_m2m(const bbfmm_handle *h, int32_t child_index, double *ou
  * BBFMM_FLAG_HOST_ONLY handles (the tables are released after upload otherwise). */
 int bbfmm_debug_apply_m2l_tables_host(const bbfmm_handle *h, const double *M, double *L);
 /* Number of stage-1 boundary variants (stacked operators with the transfer vectors towards missing targets left
- * out, fmm_tree.cpp build_m2l_tables) and of source cells that use one. */
+ * out, fmm_m2l_tables.cpp build_m2l_tables) and of source cells that use one. */
 int bbfmm_debug_m2l_variants(const bbfmm_handle *h, int64_t *n_variants, int64_t *n_cells);
 
 /* The Morton primitives of csrc/morton.hpp as the host tree build uses them (morton.rs:58-263; the
