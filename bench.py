@@ -97,6 +97,9 @@ def parse():
     ap.add_argument("--base-range", type=float, default=1.0)
     ap.add_argument("--total-sill", type=float, default=1.0)
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "off"])
+    ap.add_argument("--dropin", default="auto", choices=["auto", "off"],
+                    help="auto: with the default workload at N = 1 also time the drop-in boundary on host buffers "
+                         "(patched and unchanged caller; detail file + one small entry of the line)")
     ap.add_argument("--cpu-points", type=int, default=0, help="points of the CPU sample (0: points/8)")
     ap.add_argument("--configs", default="auto",
                     help="comma list of: auto (with the default workload: the other single-GPU configs at N = 1, "
@@ -377,16 +380,24 @@ def roofline_of(stats, N, K, kernel, per_launch, world, launches=None, valu_lane
     dur = per_launch[dominant] * 1e-3
     extra = {}
     if kd["bound"] == "fp64_valu":
+        # `frac` is against the NOMINAL issue peak (78.6e12 / 2 lane instructions per second at 2.4 GHz): a device that
+        # clocks lower must not look better.  The rate the same device sustained in this run's bare FMA loop is quoted
+        # beside it (`frac_of_measured_fma_rate`), never instead of it.
         pi = pair_issue(stats, N, K, kernel, dominant)
-        peak = valu_lane_rate or FP64_VALU_LANE_INSTR_PEAK
         if pi:
-            work, unit, scale = pi[0] * pi[1], "Tinstr/s", 1e-12
-            extra = {"fp64_valu_instr_per_evaluation": pi[1], "counted_from": pi[2]}
-        else:   # no ISA count for these sources: the reference's flop count per evaluation against the FP64 rate
-            work, unit, scale = (stats.p2p_pairs if dominant == "P2P" else stats.wx_pairs) * PAIR_FLOPS.get(kernel, 14) * K / 2.0, "Tinstr/s", 1e-12
-        extra["peak_is"] = "measured v_fma_f64 lane rate of this run" if valu_lane_rate else "nominal 78.6e12 / 2"
+            work, unit, scale, peak = pi[0] * pi[1], "Tinstr/s", 1e-12, FP64_VALU_LANE_INSTR_PEAK * 1e-12
+            extra = {"fp64_valu_instr_per_evaluation": pi[1], "counted_from": pi[2], "peak_is": "nominal 78.6e12 / 2 lane instr/s",
+                     "instr_count_is": "ISA count of the one-rhs pair loop (scripts/pair_probe.hip)" if K == 1 else
+                     "DERIVED for %d rhs: (one-rhs ISA count - 2 + 2 x slots) per pass of the 1/2/4-slot instances; idle slots "
+                     "of a partly filled instance count as work" % K}
+            if valu_lane_rate and dur > 0:
+                extra["frac_of_measured_fma_rate"] = work / world / dur / valu_lane_rate
+        else:   # no ISA count for these sources: the reference's flop count per evaluation against the FP64 flop peak
+            work = (stats.p2p_pairs if dominant == "P2P" else stats.wx_pairs) * PAIR_FLOPS.get(kernel, 14) * K
+            unit, scale, peak = "TFLOP/s", 1e-12, FP64_MFMA_PEAK_TFLOPS
+            extra = {"peak_is": "nominal 78.6 TFLOP/s (FP64 vector = matrix); flops = ordered pairs x the reference's flops per pair"}
         extra["frac_hbm"] = (kd["bytes"] / world / dur * 1e-9 / HBM_PEAK_GBPS) if dur > 0 else None
-        kd = {"bound": "fp64_valu", "work": work, "unit": unit, "peak": peak * 1e-12, "scale": scale}
+        kd = {"bound": "fp64_valu", "work": work, "unit": unit, "peak": peak, "scale": scale}
     # N > 1: rank 0's launch against ITS share of the job's algorithmic work, taken as 1 / world (the partition balances
     # a work proxy; the halo a rank computes beyond its share is not algorithmic work and lowers the figure)
     work = kd["work"] / world
@@ -559,6 +570,52 @@ def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None, valu_
     return res
 
 
+def dropin_host_buffer_times(tree, pts, reps=5):
+    """The drop-in boundary on HOST buffers (PCIe inclusive; never `value`), both ways a ferreus_rbf caller can reach the
+    matvec: (i) the patched caller, one bbfmm_fast_matrix_vector_product; (ii) the UNCHANGED caller of rbf.rs:1357-1364,
+    bbfmm_set_weights(w) then bbfmm_evaluate(w, the source rows) -- which bbfmm_evaluate recognises (bit-for-bit
+    comparison with the handle's sources beside the M2L) and serves from the resident target set; (iii) the same
+    sequence with one bit of one target coordinate changed, i.e. the general path the sequence took before round 5
+    (target upload + grouping, ordered pairs).  Median of `reps` calls after one warm-up each; preallocated outputs; the
+    caller's own select_mat_rows copy (rbf.rs:1359-1360) is the caller's and not timed."""
+    import ctypes
+    from ferreus_rbf_rs_amd import _lib as L
+    lib = L.load()
+    n = pts.shape[0]
+    x = np.asfortranarray(pts)                               # N x 3 column-major, as faer's Mat
+    w = np.random.default_rng(43).random(n)
+    y = np.zeros(n)
+    bad = ctypes.c_int64(-1)
+
+    def patched():
+        return lib.bbfmm_fast_matrix_vector_product(tree._h, w.ctypes.data, n, 0, None, 0, None, 0, 0.0, y.ctypes.data)
+
+    def unchanged(xx):
+        rc = lib.bbfmm_set_weights(tree._h, w.ctypes.data, n, 1, n)
+        return rc or lib.bbfmm_evaluate(tree._h, w.ctypes.data, n, 1, n, xx.ctypes.data, n, n, y.ctypes.data, n, ctypes.byref(bad))
+
+    def med(fn):
+        assert fn() == 0
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[len(ts) // 2] * 1e3
+
+    res = {"points": n, "patched_caller_ms": med(patched)}
+    y_patched = y.copy()
+    res["unchanged_caller_ms"] = med(lambda: unchanged(x))
+    res["unchanged_caller_took_resident_path"] = bool(tree.last_evaluate_at_sources())
+    res["unchanged_vs_patched_rel_diff"] = float(np.abs(y - y_patched).max() / np.abs(y_patched).max())
+    x2 = x.copy(order="F")
+    x2[n // 2, 1] = np.nextafter(x2[n // 2, 1], 0.0)
+    res["unchanged_caller_general_path_ms"] = med(lambda: unchanged(x2))
+    res["general_path_took_resident_path"] = bool(tree.last_evaluate_at_sources())
+    res["ratio_unchanged_over_patched"] = res["unchanged_caller_ms"] / res["patched_caller_ms"]
+    return res
+
+
 def _sig(x, digits=5):
     """Floats of the printed line at five significant digits (the detail file keeps full precision)."""
     if isinstance(x, float):
@@ -579,18 +636,24 @@ def compact_line(detail: dict) -> dict:
     roof = detail.get("roofline") or {}
     line["roofline"] = {k: _sig(roof.get(k)) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                                                          "avg_launch_ms", "mfma_util_pct")}
-    if roof.get("frac_hbm") is not None:
-        line["roofline"]["frac_hbm"] = _sig(roof["frac_hbm"])
+    for k in ("frac_hbm", "frac_of_measured_fma_rate", "peak_is"):
+        if roof.get(k) is not None:
+            line["roofline"][k] = _sig(roof[k])
     p2p = (detail.get("phase_roofline") or {}).get("P2P")
     if p2p:          # the north-star's near-field figure, whatever the dominant kernel is
         vi = p2p.get("valu_issue", {})
         line["p2p"] = {"ms": _sig(p2p["ms"]), "frac_hbm": _sig(p2p["frac_hbm"]),
-                       "frac_fp64_valu": _sig(vi.get("frac_of_measured_fma_rate", vi.get("frac")))}
+                       "frac_fp64_valu": _sig(vi.get("frac")),                       # against the nominal issue peak
+                       "frac_of_measured_fma_rate": _sig(vi.get("frac_of_measured_fma_rate"))}
     cb = detail.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample")}
         line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:200]
     line["dense_rows_rel_err"] = _sig(detail.get("dense_rows_rel_err"))
+    dh = detail.get("dropin_host_buffers")
+    if dh and "error" not in dh:   # PCIe-inclusive, host buffers: the patched and the unchanged caller (never `value`)
+        line["dropin_host_buffers_ms"] = {"patched": _sig(dh.get("patched_caller_ms")), "unchanged": _sig(dh.get("unchanged_caller_ms")),
+                                          "unchanged_general_path": _sig(dh.get("unchanged_caller_general_path_ms"))}
     if detail.get("partition_covers_every_row_once") is not None:
         line["partition_covers_every_row_once"] = detail["partition_covers_every_row_once"]
     line["source_hash"] = detail.get("source_hash")
@@ -814,6 +877,11 @@ def main():
         line["dense_rows_rel_err"] = dense_rows_err(torch, dev, args.kernel, args.base_range, args.total_sill, pts, w, out)
         line["dense_rows"] = 32
 
+    if rank == 0 and world == 1 and default_workload and K == 1 and args.dropin != "off":
+        try:
+            line["dropin_host_buffers"] = dropin_host_buffer_times(tree, pts)
+        except Exception as e:  # noqa: BLE001
+            line["dropin_host_buffers"] = {"error": f"{type(e).__name__}: {e}"}
     extra = {}
     if world == 1 and default_workload and want & {"auto", "extensions", "solve"}:
         todo = (EXTRA_CONFIGS if "auto" in want else []) + (EXTENSION_CONFIGS if "extensions" in want else [])

@@ -82,6 +82,7 @@ SIGNATURES = {
     "bbfmm_debug_partition_upward_counts": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
     "bbfmm_get_tree_stats": (ctypes.c_int, [c_p, c_p]),
     "bbfmm_tree_built_on_device": (ctypes.c_int, [c_p]),
+    "bbfmm_last_evaluate_at_sources": (ctypes.c_int, [c_p]),
     "bbfmm_get_cells": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_get_leaf_sources": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_get_list": (ctypes.c_int, [c_p, ctypes.c_char, c_p, c_p, c_p]),

@@ -845,6 +845,7 @@ int FmmTree::matvec_subset_device(int id, const double *d_w, double *d_y, bool s
     SubsetPlan *sp = registered_plans_[static_cast<size_t>(id)].get();
     CHK(ensure_rhs_capacity(1));
     nrhs_ = 1;
+    pin_w_k_ = 0;
     phase_begin();
     launch_gather_weights(d_w, N, 1, d_order_.p, N, d_w_sorted_.p, stream_);
     phase_end(kPhGather);

@@ -574,6 +574,7 @@ int FmmTree::upload() {
 int FmmTree::ensure_rhs_capacity(int k) {
     if (k <= k_cap_) return BBFMM_OK;
     const int64_t N = tree_.n_points, C = tree_.n_cells();
+    pin_w_k_ = 0;
     dfree(&d_w_sorted_);
     dfree(&d_M_);
     dfree(&d_L_);
@@ -603,6 +604,7 @@ int FmmTree::ensure_rhs_capacity(int k) {
 int FmmTree::upload_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     const int64_t N = tree_.n_points;
     if (!w || rows < N || ldw < rows || k < 1) return fail(BBFMM_BAD_ARGUMENT, "weights must be rows x k with rows >= N");
+    pin_w_k_ = 0;
     CHK(ensure_rhs_capacity(k));
     if (static_cast<size_t>(k) * N > d_w_in_.n) {
         dfree(&d_w_in_);
@@ -622,31 +624,130 @@ int FmmTree::ensure_pinned(size_t n) {
     if (h_pin_) (void)hipHostFree(h_pin_);
     h_pin_ = nullptr;
     h_pin_n_ = 0;
+    pin_w_k_ = 0;
     HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_pin_), n * sizeof(double), hipHostMallocDefault));
     h_pin_n_ = n;
     return BBFMM_OK;
 }
 
-// Host rows -> d_w_in_.  The caller's memory is pageable: it is staged through the pinned buffer in pieces, and
-// the thread that staged a piece queues its copy to the device at once, so PCIe runs beside the staging of the
-// other pieces (one memcpy pass + one 80 MB transfer at 10M points took 5 ms back to back).
-int FmmTree::stage_weights_to_device(const double *w, int64_t n) {
-    CHK(ensure_pinned(static_cast<size_t>(2 * tree_.n_points)));
-    if (static_cast<size_t>(n) > d_w_in_.n) {
+// Host rows -> d_w_in_ (k columns of N rows, leading dimension ldw on the host, N on the device).  The caller's
+// memory is pageable: it is staged through the pinned buffer in pieces, and the thread that staged a piece queues
+// its copy to the device at once, so PCIe runs beside the staging of the other pieces (one memcpy pass + one 80 MB
+// transfer at 10M points took 5 ms back to back).  The staged copy stays in h_pin_[0, k N): see pin_w_k_.
+int FmmTree::stage_weights_to_device(const double *w, int64_t n, int k, int64_t ldw) {
+    pin_w_k_ = 0;
+    CHK(ensure_pinned(static_cast<size_t>(2) * k * n));
+    if (static_cast<size_t>(k) * n > d_w_in_.n) {
         dfree(&d_w_in_);
-        CHK(dalloc(&d_w_in_, static_cast<size_t>(n)));
+        CHK(dalloc(&d_w_in_, static_cast<size_t>(k) * n));
     }
     double *pin_in = h_pin_;
     double *dst = d_w_in_.p;
     std::atomic<int> err{0};
-    parallel_for_chunks(n, kHostPiece, [&](int64_t b, int64_t e) {
-        bind_device();
-        std::memcpy(pin_in + b, w + b, static_cast<size_t>(e - b) * sizeof(double));
-        const hipError_t r = hipMemcpyAsync(dst + b, pin_in + b, static_cast<size_t>(e - b) * sizeof(double), hipMemcpyHostToDevice, stream_);
-        if (r != hipSuccess) err.store(static_cast<int>(r));
-    });
+    for (int j = 0; j < k; ++j) {
+        const double *col = w + static_cast<size_t>(j) * ldw;
+        const int64_t off = static_cast<int64_t>(j) * n;
+        parallel_for_chunks(n, kHostPiece, [&](int64_t b, int64_t e) {
+            bind_device();
+            std::memcpy(pin_in + off + b, col + b, static_cast<size_t>(e - b) * sizeof(double));
+            const hipError_t r = hipMemcpyAsync(dst + off + b, pin_in + off + b, static_cast<size_t>(e - b) * sizeof(double),
+                                                hipMemcpyHostToDevice, stream_);
+            if (r != hipSuccess) err.store(static_cast<int>(r));
+        });
+    }
     if (err.load() != 0) return hip_fail(static_cast<hipError_t>(err.load()), "hipMemcpyAsync(weights)");
     return BBFMM_OK;
+}
+
+// Device rows (contiguous, `total` doubles) -> the host through the pinned buffer at pin_out, in pieces: an event
+// behind each piece's copy, and the host threads hand a piece to consume(begin, end) -- flattened positions, the
+// values at pin_out[begin, end) -- as soon as it has landed.  Returns with the stream idle.
+template <class F> int FmmTree::download_pieces(const double *d_src, int64_t total, double *pin_out, F &&consume) {
+    const int64_t n_pieces = (total + kHostPiece - 1) / kHostPiece;
+    if (n_pieces == 0) {
+        HIPCHK(hipStreamSynchronize(stream_));
+        return BBFMM_OK;
+    }
+    while (static_cast<int64_t>(ev_out_.size()) < n_pieces) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        ev_out_.push_back(ev);
+    }
+    for (int64_t pc = 0; pc < n_pieces; ++pc) {
+        const int64_t b = pc * kHostPiece, e = std::min(total, b + kHostPiece);
+        HIPCHK(hipMemcpyAsync(pin_out + b, d_src + b, static_cast<size_t>(e - b) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+        HIPCHK(hipEventRecord(ev_out_[static_cast<size_t>(pc)], stream_));
+    }
+    HIPCHK(hipEventSynchronize(ev_out_[0])); // the product is done and the first piece is here: start the team
+    std::atomic<int> err{0};
+    parallel_for_chunks(total, kHostPiece, [&](int64_t b, int64_t e) { // chunks start at piece boundaries, ascending
+        bind_device();
+        for (int64_t pb = b; pb < e; pb += kHostPiece) {
+            const hipError_t r = hipEventSynchronize(ev_out_[static_cast<size_t>(pb / kHostPiece)]);
+            if (r != hipSuccess) {
+                err.store(static_cast<int>(r));
+                return;
+            }
+            consume(pb, std::min(e, pb + kHostPiece));
+        }
+    });
+    HIPCHK(hipStreamSynchronize(stream_));
+    if (err.load() != 0) return hip_fail(static_cast<hipError_t>(err.load()), "hipEventSynchronize(result piece)");
+    return BBFMM_OK;
+}
+
+// Host buffers above this size (weights in + values out) are not mirrored in pinned memory: pageable copies instead.
+static constexpr size_t kMaxPinnedDoubles = size_t(1) << 28; // 2 GiB
+
+// Weights of set_weights / evaluate: rows < N of k columns -> d_w_sorted_.  The pinned staging buffer keeps the last
+// staged weights; a caller that hands the same values again (rbf.rs:1357-1364: set_weights(w), evaluate(w, ..)) is
+// recognised by a threaded bit-for-bit comparison and pays no second transfer.
+int FmmTree::put_weights(const double *w, int64_t rows, int k, int64_t ldw) {
+    const int64_t N = tree_.n_points;
+    if (!w || rows < N || ldw < rows || k < 1) return fail(BBFMM_BAD_ARGUMENT, "weights must be rows x k with rows >= N");
+    if (weights_match_staged(w, k, ldw)) return BBFMM_OK;
+    if (static_cast<size_t>(2) * k * N > kMaxPinnedDoubles) {
+        pin_w_k_ = 0;
+        return upload_weights(w, rows, k, ldw);
+    }
+    CHK(ensure_rhs_capacity(k));
+    CHK(stage_weights_to_device(w, N, k, ldw));
+    phase_begin();
+    launch_gather_weights(d_w_in_.p, N, k, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_end(kPhGather);
+    pin_w_k_ = k;
+    return BBFMM_OK;
+}
+
+bool FmmTree::weights_match_staged(const double *w, int k, int64_t ldw) const {
+    const int64_t N = tree_.n_points;
+    if (pin_w_k_ != k || !h_pin_ || k < 1) return false;
+    std::atomic<bool> same{true};
+    for (int j = 0; j < k && same.load(std::memory_order_relaxed); ++j) {
+        const double *a = w + static_cast<size_t>(j) * ldw, *b = h_pin_ + static_cast<size_t>(j) * N;
+        parallel_for_chunks(N, kHostPiece, [&](int64_t lo, int64_t hi) {
+            if (same.load(std::memory_order_relaxed) && std::memcmp(a + lo, b + lo, static_cast<size_t>(hi - lo) * sizeof(double)) != 0)
+                same.store(false, std::memory_order_relaxed);
+        });
+    }
+    return same.load();
+}
+
+// m == N targets that are the handle's own source points, row for row and bit for bit (the unchanged caller of
+// rbf.rs:1359-1360 passes select_mat_rows(source_points, all rows)).  One differing coordinate, a swapped pair of
+// rows, -0.0 for 0.0: not the sources, and the caller takes the general path.
+bool FmmTree::targets_are_sources(const double *x, int64_t m, int64_t ldx) const {
+    const int64_t N = tree_.n_points;
+    if (!x || m != N || ldx < m || pts_.size() != static_cast<size_t>(N) * d_) return false;
+    std::atomic<bool> same{true};
+    for (int a = 0; a < d_ && same.load(std::memory_order_relaxed); ++a) {
+        const double *xa = x + static_cast<size_t>(a) * ldx, *pa = &pts_[static_cast<size_t>(a) * N];
+        parallel_for_chunks(N, kHostPiece, [&](int64_t lo, int64_t hi) {
+            if (same.load(std::memory_order_relaxed) && std::memcmp(xa + lo, pa + lo, static_cast<size_t>(hi - lo) * sizeof(double)) != 0)
+                same.store(false, std::memory_order_relaxed);
+        });
+    }
+    return same.load();
 }
 
 // upward_pass (bbfmm.rs:666-688)
@@ -686,8 +787,16 @@ int FmmTree::upward(int k, const DownwardPlan *dp) {
 // downward_pass (bbfmm.rs:778-857).  All cells are treated as "with targets": locals of
 // cells without targets are never read by the leaf pass, so results are unchanged.
 int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
+    CHK(downward_m2l(k, dp));
+    return downward_tail(k, dp, wx);
+}
+
+// The M2L part: reads the multipoles only -- neither the sorted weights nor any target set -- so evaluate() queues it
+// before it knows which targets it was given.
+int FmmTree::downward_m2l(int k, const DownwardPlan *dp) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
+    have_locals_ = false; // L is being rewritten; downward_tail says what it holds at the end
     // reset_local_coefficients (bbfmm.rs:627-632): tiles without any V-list entry are not written by
     // stage 2, and P2L / L2L add onto L
     HIPCHK(hipMemsetAsync(d_L_.p, 0, static_cast<size_t>(k) * C * cheb_.n_pad * sizeof(double), stream_));
@@ -743,6 +852,15 @@ int FmmTree::downward(int k, const DownwardPlan *dp, const TargetSet *wx) {
         launch_m2l_basis(d_basis_classes_.p, d_basis_tiles_e_.p, n_basis_tiles_, basis_pad_, cheb_.n_pad, k, C, d_Lc_.p, d_L_.p, stream_);
         phase_end(kPhM2L2);
     }
+    HIPCHK(hipGetLastError());
+    (void)t;
+    return BBFMM_OK;
+}
+
+// P2L (fused with M2P when wx is given) and L2L behind the M2L part
+int FmmTree::downward_tail(int k, const DownwardPlan *dp, const TargetSet *wx) {
+    const HostTree &t = tree_;
+    const int64_t C = t.n_cells();
     phase_begin();
     if (t.adaptive && wx) { // targets = all sources: P2L and M2P share their kernel evaluations (X = W^T)
         launch_wx_sym(kernel_, cheb_, wx->n_wx_jobs, wx->wx_tb.p, wx->wx_te.p, wx->wx_range.p, d_w_idx_.p, d_centers_.p,
@@ -826,7 +944,8 @@ int FmmTree::leaf_pass_far(const TargetSet &ts, int k, bool with_grads) {
 int FmmTree::set_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
-    CHK(upload_weights(w, rows, k, ldw));
+    pin_w_k_ = 0;
+    CHK(put_weights(w, rows, k, ldw));
     nrhs_ = k; // bbfmm.rs:384
     have_locals_ = locals_requested_ = false; // the stored local expansions belong to the old weights
     CHK(upward(k));
@@ -839,7 +958,7 @@ int FmmTree::set_local_coefficients(const double *w, int64_t rows, int k, int64_
     part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     if (nrhs_ == 0) return fail(BBFMM_BAD_ARGUMENT, "set_weights must be called first");
     if (k != nrhs_) return fail(BBFMM_BAD_ARGUMENT, "weights must have the column count given to set_weights");
-    CHK(upload_weights(w, rows, k, ldw));
+    CHK(put_weights(w, rows, k, ldw));
     CHK(downward(k));
     HIPCHK(hipStreamSynchronize(stream_));
     locals_requested_ = true;
@@ -857,16 +976,69 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     if (with_grads && m > 0 && (!grad || ldg < m)) return fail(BBFMM_BAD_ARGUMENT, "bad gradient array");
     if (leaves_only && !have_locals_) return fail(BBFMM_BAD_ARGUMENT, "set_local_coefficients must be called first");
     if (m >= (int64_t(1) << 31)) return fail(BBFMM_BAD_ARGUMENT, "more than 2^31-1 target points");
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
+    // The unchanged caller of the matvec (rbf.rs:1357-1364) evaluates at select_mat_rows(source_points, all rows):
+    // N targets that ARE the sources.  The whole-tree M2L reads the multipoles only, so it is queued first and the host
+    // compares targets and weights bit for bit beside it; equal targets take the resident sorted target set of
+    // matvec_device (unordered-pair near field, fused M2P + P2L) -- anything else falls through to the general path
+    // with the M2L already under way.
+    static const bool sources_fast = [] {
+        const char *e = std::getenv("BBFMM_EVAL_SOURCES_FAST"); // 0: always the general path (checker)
+        return !e || std::atoi(e) != 0;
+    }();
+    bool m2l_queued = false;
+    last_eval_at_sources_ = false;
+    if (sources_fast && !leaves_only && !with_grads && !have_part_ && m == tree_.n_points && src_targets_.m == m && w && rows >= m &&
+        ldw >= rows && static_cast<size_t>(2) * k * m <= kMaxPinnedDoubles) {
+        CHK(ensure_rhs_capacity(k));
+        CHK(downward_m2l(k, nullptr));
+        m2l_queued = true;
+        if (targets_are_sources(x, m, ldx)) {
+            const int64_t N = m;
+            const TargetSet &ts = src_targets_;
+            const auto t_cmp = std::chrono::steady_clock::now();
+            CHK(put_weights(w, rows, k, ldw)); // the weights of set_weights again: recognised, nothing moves
+            static const bool wx_on = [] {
+                const char *e = std::getenv("BBFMM_WX_FUSED");
+                const char *e2 = std::getenv("BBFMM_P2P_SYM");
+                return (!e || std::atoi(e) != 0) && (!e2 || std::atoi(e2) != 0);
+            }();
+            const bool wx = wx_on && !deterministic_ && ts.sym && ts.n_wx_jobs > 0;
+            if (wx) HIPCHK(hipMemsetAsync(ts.out.p, 0, static_cast<size_t>(k) * ts.m * sizeof(double), stream_));
+            CHK(downward_tail(k, nullptr, wx ? &ts : nullptr));
+            CHK(leaf_pass_near(ts, k, false, stream_, 3, wx));
+            CHK(leaf_pass_far(ts, k, false));
+            phase_begin();
+            launch_scatter_output(ts.out.p, ts.m, k, ts.perm.p, d_out_.p, N, 0, stream_);
+            phase_end(kPhScatter);
+            HIPCHK(hipGetLastError());
+            double *pin_out = h_pin_ + static_cast<size_t>(k) * N; // behind the staged weights (put_weights sized the buffer)
+            CHK(download_pieces(d_out_.p, static_cast<int64_t>(k) * N, pin_out, [&](int64_t pb, int64_t pe) {
+                while (pb < pe) { // a piece may run over a column boundary
+                    const int64_t col = pb / N, row = pb - col * N, len = std::min(pe - pb, N - row);
+                    std::memcpy(out + col * ldo + row, pin_out + pb, static_cast<size_t>(len) * sizeof(double));
+                    pb += len;
+                }
+            }));
+            last_eval_at_sources_ = true;
+            if (verbose) {
+                const auto t_end = std::chrono::steady_clock::now();
+                std::fprintf(stderr, "[bbfmm] evaluate: the %lld targets are the sources (compared in %.3f ms beside the M2L); total %.3f ms\n",
+                             static_cast<long long>(m), std::chrono::duration<double, std::milli>(t_cmp - t_begin).count(),
+                             std::chrono::duration<double, std::milli>(t_end - t_begin).count());
+            }
+            return BBFMM_OK;
+        }
+    }
     TargetSet ts;
     std::vector<int32_t> target_leaves;
     arena_begin();
-    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
-    const auto t_begin = std::chrono::steady_clock::now();
     int rc = build_target_set(x, m, ldx, &ts, bad_point_index, leaves_only ? nullptr : &target_leaves); // points_to_keys, bbfmm.rs:455-465
     const auto t_targets = std::chrono::steady_clock::now();
     // w == NULL (leaves-only entry points): keep the weights already on the device, i.e. those the stored
     // local coefficients were computed from -- no N x k host-to-device copy per batch
-    if (rc == BBFMM_OK && (w || !leaves_only)) rc = upload_weights(w, rows, k, ldw);
+    if (rc == BBFMM_OK && (w || !leaves_only)) rc = put_weights(w, rows, k, ldw);
     DownwardPlan dplan;
     if (rc == BBFMM_OK && !leaves_only) {
         // downward pass over cells_with_targets (bbfmm.rs:468-480) when the targets are few; many
@@ -874,9 +1046,9 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
         // set_local_coefficients has stored the whole-tree expansions (Leaves mode, rbf.rs:836-838)
         // the whole-tree pass is kept, so that evaluate_leaves stays valid afterwards.
         // (planning costs host time per call: measured break-even near N/100 targets at 10M sources)
-        const bool restricted = m * 128 < tree_.n_points && !locals_requested_;
+        const bool restricted = m * 128 < tree_.n_points && !locals_requested_ && !m2l_queued;
         if (restricted) rc = build_downward_plan(target_leaves, &dplan);
-        if (rc == BBFMM_OK) rc = downward(k, restricted ? &dplan : nullptr);
+        if (rc == BBFMM_OK) rc = m2l_queued ? downward_tail(k, nullptr, nullptr) : downward(k, restricted ? &dplan : nullptr);
     }
     if (rc == BBFMM_OK && with_grads && !kernel_supports_gradients(kernel_.id)) // bbfmm.rs:634-658
         rc = fail(BBFMM_KERNEL_NO_GRADIENTS,
@@ -934,6 +1106,7 @@ int FmmTree::matvec_device(const double *d_w, int64_t ldw, int k, double *d_out,
     if (!d_w || !d_out || k < 1 || ldw < N || ldo < N) return fail(BBFMM_BAD_ARGUMENT, "bad device matvec arguments");
     CHK(ensure_rhs_capacity(k));
     nrhs_ = k;
+    pin_w_k_ = 0; // the sorted weights come from the caller's device buffer now
     phase_begin();
     launch_gather_weights(d_w, ldw, k, d_order_.p, N, d_w_sorted_.p, stream_);
     phase_end(kPhGather);
@@ -979,6 +1152,7 @@ int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, doub
     if (!d_w || k < 1 || ldw < N || (cnt > 0 && !d_coarse)) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
     CHK(ensure_rhs_capacity(k));
     nrhs_ = k;
+    pin_w_k_ = 0;
     have_locals_ = locals_requested_ = false;
     phase_begin(); // only the weights this rank reads: its subtree and halo (the rest of w_sorted keeps stale values)
     launch_gather_weights_subset(d_w, ldw, k, d_order_.p, part_plan_.d_gather_pos.p, static_cast<int64_t>(part_plan_.gather_pos_h.size()), N,
@@ -1126,50 +1300,26 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
         // All sources (the FGMRES matvec, rbf.rs:105-117): the targets already live on the device.
         // Host traffic goes through one pinned staging buffer (pageable copies run at a fraction of
         // the PCIe rate), and the host loops are threaded.
-        CHK(stage_weights_to_device(w, N));
-        double *pin_out = h_pin_ + N;
         CHK(ensure_rhs_capacity(1));
+        CHK(stage_weights_to_device(w, N, 1, N));
+        double *pin_out = h_pin_ + N;
         nrhs_ = 1;
         if (have_part_) // a partitioned handle fills its owned rows only; the others read as 0
             HIPCHK(hipMemsetAsync(d_out_.p, 0, static_cast<size_t>(N) * sizeof(double), stream_));
         CHK(matvec_device(d_w_in_.p, N, 1, d_out_.p, N, false)); // set_weights + evaluate, rbf.rs:1357-1364
-        // The way back in pieces as well: an event behind each piece's copy, and the host threads add the nugget
-        // and polynomial terms (rbf.rs:1366-1376) of a piece as soon as it has landed.
-        const int64_t n_pieces = (N + kHostPiece - 1) / kHostPiece;
-        while (static_cast<int64_t>(ev_out_.size()) < n_pieces) {
-            hipEvent_t ev;
-            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            ev_out_.push_back(ev);
-        }
-        for (int64_t pc = 0; pc < n_pieces; ++pc) {
-            const int64_t b = pc * kHostPiece, e = std::min(N, b + kHostPiece);
-            HIPCHK(hipMemcpyAsync(pin_out + b, d_out_.p + b, static_cast<size_t>(e - b) * sizeof(double), hipMemcpyDeviceToHost, stream_));
-            HIPCHK(hipEventRecord(ev_out_[static_cast<size_t>(pc)], stream_));
-        }
-        HIPCHK(hipEventSynchronize(ev_out_[0])); // the product is done and the first piece is here: start the team
-        std::atomic<int> err{0};
-        parallel_for_chunks(N, kHostPiece, [&](int64_t b, int64_t e) { // chunks start at piece boundaries, ascending
-            bind_device();
-            for (int64_t pb = b; pb < e; pb += kHostPiece) {
-                const hipError_t r = hipEventSynchronize(ev_out_[static_cast<size_t>(pb / kHostPiece)]);
-                if (r != hipSuccess) {
-                    err.store(static_cast<int>(r));
-                    return;
+        // The way back in pieces as well; the host threads add the nugget and polynomial terms (rbf.rs:1366-1376)
+        // of a piece as soon as it has landed.
+        CHK(download_pieces(d_out_.p, N, pin_out, [&](int64_t pb, int64_t pe) {
+            for (int64_t i = pb; i < pe; ++i) {
+                double v = pin_out[i] + w[i] * nugget;
+                if (poly) {
+                    double sacc = 0.0;
+                    for (int64_t q = 0; q < basis_size; ++q) sacc += poly[q * ldp + i] * w[N + q];
+                    v += sacc;
                 }
-                const int64_t pe = std::min(e, pb + kHostPiece);
-                for (int64_t i = pb; i < pe; ++i) {
-                    double v = pin_out[i] + w[i] * nugget;
-                    if (poly) {
-                        double sacc = 0.0;
-                        for (int64_t q = 0; q < basis_size; ++q) sacc += poly[q * ldp + i] * w[N + q];
-                        v += sacc;
-                    }
-                    result[i] = v;
-                }
+                result[i] = v;
             }
-        });
-        HIPCHK(hipStreamSynchronize(stream_));
-        if (err.load() != 0) return hip_fail(static_cast<hipError_t>(err.load()), "hipEventSynchronize(result piece)");
+        }));
         std::fill(result + N, result + rows, 0.0); // the last basis_size rows stay 0 (rbf.rs:1346)
         return BBFMM_OK;
     }
@@ -1180,9 +1330,9 @@ int FmmTree::fast_matrix_vector_product(const double *w, int64_t rows, int64_t b
     const int64_t m = n_target_indices;
     std::fill(result, result + rows, 0.0); // rbf.rs:1346
     if (m == 0) return BBFMM_OK;
-    CHK(stage_weights_to_device(w, N));
-    double *pin_out = h_pin_ + N;
     CHK(ensure_rhs_capacity(1));
+    CHK(stage_weights_to_device(w, N, 1, N));
+    double *pin_out = h_pin_ + N;
     nrhs_ = 1;
     phase_begin();
     launch_gather_weights(d_w_in_.p, N, 1, d_order_.p, N, d_w_sorted_.p, stream_);

@@ -188,6 +188,7 @@ class FmmTree {
     }
     int device() const { return device_; }
     bool tree_built_on_device() const { return tree_built_on_device_; }
+    bool last_evaluate_at_sources() const { return last_eval_at_sources_; }
     void stats(bbfmm_tree_stats *out) const;
     void set_profiling(bool on) { profiling_ = on; }
     // Resolves the recorded event pairs (synchronises the stream) and returns the totals.
@@ -225,6 +226,8 @@ class FmmTree {
     int upward(int k, const DownwardPlan *dp = nullptr); // P2M + M2M from w_sorted_ (a partition's plan: needed cells only)
     // M2L + P2L + L2L into L_ (restricted by a plan); wx: run P2L fused with M2P into wx->out (zeroed by the caller)
     int downward(int k, const DownwardPlan *dp = nullptr, const TargetSet *wx = nullptr);
+    int downward_m2l(int k, const DownwardPlan *dp);                          // its M2L part (reads M only)
+    int downward_tail(int k, const DownwardPlan *dp, const TargetSet *wx);    // P2L (+ M2P when wx) and L2L
     int leaf_pass(const TargetSet &ts, int k, bool with_grads);
     int leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStream_t st, int parts, bool wx_done = false);
     int leaf_pass_far(const TargetSet &ts, int k, bool with_grads);
@@ -386,7 +389,14 @@ class FmmTree {
     double *h_pin_ = nullptr; // pinned staging for the host-buffer matvec (N doubles up, N down)
     size_t h_pin_n_ = 0;
     int ensure_pinned(size_t n);
-    int stage_weights_to_device(const double *w, int64_t n); // host rows -> d_w_in_, staging and PCIe overlapped
+    int stage_weights_to_device(const double *w, int64_t n, int k, int64_t ldw); // host rows -> d_w_in_, staging and PCIe overlapped
+    template <class F> int download_pieces(const double *d_src, int64_t total, double *pin_out, F &&consume);
+    // h_pin_[0, pin_w_k_ * N) holds exactly the host weights d_w_sorted_ was gathered from (0: no such copy)
+    int pin_w_k_ = 0;
+    int put_weights(const double *w, int64_t rows, int k, int64_t ldw);
+    bool weights_match_staged(const double *w, int k, int64_t ldw) const;
+    bool targets_are_sources(const double *x, int64_t m, int64_t ldx) const;
+    bool last_eval_at_sources_ = false;
     static constexpr int64_t kHostPiece = int64_t(1) << 18;  // rows per piece of the host <-> device pipelines (2 MB)
     std::vector<hipEvent_t> ev_out_;                         // per piece of the pipelined copy back
     TargetSet src_targets_;  // targets = sources (the matvec)

@@ -112,10 +112,14 @@ class PartitionedMatvec:
             dist.all_gather_into_tensor(counts, mine, group=group)
             self.counts = [int(c) for c in counts.tolist()]
             self.m_max = max(max(self.counts), 1)
-            b = tree.partition_bounds()
-            if len(b) - 1 < self.world:
-                raise ValueError("the handle's partition has fewer parts than the group has ranks")
-            self.bounds = [int(x) for x in b]
+            self.bounds = [int(x) for x in tree.partition_bounds()]
+            # A verdict about the partition is taken by the whole group or not at all: a rank that raised alone would leave
+            # its peers waiting in the next collective.  (min over the ranks of "my handle fits the group")
+            enough = torch.tensor([1 if len(self.bounds) - 1 >= self.world else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(enough, op=dist.ReduceOp.MIN, group=group)
+            if int(enough.item()) == 0:
+                raise ValueError("the partition of a handle in the group has fewer parts than the group has ranks "
+                                 "(this rank: %d parts, %d ranks)" % (len(self.bounds) - 1, self.world))
             self.send = torch.zeros((k, self.m_max), dtype=torch.float64, device=device)
             self.recv = torch.empty((self.world, k, self.m_max), dtype=torch.float64, device=device)
             if self.staged:
@@ -131,9 +135,14 @@ class PartitionedMatvec:
             cur = torch.cuda.current_stream(device)
             self.stream.wait_stream(cur)
             self.comm.wait_stream(cur)
-        if self.split and not always_exchange and not self.check_partition():
-            raise ValueError("the handle's partition does not match the group: rank %d of %d holds part %d, bounds %s, "
-                             "row counts %s" % (self.rank, self.world, tree.partition_rank(), self.bounds, self.counts))
+        if self.split and not always_exchange:
+            cdev = torch.device("cpu") if self.staged else device
+            ok = torch.tensor([1 if self.check_partition() else 0], dtype=torch.int64, device=cdev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)      # every rank raises, or none does
+            if int(ok.item()) == 0:
+                raise ValueError("a handle's partition does not match the group (this rank: %s): rank %d of %d holds part "
+                                 "%d, bounds %s, row counts %s" % ("ok" if self.check_partition() else "MISMATCH", self.rank,
+                                                                   self.world, tree.partition_rank(), self.bounds, self.counts))
 
     def check_partition(self) -> bool:
         """True when the ranks' shares are the parts of the handle's partition, in order, and cover every row once."""

@@ -370,6 +370,11 @@ class FmmTree:
         self._raise(self._lib.bbfmm_get_tree_stats(self._h, ctypes.byref(s)))
         return s
 
+    def last_evaluate_at_sources(self) -> bool:
+        """True when the last evaluate() found its targets to be the source points (bit for bit, row for row) and
+        ran the resident-target path of the matvec (include/ferreus_bbfmm_hip.h, bbfmm_last_evaluate_at_sources)."""
+        return bool(self._lib.bbfmm_last_evaluate_at_sources(self._h))
+
     def tree_built_on_device(self) -> bool:
         return bool(self._lib.bbfmm_tree_built_on_device(self._h))
 

@@ -144,6 +144,16 @@ int bbfmm_set_local_coefficients(bbfmm_handle *h, const double *w, int64_t rows,
 int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
                    const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo,
                    int64_t *bad_point_index);
+/* The unchanged caller of the FGMRES matvec (rbf.rs:1357-1364) calls set_weights(w) and then
+ * evaluate(w, select_mat_rows(source_points, all rows)).  bbfmm_evaluate recognises that sequence without being
+ * told: m == N targets that equal the handle's source points bit for bit and row for row (threaded comparison on
+ * the host, run beside the M2L) are served by the resident sorted target set -- every unordered near-field pair
+ * once, M2P fused with P2L, no target upload or grouping -- and weights equal to those of the preceding
+ * bbfmm_set_weights are not transferred a second time.  One differing bit (a perturbed coordinate, two rows
+ * swapped, -0.0 for 0.0) takes the general path.  Results of the two paths agree to summation order (1e-12).
+ * Returns 1 when the last bbfmm_evaluate on this handle took the resident-source path, else 0.
+ * BBFMM_EVAL_SOURCES_FAST=0 in the environment disables the detection (checker). */
+int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h);
 
 /* FmmTree::evaluate_with_gradients (utils.rs:453-461 -> bbfmm.rs:434-441).
  * grad is m x (k*d), columns [rhs0_dx, rhs0_dy, rhs0_dz, rhs1_dx, ...]. */
@@ -197,6 +207,12 @@ int bbfmm_prepare_target_subset(bbfmm_handle *h, const int64_t *target_indices, 
  *   d_out[:, j] = K(X, X) d_w[:, j]      (set_weights + evaluate at the sources)
  * d_w / d_out are DEVICE pointers (N x k, ldw / ldo).  Asynchronous on the
  * handle's stream unless sync != 0.  This is what bench.py times.
+ * Reproducibility: for ANY k (since round 4 also k > 1, and on partitioned handles) the near field runs the
+ * unordered-pair kernels and M2P is fused with P2L; both accumulate with f64 atomics, so two runs agree to summation
+ * order (<= 1e-12 relative), not bit for bit.  Handles created with BBFMM_FLAG_DETERMINISTIC (or a process with
+ * BBFMM_P2P_SYM=0 in its environment: ordered pairs, separate P2L and M2P) keep a fixed order.  The same holds for
+ * bbfmm_fast_matrix_vector_product, for bbfmm_evaluate on targets that are the sources, and for the
+ * bbfmm_matvec_partition_* calls.
  */
 int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_out,
                         int64_t ldo, int32_t sync);

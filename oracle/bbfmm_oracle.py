@@ -1128,6 +1128,12 @@ def kernel_phi(kernel_id, r, base_range=1.0, total_sill=1.0):
                                             F64(r * r)))
 
 
+def select_mat_rows(existing_mat, row_indices):
+    """select_mat_rows, ferreus_rbf_utils/src/utils.rs:44-56: an owned matrix made of the wanted rows, in the order given
+    (out[i, j] = existing_mat[row_indices[i], j], the reference's Mat::from_fn)."""
+    return np.take(np.asarray(existing_mat), np.asarray(row_indices, dtype=np.int64), axis=0).copy()
+
+
 def fast_matrix_vector_product(tree: FmmTree, weights, basis_size=0, target_indices=None,
                                polynomial_matrix=None, nugget=0.0):
     """ferreus_rbf/src/rbf.rs:1338-1379"""
@@ -1136,7 +1142,8 @@ def fast_matrix_vector_product(tree: FmmTree, weights, basis_size=0, target_indi
     wlen = len(w) - basis_size
     idx = np.arange(wlen) if target_indices is None else np.asarray(target_indices, dtype=np.int64)
     tree.set_weights(w[:, None])
-    vals = tree.evaluate(w[:, None], tree.source_points[idx])[:, 0]
+    targets = tree.source_points if target_indices is None else select_mat_rows(tree.source_points, idx)   # rbf.rs:1359-1360
+    vals = tree.evaluate(w[:, None], targets)[:, 0]
     result[idx] = vals + w[idx] * nugget
     if polynomial_matrix is not None:
         result[idx] += polynomial_matrix[idx] @ w[wlen:wlen + basis_size]

@@ -27,9 +27,11 @@ def main():
     x = pts[rng.choice(n, 5000, replace=False)] * (1.0 - 1e-9)   # inside occupied leaves (the tree is sparse: empty cells do not exist)
     tree.set_weights(w)
     z = tree.evaluate(w, x)
+    u = tree.evaluate(w, pts)                                     # the unchanged caller (rbf.rs:1357-1364): targets = sources
+    at_sources = int(tree.last_evaluate_at_sources())
     nv, nc = tree.debug_m2l_variants()
-    np.savez(out_path, y=y, y_again=y_again, z=z, n_w=st.n_w, depth=st.depth, on_device=int(tree.tree_built_on_device()),
-             n_variants=nv)
+    np.savez(out_path, y=y, y_again=y_again, z=z, u=u, at_sources=at_sources, n_w=st.n_w, depth=st.depth,
+             on_device=int(tree.tree_built_on_device()), n_variants=nv)
 
 
 if __name__ == "__main__":

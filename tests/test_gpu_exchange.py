@@ -130,3 +130,54 @@ def test_single_rank_rccl_exchange_matches_unpartitioned():
         tree.set_partition(0, 1)
     finally:
         dist.destroy_process_group()
+
+
+def test_partitioned_six_rhs_mixed_levels_against_the_deterministic_path():
+    """with more than four right-hand sides the unordered-pair near field and the fused M2P + P2L kernel
+    run in passes of four (second pass: rhs offset k0 = 4), and on a partition the fused kernel writes at an output
+    offset (out_off != 0 for every rank but the first).  Six rhs, a mixed-level cloud (W / X lists live), three ranks
+    run in turn -- against a BBFMM_FLAG_DETERMINISTIC handle (ordered pairs, separate P2L and M2P, fixed summation
+    order) at 1e-12."""
+    import torch
+    import ferreus_rbf_rs_amd as F
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    rng = np.random.default_rng(11)
+    n, K, world = 150_000, 6, 3
+    pts = np.vstack([rng.random((130_000, 3)), np.clip(rng.normal(size=(20_000, 3)) * 0.05 + 0.5, 0.0, 0.999)])
+    kp = F.KernelParams(F.FmmKernelType.LinearRbf)
+    det = F.FmmTree(pts, 6, kp, True, True, deterministic=True)
+    assert det.stats().n_w > 0
+    w = torch.from_numpy(rng.standard_normal((K, n))).to(dev)
+    ref = torch.zeros_like(w)
+    det.matvec_device(w.data_ptr(), n, K, ref.data_ptr(), n, True)
+    ref2 = torch.zeros_like(w)
+    det.matvec_device(w.data_ptr(), n, K, ref2.data_ptr(), n, True)
+    assert torch.equal(ref, ref2)                                         # the reference path is bitwise reproducible
+    del det
+    tree = F.FmmTree(pts, 6, kp, True, True)
+    one = torch.zeros_like(w)
+    tree.matvec_device(w.data_ptr(), n, K, one.data_ptr(), n, True)       # unpartitioned, default kernels, two passes
+    assert (one - ref).abs().max() / ref.abs().max() < 1e-12
+    partial = []
+    for r in range(world):
+        tree.set_partition(r, world)
+        c = torch.zeros((K, tree.partition_coarse_count()), dtype=torch.float64, device=dev)
+        tree.matvec_partition_upward(w.data_ptr(), n, K, c.data_ptr())
+        torch.cuda.synchronize()
+        torch.cuda.ExternalStream(tree.stream(), device=dev).synchronize()
+        partial.append(c)
+    total = torch.stack(partial).sum(0).contiguous()
+    full = torch.full_like(w, float("nan"))
+    for r in range(world):
+        tree.set_partition(r, world)
+        scratch = torch.zeros_like(total)
+        tree.matvec_partition_upward(w.data_ptr(), n, K, scratch.data_ptr())
+        o = torch.zeros_like(w)
+        tree.matvec_partition_finish(total.data_ptr(), o.data_ptr(), n, True)
+        idx = torch.as_tensor(tree.partition_rows(), device=dev)
+        full[:, idx] = o[:, idx]
+    assert not torch.isnan(full).any()
+    err = ((full - ref).abs().amax(dim=1) / ref.abs().amax(dim=1)).max()   # per right-hand side
+    assert err < 1e-12, float(err)

@@ -23,6 +23,7 @@ SWITCHES = [
     ("s2_one_workgroup_per_tile", {"BBFMM_M2L_S2_ZSPLIT": "1"}, []),
     ("s2_no_ksplit", {"BBFMM_M2L_S2_KSPLIT": "1"}, []),
     ("operators_host_fill", {"BBFMM_M2L_ASSEMBLE_HOST": "1"}, []),
+    ("evaluate_at_sources_general_path", {"BBFMM_EVAL_SOURCES_FAST": "0"}, []),
     ("deterministic", {}, ["deterministic"]),
     ("deterministic_again", {}, ["deterministic"]),
 ]
@@ -50,6 +51,9 @@ def test_switch_equals_default_path(runs, name):
     assert int(ref["n_w"]) > 0 and int(ref["on_device"]) == 1           # mixed levels, device-built tree by default
     assert relerr(got["y"], ref["y"]) < 1e-12, name
     assert relerr(got["z"], ref["z"]) < 1e-12, name
+    assert relerr(got["u"], ref["u"]) < 1e-12, name
+    assert int(ref["at_sources"]) == 1
+    assert int(got["at_sources"]) == (0 if name == "evaluate_at_sources_general_path" else 1)
     if name == "tree_host":
         assert int(got["on_device"]) == 0
     if name == "variants_off":
@@ -63,3 +67,4 @@ def test_deterministic_flag_is_bitwise_reproducible(runs):
     a, b = runs["deterministic"], runs["deterministic_again"]
     assert np.array_equal(a["y"], a["y_again"])                          # same handle, twice
     assert np.array_equal(a["y"], b["y"]) and np.array_equal(a["z"], b["z"])   # another process
+    assert np.array_equal(a["u"], b["u"])

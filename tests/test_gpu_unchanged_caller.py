@@ -1,0 +1,156 @@
+"""The unchanged caller of the FGMRES matvec: ferreus_rbf/src/rbf.rs:1357-1364 calls `set_weights(w)` and then
+`evaluate(w, select_mat_rows(source_points, all rows))`.  bbfmm_evaluate recognises N targets that are the handle's
+sources bit for bit and row for row and serves them from the resident sorted target set (what bbfmm_matvec_device
+runs); anything else takes the general path.  Both against the oracle at 1e-11 (same host-computed operators: only
+the summation order differs), against each other and against the patched entry point at 1e-12."""
+import numpy as np
+import pytest
+
+import ferreus_rbf_rs_amd as F
+from conftest import clustered_points, inject_product_operators, relerr
+from oracle import bbfmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+
+
+@pytest.fixture(scope="module")
+def case():
+    rng = np.random.default_rng(77)
+    pts = np.vstack([rng.random((120000, 3)), clustered_points(rng, 10000, 3)])   # mixed levels: W / X lists live
+    pts[5, 1] = 0.0                                                                # a coordinate whose sign bit can flip
+    t = F.FmmTree(pts, 7, F.KernelParams(F.FmmKernelType.LinearRbf), True, True)
+    r = O.FmmTree(pts, 7, 0, True, True)
+    inject_product_operators(t, r)
+    assert t.stats().n_w > 0
+    return rng, pts, t, r
+
+
+def test_targets_equal_sources_take_the_resident_path(case):
+    rng, pts, t, r = case
+    n = len(pts)
+    w = np.asfortranarray(rng.standard_normal((n + 4, 1)))       # N + basis_size rows, as the solver's vectors (rbf.rs:1344)
+    t.set_weights(w)
+    y = t.evaluate(w, pts.copy())                                # a fresh copy of the rows: select_mat_rows, rbf.rs:1359-1360
+    assert t.last_evaluate_at_sources()
+    r.set_weights(w[:n])
+    yr = r.evaluate(w[:n], pts)
+    assert relerr(y, yr) < TOL
+    assert relerr(t.debug_get_coefficients("L", 1), r.L) < TOL
+    ym = t.fast_matrix_vector_product(w[:, 0].copy(), basis_size=4)          # the patched caller
+    assert relerr(y[:, 0], ym[:n]) < 1e-12
+    # again on the same handle, behind an entry point that replaced the staged weights
+    t.set_weights(w)
+    y2 = t.evaluate(w, pts)
+    assert t.last_evaluate_at_sources() and relerr(y2, y) < 1e-12
+
+
+def test_two_rhs_and_strided_weights(case):
+    rng, pts, t, r = case
+    n = len(pts)
+    w = np.asfortranarray(rng.standard_normal((n + 10, 2)))
+    t.set_weights(w)
+    y = t.evaluate(w, pts)
+    assert t.last_evaluate_at_sources() and y.shape == (n, 2)
+    r.set_weights(w[:n])
+    assert relerr(y, r.evaluate(w[:n], pts)) < TOL
+
+
+def test_one_perturbed_target_takes_the_general_path(case):
+    rng, pts, t, r = case
+    n = len(pts)
+    w = rng.standard_normal((n, 1))
+    x = pts.copy()
+    x[n // 2, 2] = np.nextafter(x[n // 2, 2], 0.0)                # one bit of one coordinate
+    t.set_weights(w)
+    y = t.evaluate(w, x)
+    assert not t.last_evaluate_at_sources()
+    r.set_weights(w)
+    assert relerr(y, r.evaluate(w, x)) < TOL
+    y0 = t.evaluate(w, pts)                                       # and the two paths agree where the targets agree
+    assert t.last_evaluate_at_sources()
+    keep = np.arange(n) != n // 2
+    assert relerr(y[keep], y0[keep]) < 1e-12
+
+
+def test_row_permuted_sources_are_not_mistaken_for_the_sources(case):
+    rng, pts, t, r = case
+    n = len(pts)
+    w = rng.standard_normal((n, 1))
+    perm = np.arange(n)
+    perm[[10, n - 3]] = perm[[n - 3, 10]]                         # the same point set, two rows swapped
+    t.set_weights(w)
+    y = t.evaluate(w, pts[perm])
+    assert not t.last_evaluate_at_sources()
+    y0 = t.evaluate(w, pts)
+    assert t.last_evaluate_at_sources()
+    assert relerr(y, y0[perm]) < 1e-12
+    assert abs(y0[10, 0] - y0[n - 3, 0]) > 1e-6 * np.abs(y0).max()   # the swap is visible in the values
+    full = rng.permutation(n)                                     # and a full shuffle
+    yf = t.evaluate(w, pts[full])
+    assert not t.last_evaluate_at_sources() and relerr(yf, y0[full]) < 1e-12
+
+
+def test_negative_zero_is_not_positive_zero(case):
+    rng, pts, t, r = case
+    n = len(pts)
+    w = rng.standard_normal((n, 1))
+    x = pts.copy()
+    x[5, 1] = -0.0                                                # equal as a number, different as bits: general path, same values
+    t.set_weights(w)
+    y = t.evaluate(w, x)
+    assert not t.last_evaluate_at_sources()
+    y0 = t.evaluate(w, pts)
+    assert t.last_evaluate_at_sources() and relerr(y, y0) < 1e-12
+
+
+def test_other_weights_in_evaluate_than_in_set_weights(case):
+    """The reference reads the multipoles left by set_weights and the weights handed to evaluate (bbfmm.rs:444-507: P2P
+    and P2L take the argument): a caller that passes different vectors gets exactly that mixture on both paths."""
+    rng, pts, t, r = case
+    n = len(pts)
+    w1, w2 = rng.standard_normal((n, 1)), rng.standard_normal((n, 1))
+    r.set_weights(w1)
+    yr = r.evaluate(w2, pts)
+    t.set_weights(w1)
+    y = t.evaluate(w2, pts)
+    assert t.last_evaluate_at_sources() and relerr(y, yr) < TOL
+    x = pts.copy()
+    x[0, 0] = np.nextafter(x[0, 0], 1.0)
+    t.set_weights(w1)
+    yg = t.evaluate(w2, x)
+    assert not t.last_evaluate_at_sources()
+    assert relerr(yg[1:], yr[1:]) < 1e-9                          # (row 0 moved by one ulp)
+    # the staged copy follows the weights that are on the device: w2 now, so w1 must be transferred again
+    y1 = t.evaluate(w1, pts)
+    r.set_weights(w1)
+    assert relerr(y1, r.evaluate(w1, pts)) < TOL
+
+
+def test_deterministic_handle_and_leaves_after_the_resident_path():
+    rng = np.random.default_rng(5)
+    pts = rng.random((60000, 3))
+    w = rng.standard_normal((60000, 1))
+    t = F.FmmTree(pts, 5, F.KernelParams(F.FmmKernelType.CubicRbf), True, True, deterministic=True)
+    t.set_weights(w)
+    a = t.evaluate(w, pts)
+    assert t.last_evaluate_at_sources()
+    t.set_weights(w)
+    b = t.evaluate(w, pts)
+    assert np.array_equal(a, b)                                   # ordered pairs, no atomics: bit for bit
+    x = pts[:100] * (1 - 1e-9)
+    t.set_local_coefficients(w)
+    z = t.evaluate_leaves(w, x)
+    assert relerr(z, t.evaluate(w, x)) < 1e-12
+
+
+def test_gradients_at_the_sources_keep_the_general_path(case):
+    rng, pts, t, r = case
+    n = len(pts)
+    t2 = F.FmmTree(pts[:30000], 6, F.KernelParams(F.FmmKernelType.CubicRbf), True, True)
+    w = rng.standard_normal((30000, 1))
+    t2.set_weights(w)
+    y, g = t2.evaluate_with_gradients(w, pts[:30000])
+    assert not t2.last_evaluate_at_sources()
+    y0 = t2.evaluate(w, pts[:30000])
+    assert t2.last_evaluate_at_sources() and relerr(y, y0) < 1e-12 and g.shape == (30000, 3)

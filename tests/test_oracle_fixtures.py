@@ -63,7 +63,8 @@ def test_remaining_utils_doctests():
     the dense sum with the linear kernel phi(r) = -r."""
     assert list(O.argsort_stable([30, 10, 20])) == [1, 2, 0]
     m = np.array([[0.0, 1.0], [1.0, 1.0], [2.0, 2.0], [3.0, 3.0]])
-    assert m[[0, 2]].tolist() == [[0.0, 1.0], [2.0, 2.0]]
+    assert O.select_mat_rows(m, [0, 2]).tolist() == [[0.0, 1.0], [2.0, 2.0]]    # the function the oracle's matvec calls
+    assert O.select_mat_rows(m, [3, 0, 3]).tolist() == [[3.0, 3.0], [0.0, 1.0], [3.0, 3.0]]
     pts = np.array([[1.0, 2.0], [4.0, 6.0]])
     y = O.dense_sum(O.KERNEL_IDS["LinearRbf"], 1.0, 1.0, pts, pts, np.array([[1.0], [1.0]]))
     assert y[:, 0].tolist() == [-5.0, -5.0]                               # -get_distance, exactly

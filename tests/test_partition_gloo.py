@@ -75,3 +75,44 @@ def test_two_rank_exchange_reassembles_the_matvec():
     assert all(r[1] for r in res), res
     assert all(r[2] for r in res), res
     assert sum(r[3] for r in res) == n
+
+
+def _mismatch_worker(rank, world, port, n, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import ferreus_rbf_rs_amd as F
+        from ferreus_rbf_rs_amd.distributed import PartitionedMatvec
+        pts = np.random.default_rng(5).random((n, 3))
+        tree = F.FmmTree(pts, 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, host_only=True)
+        tree.set_partition(0, world)            # rank 1 holds part 0 as well: ITS handle does not match the group
+        try:
+            PartitionedMatvec(tree, n, 1, torch.device("cpu"))
+            verdict = "accepted"
+        except ValueError as e:
+            verdict = "refused: " + str(e)
+        dist.barrier()                          # both ranks are still in step: nobody hangs in a collective the other left
+        q.put((rank, verdict))
+        dist.destroy_process_group()
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "error: " + repr(e)))
+
+
+@pytest.mark.timeout(300)
+def test_a_partition_mismatch_on_one_rank_is_refused_by_every_rank():
+    """the check is per rank (`partition_rank() == rank`), the verdict must be collective -- a rank raising
+    alone would leave its peers in the next all-reduce."""
+    world, n = 2, 20000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert res[0].startswith("refused"), res          # (rank 0 sees the doubled row counts; what matters: it did not go on alone)
+    assert res[1].startswith("refused") and "this rank: MISMATCH" in res[1], res
