@@ -9,7 +9,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libferreus_bbfmm_hip.so")
+# FERREUS_BBFMM_HIP_LIB: another build of the same sources (the host-sanitizer libraries of build.py --sanitize)
+LIB_PATH = os.environ.get("FERREUS_BBFMM_HIP_LIB") or os.path.join(HERE, "libferreus_bbfmm_hip.so")
 
 # bbfmm_status
 OK, POINT_OUTSIDE_TREE, KERNEL_NO_GRADIENTS, BAD_ARGUMENT, DEVICE_ERROR, UNSUPPORTED = range(6)

@@ -69,11 +69,47 @@ def _compiler_id(hipcc: str) -> str:
     return _COMPILER_ID
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+# Host-side sanitizer builds (CPU only -- never on the GPU box, whose pool refuses GPU sanitizers): the HOST code of
+# every translation unit instrumented, device code compiled as always.  A second library beside the product's, loaded
+# instead of it when FERREUS_BBFMM_HIP_LIB names it (scripts/sanitize_host.sh preloads the matching runtime).
+SANITIZERS = {
+    "asan": ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"],
+    "tsan": ["-fsanitize=thread"],
+}
+
+
+def sanitized_lib(kind: str) -> str:
+    return os.path.join(HERE, f"libferreus_bbfmm_hip_{kind}.so")
+
+
+def sanitizer_runtime(kind: str, hipcc: str = None) -> str:
+    """The shared runtime to LD_PRELOAD into the Python process (clang's, matching the compiler that built the library)."""
+    hipcc = hipcc or os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    name = {"asan": "libclang_rt.asan-x86_64.so", "tsan": "libclang_rt.tsan-x86_64.so"}[kind]
+    out = subprocess.run([hipcc, f"-print-file-name={name}"], stdout=subprocess.PIPE, timeout=120).stdout.decode().strip()
+    if not os.path.isabs(out) or not os.path.exists(out):
+        raise FileNotFoundError(f"{name}: not found next to {hipcc}")
+    return out
+
+
+def build(force: bool = False, verbose: bool = False, sanitize: str = None) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    global OBJ, LIB
+    if sanitize:
+        if sanitize not in SANITIZERS:
+            raise ValueError(f"unknown sanitizer {sanitize!r}: one of {sorted(SANITIZERS)}")
+        obj_dir, lib_path = os.path.join(HERE, f"_obj_{sanitize}"), sanitized_lib(sanitize)
+    else:
+        obj_dir, lib_path = OBJ, LIB
+    return _build(hipcc, obj_dir, lib_path, force, verbose, sanitize)
+
+
+def _build(hipcc: str, OBJ: str, LIB: str, force: bool, verbose: bool, sanitize: str) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     flags = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-result", "--offload-arch=gfx950"]  # path-independent
+    if sanitize:   # -fno-gpu-sanitize: host code only; -shared-libsan: the runtime comes from the preloaded shared object
+        flags = ["-O1", "-g", "-fno-omit-frame-pointer"] + SANITIZERS[sanitize] + ["-fno-gpu-sanitize", "-shared-libsan"] + flags[1:]
     common = flags[:-1] + ["-I", CSRC, "-I", os.path.join(ROOT, "include")]
     flag_id = " ".join(flags) + "\n" + _compiler_id(hipcc)
     objs, digests, todo = [], [], []
@@ -106,6 +142,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     lib_stamp = os.path.join(OBJ, "lib.sha256")
     if force or _stale(LIB, lib_stamp, lib_digest):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs + ["-lpthread", "-ldl"]
+        if sanitize:
+            cmd[1:1] = SANITIZERS[sanitize] + ["-fno-gpu-sanitize", "-shared-libsan"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -114,4 +152,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    kind = None
+    for a in sys.argv[1:]:
+        if a == "--sanitize":
+            kind = "asan"
+        elif a.startswith("--sanitize="):
+            kind = a.split("=", 1)[1]
+    print(build(force="--force" in sys.argv, verbose=True, sanitize=kind))

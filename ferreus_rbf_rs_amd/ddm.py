@@ -135,7 +135,9 @@ class SchwarzPreconditioner:
             buf = (ctypes.c_double * (n * self.basis_size)).from_address(mp)
             self.monomial_matrix = np.frombuffer(buf, dtype=np.float64).reshape((n, self.basis_size), order="F").copy(order="F")
         from .solvers import _Operator
-        self._op = _Operator(ctypes.cast(lib.bbfmm_schwarz_apply, ctypes.c_void_p), h, (self,))
+        # (the operator must not keep `self` alive: a cycle would hold the factors -- 95 GB of HBM at 10M points -- until the
+        # cyclic collector happens to run; whoever passes the preconditioner to a solver holds it for the call anyway)
+        self._op = _Operator(ctypes.cast(lib.bbfmm_schwarz_apply, ctypes.c_void_p), h, ())
         self._op.errors = []
 
     def __call__(self, residual):
@@ -161,8 +163,13 @@ class SchwarzPreconditioner:
             raise RuntimeError(f"bbfmm_schwarz_debug_level_solve failed with status {rc}")
         return z
 
-    def __del__(self):
+    def close(self) -> None:
+        """Release the factors and every device buffer now (also done when the last reference goes)."""
         h = getattr(self, "_h", None)
         if h:
             self._lib.bbfmm_schwarz_destroy(h)
             self._h = None
+            self._op.user_ptr = None
+
+    def __del__(self):
+        self.close()

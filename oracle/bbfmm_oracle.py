@@ -53,11 +53,21 @@ COMPRESSION_NONE, COMPRESSION_SVD, COMPRESSION_ACA = 0, 1, 2
 def build_passes(force: bool = False) -> str:
     """Compile oracle/passes.c -> oracle/_build/liboracle_passes.so (gcc, OpenMP)."""
     src = os.path.join(_HERE, "passes.c")
+    if os.environ.get("ORACLE_PASSES_SANITIZE") == "1":
+        # the checker checked: AddressSanitizer + UBSan build (scripts/sanitize_host.sh preloads gcc's libasan.so)
+        so = os.path.join(_BUILD, "liboracle_passes_asan.so")
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            os.makedirs(_BUILD, exist_ok=True)
+            subprocess.check_call(["gcc", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                                   "-fno-sanitize-recover=undefined", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
+                                   "-std=c11", "-o", so, src, "-lm"])
+        return so
     if (not force) and os.path.exists(_SO) and os.path.getmtime(_SO) >= os.path.getmtime(src):
         return _SO
     os.makedirs(_BUILD, exist_ok=True)
     # -ffp-contract=off: the reference (rustc) never fuses a*b+c; keep plain IEEE arithmetic.
-    cmd = ["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared",
+    # -fno-math-errno: sqrt() is the instruction, not a call that may set errno (values unchanged; lets loops vectorise).
+    cmd = ["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-math-errno", "-fopenmp", "-fPIC", "-shared",
            "-std=c11", "-o", _SO, src, "-lm"]
     try:
         subprocess.check_call(cmd)
@@ -492,22 +502,22 @@ class KernelDoesNotSupportGradients(Exception):
 def points_to_keys(points: np.ndarray, leaves: set, depth: int, center, radius: float, d: int):
     """linear_tree.rs:487-520: deepest-level key, walk up until a leaf."""
     keys = points_to_anchor_keys(points, depth, center, radius)
-    out = np.zeros(len(keys), dtype=np.uint64)
-    cache = {}
-    for i, k in enumerate(keys.tolist()):
-        r = cache.get(k)
-        if r is None:
-            cur = k
-            while cur not in leaves:
-                cur = get_parent(cur, d)
-                if cur is None:
-                    break
-            r = -1 if cur is None else cur
-            cache[k] = r
-        if r == -1:
-            raise PointOutsideTree(i)      # smallest failing row: results are scanned in order (514-517)
-        out[i] = r
-    return out
+    uniq, inverse = np.unique(keys, return_inverse=True)        # the walk is a function of the deepest key: once per key
+    res = np.zeros(len(uniq), dtype=np.uint64)
+    bad = []
+    for j, k in enumerate(uniq.tolist()):
+        cur = k
+        while cur not in leaves:
+            cur = get_parent(cur, d)
+            if cur is None:
+                break
+        if cur is None:
+            bad.append(j)
+        else:
+            res[j] = cur
+    if bad:                                                     # smallest failing row: results are scanned in order (514-517)
+        raise PointOutsideTree(int(np.nonzero(np.isin(inverse, np.asarray(bad)))[0][0]))
+    return res[inverse]
 
 
 # ----------------------------------------------------------------------------
@@ -843,6 +853,11 @@ class FmmTree:
             raise ValueError(f"Unsupported number of dimensions: {self.d}")               # bbfmm.rs:293-298
         self.center, self.radius = calculate_tree_center_and_radius(tree_extents)
         self.nrhs = 1
+        self._parent_of = None
+        # cpu_baseline mode (bench.py): M2L through register-blocked GEMMs and the near field through gathered,
+        # vectorised loops (oracle/passes.c: oracle_m2l_gemm, leaf-pass flag 8) -- the arithmetic the reference's
+        # faer calls and monomorphised loops do; off for every test that uses the oracle as the checker
+        self.gemm_shaped = False
         self.tl = build_tree(self.source_points, self.center, self.radius,
                              self.params.max_points_per_cell, not self.sparse_tree, self.d,
                              self.adaptive_tree)
@@ -932,13 +947,17 @@ class FmmTree:
         """cells_with_sources / cells_with_targets: ancestors of the given leaves
         (bbfmm.rs:395-398, 475-478)."""
         flags = np.zeros(self.C, dtype=np.uint8)
-        k2i = self.tl.key_to_index_map
-        for c in leaf_cell_indices:
-            for a in get_ancestors(self.cell_keys[c], self.d):
-                i = k2i[a]
-                if flags[i]:
-                    break
-                flags[i] = 1
+        if self._parent_of is None:                             # parent index of every cell (-1: none), from the children lists
+            par = np.full(self.C, -1, dtype=np.int64)
+            counts = np.diff(self.child_ptr)
+            par[self.child_idx] = np.repeat(np.arange(self.C, dtype=np.int64), counts)
+            self._parent_of = par
+        cur = np.unique(np.asarray(leaf_cell_indices, dtype=np.int64))
+        while len(cur):                                         # get_ancestors includes the cell itself (morton.rs:193-210)
+            cur = cur[flags[cur] == 0]
+            flags[cur] = 1
+            cur = np.unique(self._parent_of[cur])
+            cur = cur[cur >= 0]
         return flags
 
     def _w(self, weights):
@@ -978,7 +997,8 @@ class FmmTree:
         tp = np.ascontiguousarray(tp)
         keys = points_to_keys(tp, self.tl.leaves, self.depth, self.center, self.radius, self.d)
         k2i = self.tl.key_to_index_map
-        cell_of = np.array([k2i[int(k)] for k in keys.tolist()], dtype=np.int64)
+        uniq, inverse = np.unique(keys, return_inverse=True)
+        cell_of = np.array([k2i[int(k)] for k in uniq.tolist()], dtype=np.int64)[inverse]
         order = np.argsort(cell_of, kind="stable")             # rows ascending inside a leaf
         counts = np.bincount(cell_of, minlength=self.C)
         tgt_ptr = np.zeros(self.C + 1, dtype=np.int64)
@@ -998,7 +1018,8 @@ class FmmTree:
             cells = np.ascontiguousarray(cells[active[cells] == 1])
             if level >= 2 and len(cells):
                 buf, u_off, vt_off, rank = self.opbuf[level]
-                L.oracle_m2l(I32(n), I64(C), I32(K), _p(cells), I64(len(cells)), _p(self.v_ptr),
+                m2l = L.oracle_m2l_gemm if self.gemm_shaped else L.oracle_m2l
+                m2l(I32(n), I64(C), I32(K), _p(cells), I64(len(cells)), _p(self.v_ptr),
                              _p(self.v_idx), _p(self.v_tidx), I32(len(rank)), _p(u_off),
                              _p(vt_off), _p(rank), _p(buf), I32(compressed), _p(self.ops.perm),
                              _p(self.ops.invperm), _p(self.ops.perm_lookup),
@@ -1032,7 +1053,7 @@ class FmmTree:
             _p(self.w_ptr) if self.adaptive_tree else ctypes.c_void_p(0), _p(self.w_idx),
             _p(self.src_ptr), _p(self.src_idx), _p(tgt_ptr), _p(tgt_idx), _p(self.source_points),
             _p(tp), _p(w), I64(w.shape[0]), _p(self.M), _p(self.L), _p(out), I64(m),
-            _p(grad), I64(m), I32(flags))
+            _p(grad), I64(m), I32(flags | (8 if self.gemm_shaped else 0)))
         return out, grad
 
     def _check_grads(self):

@@ -527,6 +527,131 @@ void oracle_m2l(int n, int64_t C, int K, const int64_t *cells, int64_t ncells,
     }
 }
 
+/* The same pass with the reference's SHAPE of arithmetic: per (target cell, reference vector) the gathered k x n block
+ * goes through two small GEMMs (bbfmm.rs:953-960 calls faer's, i.e. register-blocked FMA micro-kernels) instead of the
+ * per-column multiply-add loops above.  Used by bench.py's cpu_baseline ("port" = what a CPU does with this algorithm);
+ * oracle_m2l stays the checker of this one (tests/test_oracle_vs_dense.py: 1e-13) and the pass the parity tests run. */
+typedef double v4d __attribute__((vector_size(32)));
+typedef double v4du __attribute__((vector_size(32), aligned(8)));
+
+/* Cc[m x nc] (ldc) = A[m x k] (lda) * B[k x nc] (ldb), all column-major; 8 x 4 register tiles, scalar edges */
+__attribute__((optimize("fp-contract=fast")))
+static void gemm_nn(int m, int nc, int k, const double *A, int lda, const double *B, int ldb, double *Cc, int ldc)
+{
+    int i = 0;
+    for (; i + 8 <= m; i += 8) {
+        int c = 0;
+        for (; c + 4 <= nc; c += 4) {
+            v4d a00 = {0, 0, 0, 0}, a01 = a00, a02 = a00, a03 = a00, a10 = a00, a11 = a00, a12 = a00, a13 = a00;
+            const double *b0 = B + (int64_t)c * ldb, *b1 = b0 + ldb, *b2 = b1 + ldb, *b3 = b2 + ldb;
+            const double *Ai = A + i;
+            for (int q = 0; q < k; ++q) {
+                v4d x0 = *(const v4du *)(Ai + (int64_t)q * lda), x1 = *(const v4du *)(Ai + (int64_t)q * lda + 4);
+                v4d y0 = {b0[q], b0[q], b0[q], b0[q]}, y1 = {b1[q], b1[q], b1[q], b1[q]};
+                v4d y2 = {b2[q], b2[q], b2[q], b2[q]}, y3 = {b3[q], b3[q], b3[q], b3[q]};
+                a00 += x0 * y0; a10 += x1 * y0;
+                a01 += x0 * y1; a11 += x1 * y1;
+                a02 += x0 * y2; a12 += x1 * y2;
+                a03 += x0 * y3; a13 += x1 * y3;
+            }
+            double *o = Cc + (int64_t)c * ldc + i;
+            *(v4du *)(o) = a00; *(v4du *)(o + 4) = a10;
+            *(v4du *)(o + ldc) = a01; *(v4du *)(o + ldc + 4) = a11;
+            *(v4du *)(o + 2 * (int64_t)ldc) = a02; *(v4du *)(o + 2 * (int64_t)ldc + 4) = a12;
+            *(v4du *)(o + 3 * (int64_t)ldc) = a03; *(v4du *)(o + 3 * (int64_t)ldc + 4) = a13;
+        }
+        for (; c < nc; ++c) { /* column edge: 8 x 1 */
+            v4d a0 = {0, 0, 0, 0}, a1 = a0;
+            const double *b = B + (int64_t)c * ldb, *Ai = A + i;
+            for (int q = 0; q < k; ++q) {
+                v4d y = {b[q], b[q], b[q], b[q]};
+                a0 += *(const v4du *)(Ai + (int64_t)q * lda) * y;
+                a1 += *(const v4du *)(Ai + (int64_t)q * lda + 4) * y;
+            }
+            *(v4du *)(Cc + (int64_t)c * ldc + i) = a0;
+            *(v4du *)(Cc + (int64_t)c * ldc + i + 4) = a1;
+        }
+    }
+    for (; i < m; ++i) /* row edge */
+        for (int c = 0; c < nc; ++c) {
+            double acc = 0.0;
+            const double *b = B + (int64_t)c * ldb;
+            for (int q = 0; q < k; ++q) acc += A[(int64_t)q * lda + i] * b[q];
+            Cc[(int64_t)c * ldc + i] = acc;
+        }
+}
+
+void oracle_m2l_gemm(int n, int64_t C, int K, const int64_t *cells, int64_t ncells,
+                     const int64_t *v_ptr, const int64_t *v_idx, const int32_t *v_tidx,
+                     int nref, const int64_t *u_off, const int64_t *vt_off, const int32_t *rank,
+                     const double *opbuf, int compressed,
+                     const int32_t *perm, const int32_t *invperm,
+                     const int32_t *perm_lookup, const int32_t *ref_lookup,
+                     const double *M, double *L)
+{
+    /* the level's operators once, rows padded to whole register tiles (zero rows: the edge loops of gemm_nn never run) */
+    const int np8 = (n + 7) & ~7;
+    double **Up = (double **)calloc((size_t)nref, sizeof(double *)), **Vp = (double **)calloc((size_t)nref, sizeof(double *));
+    int *rp8 = (int *)calloc((size_t)nref, sizeof(int));
+    for (int ref = 0; ref < nref; ++ref) {
+        int r = compressed ? rank[ref] : n;
+        rp8[ref] = (r + 7) & ~7;
+        Up[ref] = (double *)calloc((size_t)np8 * r, sizeof(double));
+        for (int a = 0; a < r; ++a) memcpy(Up[ref] + (size_t)a * np8, opbuf + u_off[ref] + (size_t)a * n, sizeof(double) * n);
+        if (compressed) {
+            Vp[ref] = (double *)calloc((size_t)rp8[ref] * n, sizeof(double));
+            for (int j = 0; j < n; ++j) memcpy(Vp[ref] + (size_t)j * rp8[ref], opbuf + vt_off[ref] + (size_t)j * r, sizeof(double) * r);
+        }
+    }
+#pragma omp parallel
+    {
+        int maxv = 7 * 7 * 7;
+        double *X = (double *)malloc(sizeof(double) * (size_t)np8 * maxv);
+        double *Cm = (double *)malloc(sizeof(double) * (size_t)np8 * maxv);
+        double *Y = (double *)malloc(sizeof(double) * (size_t)np8 * maxv);
+        int64_t *grp = (int64_t *)malloc(sizeof(int64_t) * maxv);
+        /* cells of a level come in (level, key) order: neighbours in the list share most of their V-list sources, so a
+         * thread keeps a contiguous block (static) -- no queue shared by all threads, no accumulator shared by any two */
+#pragma omp for schedule(static)
+        for (int64_t ci = 0; ci < ncells; ++ci) {
+            int64_t B = cells[ci];
+            int64_t v0 = v_ptr[B], v1 = v_ptr[B + 1];
+            if (v1 == v0) continue;
+            for (int ref = 0; ref < nref; ++ref) {
+                int kk = 0;
+                for (int64_t q = v0; q < v1; ++q)
+                    if (ref_lookup[v_tidx[q]] == ref) grp[kk++] = q;
+                if (!kk) continue;
+                int r = rank[ref], rp = rp8[ref];
+                for (int k = 0; k < K; ++k) {
+                    for (int c = 0; c < kk; ++c) { /* gather + permute, bbfmm.rs:910-931 */
+                        int64_t q = grp[c];
+                        const int32_t *pi = perm + (int64_t)perm_lookup[v_tidx[q]] * n;
+                        const double *Mv = M + ((int64_t)k * C + v_idx[q]) * n;
+                        double *Xc = X + (int64_t)c * n;
+                        for (int j = 0; j < n; ++j) Xc[j] = Mv[pi[j]];
+                    }
+                    if (compressed) {
+                        gemm_nn(rp, kk, n, Vp[ref], rp, X, n, Cm, rp);      /* Cm = Vt * X, bbfmm.rs:953-954 */
+                        gemm_nn(np8, kk, r, Up[ref], np8, Cm, rp, Y, np8);  /* Y = U * Cm, bbfmm.rs:955-960 */
+                    } else {
+                        gemm_nn(np8, kk, n, Up[ref], np8, X, n, Y, np8);
+                    }
+                    double *Lb = L + ((int64_t)k * C + B) * n; /* inverse permute + accumulate, bbfmm.rs:964-982 */
+                    for (int c = 0; c < kk; ++c) {
+                        const int32_t *ip = invperm + (int64_t)perm_lookup[v_tidx[grp[c]]] * n;
+                        const double *Yc = Y + (int64_t)c * np8;
+                        for (int i = 0; i < n; ++i) Lb[i] += Yc[ip[i]];
+                    }
+                }
+            }
+        }
+        free(X); free(Cm); free(Y); free(grp);
+    }
+    for (int ref = 0; ref < nref; ++ref) { free(Up[ref]); free(Vp[ref]); }
+    free(Up); free(Vp); free(rp8);
+}
+
 /* ------------------------------------------------------------------ P2L */
 /* particle_to_local, bbfmm.rs:1001-1048 with nodes scaled by
  * scale_cheb_nodes_to_cell (chebyshev.rs:951-968). */
@@ -596,7 +721,49 @@ void oracle_leaf_pass(int id, double base_range, double total_sill, int p, int d
             int64_t t0 = tgt_ptr[B], t1 = tgt_ptr[B + 1];
             if (t1 == t0) continue;
             /* ---- P2P */
-            if (flags & 1) {
+            if ((flags & 1) && (flags & 8) && !grad && d == 3 && (id == K_LINEAR || id == K_CUBIC)) {
+                /* cpu_baseline only: the reference's loop (bbfmm.rs:1162-1251) copies the points and weights of every
+                 * U-list leaf next to each other first; on the copies the pair loop of a kernel without branches is a
+                 * plain reduction the compiler vectorises -- as LLVM can for the monomorphised Rust loop.  Sums run over
+                 * the same sources in the same order per target as the loop below, in SIMD partial sums. */
+                int64_t ns = 0;
+                for (int64_t q = u_ptr[B]; q < u_ptr[B + 1]; ++q) ns += src_ptr[u_idx[q] + 1] - src_ptr[u_idx[q]];
+                double *gx = (double *)malloc(sizeof(double) * (size_t)ns * (3 + (size_t)K));
+                double *gy = gx + ns, *gz = gy + ns, *gw = gz + ns;
+                int64_t at = 0;
+                for (int64_t q = u_ptr[B]; q < u_ptr[B + 1]; ++q) {
+                    int64_t U = u_idx[q];
+                    for (int64_t s = src_ptr[U]; s < src_ptr[U + 1]; ++s, ++at) {
+                        int64_t si = src_idx[s];
+                        gx[at] = pts[si * 3]; gy[at] = pts[si * 3 + 1]; gz[at] = pts[si * 3 + 2];
+                        for (int k = 0; k < K; ++k) gw[(int64_t)k * ns + at] = w[k * ldw + si];
+                    }
+                }
+                for (int64_t tq = t0; tq < t1; ++tq) {
+                    int64_t ti = tgt_idx[tq];
+                    double tx = tpts[ti * 3], ty = tpts[ti * 3 + 1], tz = tpts[ti * 3 + 2];
+                    for (int k = 0; k < K; ++k) {
+                        const double *wk = gw + (int64_t)k * ns;
+                        double acc = 0.0;
+                        if (id == K_LINEAR) {
+#pragma omp simd reduction(+ : acc)
+                            for (int64_t s = 0; s < ns; ++s) {
+                                double dx = tx - gx[s], dy = ty - gy[s], dz = tz - gz[s];
+                                acc += -sqrt(dx * dx + dy * dy + dz * dz) * wk[s];
+                            }
+                        } else {
+#pragma omp simd reduction(+ : acc)
+                            for (int64_t s = 0; s < ns; ++s) {
+                                double dx = tx - gx[s], dy = ty - gy[s], dz = tz - gz[s];
+                                double r2 = dx * dx + dy * dy + dz * dz;
+                                acc += r2 * sqrt(r2) * wk[s];
+                            }
+                        }
+                        out[k * ldo + ti] += acc;
+                    }
+                }
+                free(gx);
+            } else if (flags & 1) {
                 for (int64_t q = u_ptr[B]; q < u_ptr[B + 1]; ++q) {
                     int64_t U = u_idx[q];
                     for (int64_t tq = t0; tq < t1; ++tq) {

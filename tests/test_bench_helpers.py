@@ -50,12 +50,15 @@ def test_committed_counters_are_only_quoted_for_the_sources_they_were_taken_on(t
 
 
 def test_extra_configs_name_baseline_json_configs():
-    """The default line carries the reference's arithmetic only: configs 2 (x2), 3, 4 at N = 1, config 5 at N > 1;
-    the extensions are opt-in and say what they are."""
+    """The default line carries configs 2 (x2), 3, 4 (x2: the reference's kernel and the Gaussian extension kernel,
+    SURVEY 8(d)) at N = 1, config 5 at N > 1, and -- VERDICT r04 next #7 -- ONE labelled extension (the shared-basis M2L on
+    the headline workload, so that its figure is driver-measured; never the headline); the other extensions are opt-in.
+    Every flagged configuration says what it is by its name."""
     flagged = lambda c: bool(c.get("m2l_shared_basis") or c.get("direct_small_w_leaves"))
     names = [c["name"] for c in bench.EXTRA_CONFIGS + bench.EXTENSION_CONFIGS + [bench.CONFIG5]]
-    assert len(names) == len(set(names)) == 9
-    assert len(bench.EXTRA_CONFIGS) == 4 and not any(flagged(c) for c in bench.EXTRA_CONFIGS + [bench.CONFIG5])
+    assert len(names) == len(set(names)) == 10
+    assert len(bench.EXTRA_CONFIGS) == 6 and not flagged(bench.CONFIG5)
+    assert [c["name"] for c in bench.EXTRA_CONFIGS if flagged(c)] == ["extension_shared_basis_linear_10M"]
     assert all(flagged(c) and c["name"].startswith("extension_") for c in bench.EXTENSION_CONFIGS)
     assert (bench.CONFIG5["points"], bench.CONFIG5["kernel"]) == (40_000_000, "Spheroidal3Rbf")
     for c in bench.EXTRA_CONFIGS + bench.EXTENSION_CONFIGS + [bench.CONFIG5]:
@@ -140,7 +143,9 @@ def _synthetic_detail(world=1):
             "phase_roofline": bench.phase_roofline(S, 10_000_000, 1, 7, "LinearRbf", ms, 3.1e13),
             "dense_rows_rel_err": 9.390407276931204e-09, "configs": cfgs,
             "cpu_baseline": {"value": 0.03216402327044833, "unit": "matvecs/s", "cores": 128, "kind": "port", "sample": "s" * 400},
-            "cpu_baseline_detail": {"note": "n" * 600}}
+            "cpu_baseline_detail": {"note": "n" * 600},
+            "dropin_host_buffers": {"points": 10_000_000, "patched_caller_ms": 46.322698937729, "unchanged_caller_ms": 46.43676499836147,
+                                    "unchanged_caller_general_path_ms": 57.23296804353595, "unchanged_caller_took_resident_path": True}}
 
 
 @pytest.mark.parametrize("world", [1, 8])
@@ -166,6 +171,12 @@ def test_the_stdout_line_stays_under_4_kb_and_round_trips(world, tmp_path, monke
     assert abs(line["value"] - detail["value"]) < 1e-5 * detail["value"]
     assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 200
     assert line["p2p"]["frac_hbm"] < 0.5 and 0 < line["p2p"]["frac_fp64_valu"] < 1
+    # round 5: config 4's Gaussian-extension instance and the shared-basis extension ride on the default N = 1 line; the
+    # drop-in boundary's host-buffer figures (patched and unchanged caller) as one small entry
+    assert {"config4_gaussian_ext_10M_8rhs", "extension_shared_basis_linear_10M"} <= {c["name"] for c in bench.EXTRA_CONFIGS}
+    assert {"config4_gaussian_ext_10M_8rhs", "extension_shared_basis_linear_10M"} <= set(line["configs"])
+    assert set(line["dropin_host_buffers_ms"]) == {"patched", "unchanged", "unchanged_general_path"}
+    assert line["roofline"].get("peak_is") is None or isinstance(line["roofline"]["peak_is"], str)
     for name, c in line["configs"].items():
         if name == "broken":
             assert len(c["error"]) <= 120

@@ -205,3 +205,32 @@ def test_large_coarse_domain_that_is_not_positive_definite_takes_the_pivoted_lu(
         z = pre.debug_level_solve(lv, r, True)
         zo = _oracle_level_solve(levels, lv, r, n, ost, None)
         assert np.abs(z - zo).max() < 1e-7 * np.abs(zo).max(), f"level {lv}"
+
+
+def test_the_factors_are_released_with_the_last_reference():
+    """Round 5: the preconditioner's operator object used to hold the preconditioner (a reference cycle), so `del pre`
+    kept the factors -- 95 GB of HBM at 10M points -- until the cyclic collector ran; a sweep over hierarchies at 10M
+    points ran out of device memory on its third preconditioner (tests/checks/ddm_depth_sweep_10M.py)."""
+    import gc
+    import weakref
+    import torch
+    from ferreus_rbf_rs_amd import solvers as S
+    rng = np.random.default_rng(3)
+    pts = rng.random((60000, 3))
+    tree = F.FmmTree(pts, 5, F.KernelParams(F.KernelType(0)), True, True)
+    st = InterpolantSettings(0, 3)
+    gc.disable()
+    try:
+        free0 = torch.cuda.mem_get_info()[0]
+        pre = SchwarzPreconditioner(tree, pts, st, DDMParams())
+        op = S.RbfSystemOperator(tree, st.basis_size, pre.monomial_matrix, 0.0)
+        rhs = np.concatenate([np.sin(pts[:, 0]), np.zeros(st.basis_size)])
+        S.fgmres(op, rhs, pre, None, 1, 3, S.FittingAccuracy(1e-6))
+        held = free0 - torch.cuda.mem_get_info()[0]
+        assert held > 50e6                                        # the factors of ~100 domains of ~1,200 points
+        ref = weakref.ref(pre)
+        del pre
+        assert ref() is None                                      # no collector pass needed
+        assert free0 - torch.cuda.mem_get_info()[0] < 0.2 * held  # and the device memory is back
+    finally:
+        gc.enable()

@@ -101,3 +101,23 @@ def test_leaf_only_evaluator_and_matvec_caller():
     mask = np.ones(6004, bool)
     mask[sub] = False
     assert np.all(r[mask] == 0.0)
+
+
+def test_gemm_shaped_port_equals_the_plain_loop_passes():
+    """bench.py's cpu_baseline runs the oracle with M2L as gather + two register-blocked FMA GEMMs +
+    permuted scatter (oracle_m2l_gemm; the shape of bbfmm.rs:910-982 with faer's GEMMs) and the near field on gathered
+    copies in vectorised loops.  The plain-loop passes every parity test uses are its checker: 1e-13 on L and on the
+    potentials, compressed and uncompressed operators, two right-hand sides, mixed levels (P2L / M2P run too)."""
+    rng = np.random.default_rng(12)
+    pts = np.vstack([rng.random((26000, 3)), np.clip(rng.normal(size=(4000, 3)) * 0.03 + 0.4, 0.0, 0.999)])
+    w = rng.standard_normal((len(pts), 2))
+    for kid, params in ((O.KERNEL_IDS["LinearRbf"], None), (O.KERNEL_IDS["CubicRbf"], O.FmmParams(64, O.COMPRESSION_NONE, 1e-5, 1024)),
+                        (O.KERNEL_IDS["Spheroidal3Rbf"], None)):
+        t = O.FmmTree(pts, 5, kid, True, True, None, params, base_range=0.5, total_sill=0.4)
+        got = {}
+        for mode in (False, True):
+            t.gemm_shaped = mode
+            t.set_weights(w)
+            got[mode] = (t.evaluate(w, pts), t.L.copy())
+        assert np.abs(got[True][1] - got[False][1]).max() <= 1e-13 * np.abs(got[False][1]).max(), kid
+        assert np.abs(got[True][0] - got[False][0]).max() <= 1e-13 * np.abs(got[False][0]).max(), kid
