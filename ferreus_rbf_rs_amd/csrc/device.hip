@@ -1086,8 +1086,14 @@ constexpr int SYM2_WAVES = 4;
 constexpr int SYM2_MAX_ROWS = 256;
 template <int KB> constexpr int sym2_rows() { return KB == 1 ? 8 : 4; }
 
+// The transpose of the row sums: NV rows of 64 partial sums, every NV-column segment followed by two pad columns so that
+// the 16-byte reads of the reduction (lane l reads segment l % LPV of row l / LPV) fall on sixteen different bank groups
+// per pass (round 5: unpadded, 65 % of the kernel's LDS cycles at four rhs and 36 % at one were bank conflicts --
+// SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE, profiles/r05_nearfield_counters_before.json; time unchanged, the kernel
+// does not wait for its LDS: DESIGN.md section 10).
 template <int NV> struct Sym2Wave { // wave-private
-    double red[NV][64];
+    static constexpr int kSeg = NV + 2, kRow = (64 / NV) * kSeg;
+    double red[NV][kRow];
     int32_t seg_src[64], seg_off[64], seg_two[64];
 };
 
@@ -1199,11 +1205,12 @@ __global__ __launch_bounds__(64 * SYM2_WAVES) void p2p_sym2_kernel(KernelSpec ks
             }
             // row sums: transpose through the wave's slice; LPV lanes share one of the NV sums, each adds NV of its 64
             // partial sums (NV / 2 16-byte reads)
+            const int wcol = lane + 2 * (lane / NV); // (pad columns behind every NV-column segment)
 #pragma unroll
             for (int r = 0; r < R; ++r)
 #pragma unroll
-                for (int k = 0; k < KB; ++k) W.red[r * KB + k][lane] = racc[r][k];
-            const double2 *pr = reinterpret_cast<const double2 *>(&W.red[lane / LPV][(lane % LPV) * NV]);
+                for (int k = 0; k < KB; ++k) W.red[r * KB + k][wcol] = racc[r][k];
+            const double2 *pr = reinterpret_cast<const double2 *>(&W.red[lane / LPV][(lane % LPV) * Sym2Wave<NV>::kSeg]);
             double sum = 0.0;
 #pragma unroll
             for (int i = 0; i < NV / 2; i += 2) {

@@ -101,6 +101,15 @@ def test_every_kernel(kid, br, sill, tol):
     check(np.random.default_rng(5).random((20000, 3)), kid=kid, br=br, sill=sill, dense_tol=tol)
 
 
+def test_narrow_gaussian_extension_device_equals_restatement_where_the_method_is_inaccurate():
+    """Config 4's second instance: the Gaussian EXTENSION kernel exp(-(r / 0.1)^2).  Its width is below the
+    cell size of the upper levels, where an order-7 Chebyshev interpolant does not resolve it: the BBFMM itself is only
+    ~1e-2 accurate against the dense sum here (oracle alone: 2.4e-3 at 50k points, 1.3e-2 at 400k; bench.py's 10M x 8 rhs
+    line shows 1.2e-2) -- a property of the method on this kernel, not of the device code: device and restatement still
+    agree to 1e-11 on M, L and the potentials."""
+    check(np.random.default_rng(8).random((60000, 3)), kid=100, br=0.1, sill=0.1, nrhs=2, dense_tol=3e-2)
+
+
 def test_two_and_one_dimensions():
     check(np.random.default_rng(6).random((30000, 2)))
     check(np.random.default_rng(7).random((5000, 1)), dense_tol=1e-10)
