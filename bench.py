@@ -261,8 +261,8 @@ def cpu_baseline(args, kernel_id):
     The port runs in its GEMM-shaped mode (round 5): M2L per (target cell, reference vector) as gather, two
     register-blocked FMA GEMMs, permuted scatter -- what the reference's faer calls do (bbfmm.rs:910-982) -- and the
     near field on gathered copies in vectorised loops; the plain-loop passes the parity tests use stay its checker
-    (tests/test_oracle_vs_dense.py, 1e-13).  Threads: all hardware threads and half of them are both timed ON THE SAMPLE
-    ITSELF (one tree build serves both; the 64x smaller pick of round 4 chose 32 of 128 because small problems dislike
+    (tests/test_oracle_vs_dense.py, 1e-13).  Threads: all hardware threads, a half and a quarter of them are timed ON THE
+    SAMPLE ITSELF (one tree build serves both; the 64x smaller pick of round 4 chose 32 of 128 because small problems dislike
     many threads) and the faster one is the value.  One warm-up, then matvecs until two are done and the budget is
     spent, median.  The oracle's Python tree build is timed separately (`tree_build_s`; not part of a matvec).
     The O(N) scaling of the sample OVERSTATES the port at the full size (caches: measured once at 10M, see
@@ -290,7 +290,7 @@ def cpu_baseline(args, kernel_id):
             times.append(time.time() - t0)
         return float(np.median(times)), threads, len(times)
 
-    runs = [timed(th, 6.0, 5) for th in sorted({hw, max(hw // 2, 1)}, reverse=True)]
+    runs = [timed(th, 5.0, 4) for th in sorted({hw, max(hw // 2, 1), max(hw // 4, 1)}, reverse=True)]
     O.lib().oracle_set_num_threads(hw)
     t, threads, reps = min(runs)
     scale = n_cpu / float(args.points)

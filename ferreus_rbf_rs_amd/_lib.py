@@ -123,6 +123,9 @@ SIGNATURES = {
     "bbfmm_ddm_domain_size": (c_i64, [c_p, c_i32, c_i64]),
     "bbfmm_ddm_domain": (ctypes.c_int, [c_p, c_i32, c_i64, c_p, c_p, c_p]),
     "bbfmm_schwarz_create": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64, c_p, c_p, c_p]),
+    "bbfmm_schwarz_create_sharded": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64, c_p, c_p, c_i32, c_i32, c_p, c_i64, c_p, c_p, c_p]),
+    "bbfmm_schwarz_factor_bytes": (c_i64, [c_p]),
+    "bbfmm_schwarz_domains_owned": (c_i64, [c_p, c_i32, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "bbfmm_schwarz_destroy": (None, [c_p]),
     "bbfmm_schwarz_basis_size": (c_i64, [c_p]),
     "bbfmm_schwarz_num_levels": (c_i32, [c_p]),
@@ -151,6 +154,7 @@ class DdmParams(ctypes.Structure):
 
 # bbfmm_apply_fn, bbfmm_iteration_fn
 APPLY_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_p, ctypes.POINTER(c_f64), ctypes.POINTER(c_f64), c_i64)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_p, c_i64)     # bbfmm_allreduce_fn
 ITERATION_FN = ctypes.CFUNCTYPE(None, c_p, c_i64, c_f64, c_f64)
 ACCURACY_ABSOLUTE, ACCURACY_RELATIVE = 0, 1
 

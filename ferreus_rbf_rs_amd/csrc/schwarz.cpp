@@ -52,6 +52,17 @@ struct Schwarz {
     int64_t small_cap = 0;
     std::vector<int32_t *> d_lidx;      // per level: its rows on the device (nullptr: all rows in order)
     std::vector<int32_t> subset_id;     // per level: registered target subset of the tree (-1: all rows)
+    // Factors sharded over the ranks of a job (bbfmm_schwarz_create_sharded): this rank factorises and solves the
+    // domains [dom_first, dom_first + count) of every fine level; a level's corrections -- disjoint rows, zeros for the
+    // domains of the other ranks -- are summed over the ranks in the caller's exchange buffer.  The coarse domain and the
+    // partial products are replicated.
+    int rank = 0, world = 1;
+    double *d_xchg = nullptr;   // caller's device buffer (not owned), >= the largest fine level
+    int64_t xchg_cap = 0;
+    bbfmm_allreduce_fn allreduce = nullptr;
+    void *allreduce_user = nullptr;
+    std::vector<int64_t> dom_total, dom_first; // per level: domains of the decomposition, first one owned here
+    double t_exchange = 0;
     double t_matvec = 0, t_solve = 0, t_host = 0; // BBFMM_VERBOSE: seconds per apply (stream synchronised per stage)
     std::vector<double> t_level, t_level_mv;      // per level: local solves, partial matvecs
     bool verbose = false;
@@ -99,8 +110,19 @@ int level_step(Schwarz &S, size_t li, bool have_sl, bool coarse, bool add_poly, 
             t0 = now();
         }
     }
-    int rc = ddm_level_solve(lv, src, S.d_out, coarse, S.stream);
+    const bool sharded = !coarse && S.world > 1;
+    if (sharded) launch_schwarz_scatter_rows(nullptr, rows, nl, S.d_out, S.stream); // rows of the other ranks' domains: 0
+    int rc = lv.n_dom > 0 ? ddm_level_solve(lv, src, S.d_out, coarse, S.stream) : BBFMM_OK;
     if (rc) return rc;
+    if (sharded) { // the level's correction = the sum over the ranks of their domains' rows (disjoint: exact)
+        if (nl > S.xchg_cap) return BBFMM_BAD_ARGUMENT;
+        launch_schwarz_gather_rows(S.d_out, rows, nl, S.d_xchg, S.stream);
+        HIPOK(hipStreamSynchronize(S.stream));
+        const auto tx = std::chrono::steady_clock::now();
+        if ((rc = S.allreduce(S.allreduce_user, nl)) != 0) return BBFMM_DEVICE_ERROR;
+        S.t_exchange += std::chrono::duration<double>(std::chrono::steady_clock::now() - tx).count();
+        launch_schwarz_scatter_rows(S.d_xchg, rows, nl, S.d_out, S.stream);
+    }
     if (!coarse) { // solve_fine_level, schwarz.rs:84-126: internal points written back, then orthogonalised
         if (S.basis)
             launch_schwarz_project(S.d_ortho, S.n, S.basis, S.d_out, rows, nl, S.d_part, kSchwarzProjectBlocks, S.d_proj,
@@ -194,6 +216,7 @@ struct bbfmm_schwarz {
 namespace {
 int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
                         const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, Schwarz &S) {
+    // (S.rank / S.world / the exchange were set by the caller for a sharded preconditioner)
     S.tree = tree;
     S.n = n;
     S.d = d;
@@ -291,8 +314,22 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
             }
     }
     S.levels.resize(S.ddm.levels.size());
+    S.dom_total.assign(S.ddm.levels.size(), 0);
+    S.dom_first.assign(S.ddm.levels.size(), 0);
     for (size_t li = 0; li < S.ddm.levels.size(); ++li) {
         const bool coarse = li + 1 == S.ddm.levels.size();
+        {
+            auto &leaves = S.ddm.levels[li].leaves;
+            const int64_t nd = static_cast<int64_t>(leaves.size());
+            S.dom_total[li] = nd;
+            if (!coarse && S.world > 1) { // this rank's contiguous share of the level's domains; the others are dropped here
+                const int64_t b = nd * S.rank / S.world, e = nd * (S.rank + 1) / S.world;
+                S.dom_first[li] = b;
+                std::vector<DdmDomain> own(std::make_move_iterator(leaves.begin() + b), std::make_move_iterator(leaves.begin() + e));
+                leaves.swap(own);
+                if (static_cast<int64_t>(S.ddm.levels[li].point_indices.size()) > S.xchg_cap) return BBFMM_BAD_ARGUMENT;
+            }
+        }
         // The coarse domain returns the polynomial tail of the correction.  The reference scales that
         // domain's monomials by the extents of its own points (domain.rs:171-172) although the system's
         // monomial matrix is scaled by the extents of all points (rbf.rs:418-421, 485-491), so the tail
@@ -301,6 +338,7 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
         // with the global scaling).  Default: as the reference; BBFMM_FLAG_GLOBAL_SCALING: the global one.
         // (Measured: the FGMRES histories at 3M points are the same either way.)
         const bool global_scaling = (settings->flags & BBFMM_FLAG_GLOBAL_SCALING) != 0;
+        if (S.ddm.levels[li].leaves.empty()) continue; // (a level with fewer domains than ranks: nothing to factorise here)
         rc = ddm_level_build(points, ld, d, &S.ddm.levels[li], S.ks, S.nugget, S.degree, S.basis, coarse && S.basis != 0,
                              S.stream, &S.levels[li], (coarse && S.basis != 0 && global_scaling) ? gscale : nullptr);
         if (rc) return rc;
@@ -368,21 +406,50 @@ int schwarz_create_impl(bbfmm_handle *tree, const double *points, int64_t n, int
 
 extern "C" {
 
-int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
-                         const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, bbfmm_schwarz **out) {
+int bbfmm_schwarz_create_sharded(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
+                                 const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, int32_t rank,
+                                 int32_t world, double *d_exchange, int64_t exchange_capacity,
+                                 bbfmm_allreduce_fn allreduce, void *allreduce_user, bbfmm_schwarz **out) {
     if (!out) return BBFMM_BAD_ARGUMENT;
     *out = nullptr;
     if (!tree || !points || !settings || n < 1 || d < 1 || d > 3 || ld < n) return BBFMM_BAD_ARGUMENT;
     if (settings->kernel_type < 0 || settings->kernel_type > 6 || settings->polynomial_degree < -1 ||
         settings->polynomial_degree > 2)
         return BBFMM_BAD_ARGUMENT;
+    if (world < 1 || rank < 0 || rank >= world) return BBFMM_BAD_ARGUMENT;
+    if (world > 1 && (!d_exchange || !allreduce || exchange_capacity < 1)) return BBFMM_BAD_ARGUMENT;
     SCHWARZ_GUARD
     std::unique_ptr<bbfmm_schwarz> h(new bbfmm_schwarz());
+    h->s.rank = rank;
+    h->s.world = world;
+    h->s.d_xchg = d_exchange;
+    h->s.xchg_cap = exchange_capacity;
+    h->s.allreduce = allreduce;
+    h->s.allreduce_user = allreduce_user;
     const int rc = schwarz_create_impl(tree, points, n, d, ld, settings, params, h->s);
     if (rc) return rc;
     *out = h.release();
     return BBFMM_OK;
     SCHWARZ_END_GUARD
+}
+
+int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
+                         const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, bbfmm_schwarz **out) {
+    return bbfmm_schwarz_create_sharded(tree, points, n, d, ld, settings, params, 0, 1, nullptr, 0, nullptr, nullptr, out);
+}
+
+int64_t bbfmm_schwarz_factor_bytes(const bbfmm_schwarz *h) {
+    if (!h) return -1;
+    int64_t bytes = 0;
+    for (const DdmLevelSolver &lv : h->s.levels)
+        if (!lv.fac_off.empty()) bytes += lv.fac_off.back() * static_cast<int64_t>(sizeof(double));
+    return bytes;
+}
+int64_t bbfmm_schwarz_domains_owned(const bbfmm_schwarz *h, int32_t level, int64_t *first, int64_t *total) {
+    if (!h || level < 0 || level >= static_cast<int32_t>(h->s.levels.size())) return -1;
+    if (first) *first = h->s.dom_first[static_cast<size_t>(level)];
+    if (total) *total = h->s.dom_total[static_cast<size_t>(level)];
+    return h->s.levels[static_cast<size_t>(level)].n_dom;
 }
 
 void bbfmm_schwarz_destroy(bbfmm_schwarz *h) { delete h; }
@@ -454,9 +521,10 @@ int bbfmm_schwarz_apply(void *user, const double *rg, double *sl, int64_t n) {
     }
     if ((rc = download_correction(S, tail, sl))) return rc;
     if (S.verbose) {
-        std::fprintf(stderr, "[bbfmm] schwarz apply %.3f s: partial matvecs %.3f s, level solves %.3f s, host %.3f s\n",
+        std::fprintf(stderr, "[bbfmm] schwarz apply %.3f s: partial matvecs %.3f s, level solves %.3f s (of which exchange %.3f s), host %.3f s\n",
                      std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count(), S.t_matvec, S.t_solve,
-                     S.t_host);
+                     S.t_exchange, S.t_host);
+        S.t_exchange = 0;
         for (size_t l = 0; l < S.t_level.size(); ++l) {
             std::fprintf(stderr, "[bbfmm]   level %zu: %lld domains, %lld entries, max m %d: solves %.3f s, matvecs %.3f s\n", l,
                          (long long)S.levels[l].n_dom, (long long)S.levels[l].n_entries, S.levels[l].max_m, S.t_level[l],

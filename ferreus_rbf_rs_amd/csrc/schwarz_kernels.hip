@@ -80,8 +80,30 @@ __global__ __launch_bounds__(256) void gather64_kernel(const double *__restrict_
     if (j < m) dst[j] = src[idx[j]];
 }
 
+__global__ __launch_bounds__(256) void gather_rows_kernel(const double *__restrict__ src, const int32_t *__restrict__ rows,
+                                                          int64_t m, double *__restrict__ dst) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m) dst[j] = src[rows ? rows[j] : j];
+}
+
+// dst[row_j] = src ? src[j] : 0
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const double *__restrict__ src, const int32_t *__restrict__ rows,
+                                                           int64_t m, double *__restrict__ dst) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m) dst[rows ? rows[j] : j] = src ? src[j] : 0.0;
+}
+
 inline unsigned grid_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 } // namespace
+
+void launch_schwarz_gather_rows(const double *src, const int32_t *rows, int64_t m, double *dst, hipStream_t s) {
+    if (m == 0) return;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(m)), dim3(256), 0, s, src, rows, m, dst);
+}
+void launch_schwarz_scatter_rows(const double *src, const int32_t *rows, int64_t m, double *dst, hipStream_t s) {
+    if (m == 0) return;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(grid_for(m)), dim3(256), 0, s, src, rows, m, dst);
+}
 
 void launch_schwarz_residual(const double *rg, const double *y, const double *sl, double nugget, const int32_t *rows,
                              int64_t m, double *res, hipStream_t s) {

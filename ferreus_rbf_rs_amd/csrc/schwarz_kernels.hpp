@@ -22,6 +22,10 @@ void launch_schwarz_subtract_projection(const double *ortho, int64_t n, int basi
 // dst[j] = src[idx[j]] with 64-bit indices (the coarse domain's entry list)
 void launch_gather_rows64(const double *src, const int64_t *idx, int64_t m, double *dst, hipStream_t s);
 
+// dst[j] = src[row_j]; dst[row_j] = src[j] (src == nullptr: zero) -- the packed exchange buffer of a sharded level
+void launch_schwarz_gather_rows(const double *src, const int32_t *rows, int64_t m, double *dst, hipStream_t s);
+void launch_schwarz_scatter_rows(const double *src, const int32_t *rows, int64_t m, double *dst, hipStream_t s);
+
 constexpr int kSchwarzProjectBlocks = 1024;
 
 } // namespace bbfmm

@@ -109,10 +109,14 @@ class SchwarzPreconditioner:
     as the `m` of solvers.fgmres, or call it on a residual of N + basis_size values."""
 
     def __init__(self, tree, points, settings: InterpolantSettings, ddm_params: Optional[DDMParams] = None,
-                 global_scaling: bool = False):
+                 global_scaling: bool = False, shard_group=None):
         """global_scaling: scale the coarse domain's monomials by the extents of all points (the basis of the
         system's monomial matrix) instead of by its own extents as the reference does (domain.rs:171-172);
-        see csrc/schwarz.cpp."""
+        see csrc/schwarz.cpp.
+        shard_group: a torch.distributed process group (True: the default group): the factors are sharded over its ranks
+        (bbfmm_schwarz_create_sharded: every rank factorises and solves a contiguous share of each fine level's domains,
+        a level's corrections are summed over the ranks -- RCCL all-reduce on the exchange tensor, staged through the host
+        when the group's backend is gloo); every rank must create it and call it in step."""
         pts = np.asfortranarray(np.atleast_2d(np.asarray(points, dtype=np.float64)))
         n, d = pts.shape
         lib = L.load()
@@ -120,8 +124,41 @@ class SchwarzPreconditioner:
                            settings.total_sill, L.FLAG_GLOBAL_SCALING if global_scaling else 0)
         prm = (ddm_params or DDMParams())._c()
         h = ctypes.c_void_p()
-        rc = lib.bbfmm_schwarz_create(tree._h, pts.ctypes.data, n, d, n, ctypes.byref(st), ctypes.byref(prm),
-                                      ctypes.byref(h))
+        self._xchg = self._allreduce_cb = None
+        self.rank, self.world = 0, 1
+        if shard_group is not None:
+            import torch
+            import torch.distributed as dist
+            group = None if shard_group is True else shard_group
+            self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+            dev = torch.device("cuda", tree.device()) if hasattr(tree, "device") else torch.device("cuda", torch.cuda.current_device())
+            self._xchg = torch.zeros(n, dtype=torch.float64, device=dev)
+            staged = dist.get_backend(group) == "gloo"
+            host = torch.zeros(n, dtype=torch.float64).pin_memory() if staged else None
+            xchg = self._xchg
+
+            def _allreduce(_user, count):      # bbfmm_allreduce_fn: sum xchg[:count] over the ranks, result visible on return
+                try:
+                    if staged:
+                        host[:count].copy_(xchg[:count])
+                        dist.all_reduce(host[:count], group=group)
+                        xchg[:count].copy_(host[:count])
+                    else:
+                        dist.all_reduce(xchg[:count], group=group)
+                    torch.cuda.synchronize(dev)
+                    return 0
+                except BaseException:  # noqa: BLE001 -- must not unwind through C
+                    return 1
+
+            self._allreduce_cb = L.ALLREDUCE_FN(_allreduce)
+        if self.world > 1:
+            torch.cuda.synchronize()
+            rc = lib.bbfmm_schwarz_create_sharded(tree._h, pts.ctypes.data, n, d, n, ctypes.byref(st), ctypes.byref(prm),
+                                                  self.rank, self.world, self._xchg.data_ptr(), n,
+                                                  ctypes.cast(self._allreduce_cb, ctypes.c_void_p), None, ctypes.byref(h))
+        else:
+            rc = lib.bbfmm_schwarz_create(tree._h, pts.ctypes.data, n, d, n, ctypes.byref(st), ctypes.byref(prm),
+                                          ctypes.byref(h))
         if rc != L.OK:
             raise ValueError(f"bbfmm_schwarz_create failed with status {rc}"
                              + (" (a local system is not positive definite)" if rc == L.UNSUPPORTED else ""))
@@ -147,6 +184,16 @@ class SchwarzPreconditioner:
         if rc != L.OK:
             raise RuntimeError(f"bbfmm_schwarz_apply failed with status {rc}")
         return z
+
+    def factor_bytes(self) -> int:
+        """device bytes of the packed factors this handle (this rank) holds"""
+        return int(self._lib.bbfmm_schwarz_factor_bytes(self._h))
+
+    def domains_owned(self, level: int):
+        """(domains of the level factorised here, the first of them, the level's total)"""
+        first, total = ctypes.c_int64(0), ctypes.c_int64(0)
+        own = self._lib.bbfmm_schwarz_domains_owned(self._h, level, ctypes.byref(first), ctypes.byref(total))
+        return int(own), int(first.value), int(total.value)
 
     def level_points(self, level: int) -> np.ndarray:
         """Level::point_indices of one level (finest first)"""

@@ -509,6 +509,26 @@ typedef struct bbfmm_interpolant { /* InterpolantSettings, interpolant_config.rs
  * the preconditioner.  params NULL -> DDMParams defaults. */
 int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
                          const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, bbfmm_schwarz **out);
+/* The same preconditioner with its FACTORS SHARDED over the ranks of a job (level 0 of 10M points holds
+ * 95 GB of Cholesky factors, one GPU's 288 GB end near 28M points).  No counterpart in the reference (one address space).
+ * Every rank decomposes the same points the same way, keeps the contiguous share [nd * rank / world, nd * (rank + 1) /
+ * world) of every fine level's domains -- factorises and solves only those -- and after a level's local solves the
+ * corrections of all ranks are summed: the internal points of the domains partition the level's rows (restricted
+ * additive Schwarz, schwarz.rs:96-113), so each row is written by exactly one rank and the sum adds zeros (the result
+ * equals the unsharded preconditioner's bit for bit).  The coarse domain (one domain) and the partial products through
+ * `tree` are replicated.
+ *   d_exchange: DEVICE buffer of the caller, exchange_capacity >= the largest fine level (N) doubles;
+ *   allreduce(user, count): sum d_exchange[0 .. count) over the ranks in place (ncclAllReduce / torch.distributed);
+ *     called from bbfmm_schwarz_apply with the library's stream idle, must return with the result visible to the device.
+ * rank 0 / world 1 (no exchange) is bbfmm_schwarz_create. */
+typedef int (*bbfmm_allreduce_fn)(void *user, int64_t count);
+int bbfmm_schwarz_create_sharded(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,
+                                 const bbfmm_interpolant *settings, const bbfmm_ddm_params *params, int32_t rank,
+                                 int32_t world, double *d_exchange, int64_t exchange_capacity,
+                                 bbfmm_allreduce_fn allreduce, void *allreduce_user, bbfmm_schwarz **out);
+int64_t bbfmm_schwarz_factor_bytes(const bbfmm_schwarz *h); /* device bytes of the packed factors this handle holds */
+/* domains of `level` this handle factorised (returned), the first of them and the level's total in the decomposition */
+int64_t bbfmm_schwarz_domains_owned(const bbfmm_schwarz *h, int32_t level, int64_t *first, int64_t *total);
 void bbfmm_schwarz_destroy(bbfmm_schwarz *h);
 int64_t bbfmm_schwarz_basis_size(const bbfmm_schwarz *h);           /* InterpolantSettings::basis_size */
 int32_t bbfmm_schwarz_num_levels(const bbfmm_schwarz *h);

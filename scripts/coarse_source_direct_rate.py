@@ -2,7 +2,8 @@
 """Pricing the 'source-sparse' partial products of the Schwarz sweep from their parts, at config 3's
 sizes (10M uniform points, thin-plate spline): what a product K c costs when c lives on the 19.7k coarse points only,
  (a) as a direct sum over the coarse points -- timed here through the library's own near-field kernel: a tree over the
-     coarse points alone with one leaf (max_points_per_cell > their number), evaluated at the level's rows;
+     coarse points alone whose eight level-1 cells are leaves (max_points_per_cell > their number) and each other's
+     neighbours, so that every pair is near field, evaluated at the level's rows;
  (b) the K Q columns the polynomial projection of the fine-level corrections needs (schwarz.rs:117-126 makes every
      fine-level increment dense: s - Q Q^T s) -- 4 partial products onto the 1.25M level-1 rows, timed as one.
 args: [points=10000000]"""
@@ -19,7 +20,7 @@ coarse = pts[rng.choice(n, nc, replace=False)]
 out = {"points": n, "coarse_points": nc, "kernel": "ThinPlateSplineRbf"}
 t = F.FmmTree(coarse, 4, F.KernelParams(F.KernelType(1)), True, True, extents=[0, 0, 0, 1, 1, 1],
               params=F.FmmParams(nc + 1, 2, 1e-4, 1024))
-assert t.stats().n_leaves == 1
+assert t.stats().n_leaves <= 8 and t.stats().n_v == 0     # the root's children are leaves and each other's neighbours: all near field
 w = rng.standard_normal((nc, 1))
 t.set_weights(w)
 for label, m in (("direct_coarse_sources_to_level1_rows", n1), ("direct_coarse_sources_to_level2_rows", n2)):
