@@ -29,7 +29,7 @@ def main():
     vals = np.sin(3 * pts[:, 0]) * np.cos(2 * pts[:, 1]) + 0.5 * pts[:, 2] ** 2
     tree = F.FmmTree(pts, 6, F.KernelParams(F.KernelType(kid), base_range=0.3, total_sill=0.3), True, True, deterministic=True)
     st = InterpolantSettings(kid, 3, base_range=0.3, total_sill=0.3)
-    prm = DDMParams(256, 0.5, 0.125, 1000)
+    prm = DDMParams(1024, 0.5, 0.125, 2000)      # 60k points: 60k -> 7.5k -> 938 (coarse), ~128 and ~16 domains
     whole = SchwarzPreconditioner(tree, pts, st, prm)
     shard = SchwarzPreconditioner(tree, pts, st, prm, shard_group=True)
     m = st.basis_size
@@ -41,8 +41,8 @@ def main():
     own = [shard.domains_owned(lv) for lv in range(shard.num_levels)]
     op = S.RbfSystemOperator(tree, m, whole.monomial_matrix, 0.0)
     rhs = np.concatenate([vals, np.zeros(m)])
-    x0, h0 = S.fgmres(op, rhs, whole, None, 4, 5, S.FittingAccuracy(1e-7))
-    x1, h1 = S.fgmres(op, rhs, shard, None, 4, 5, S.FittingAccuracy(1e-7))
+    x0, h0 = S.fgmres(op, rhs, whole, None, 4, 5, S.FittingAccuracy(1e-6))
+    x1, h1 = S.fgmres(op, rhs, shard, None, 4, 5, S.FittingAccuracy(1e-6))
     print(json.dumps({"rank": rank, "world": world, "levels": shard.num_levels,
                       "apply_equal": bool(np.array_equal(z0, z1) and np.array_equal(z1, z2)),
                       "apply_max_diff": float(np.abs(z0 - z1).max()), "apply_norm": float(np.abs(z0).max()),

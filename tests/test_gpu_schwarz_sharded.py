@@ -41,7 +41,7 @@ def test_sharded_factors_give_the_unsharded_preconditioner(world, kid):
     for r in res:
         assert r["apply_equal"], r                                  # one apply: bit for bit (twice)
         assert r["iterations"][0] == r["iterations"][1] and r["history_equal"] and r["solution_equal"], r
-        assert r["final_residual"] < 1e-7
+        assert r["final_residual"] < 1e-6
     levels = res[0]["levels"]
     assert levels >= 3
     for lv in range(levels - 1):                                     # fine levels: contiguous shares that cover the domains
