@@ -16,12 +16,12 @@ wc -c gpurun_out/${TAG}_bench.json
 grep -v "bench detail" gpurun_out/${TAG}_bench.err | tail -2; cut -c1-400 gpurun_out/${TAG}_bench.json
 cd /tmp && export TMPDIR=/tmp
 rm -rf $ROOT/gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-baseline off --configs off > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>$ROOT/gpurun_out/prof_${TAG}.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_$TAG -- python3 $ROOT/bench.py --steps 10 --warmup 2 --cpu-baseline off --configs off --dropin off > $ROOT/gpurun_out/${TAG}_bench_under_rocprof.json 2>$ROOT/gpurun_out/prof_${TAG}.err
 cp $ROOT/gpurun_out/prof_$TAG/*/*_kernel_stats.csv $ROOT/gpurun_out/${TAG}_kernel_stats.csv
 head -12 $ROOT/gpurun_out/${TAG}_kernel_stats.csv | cut -c1-150
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil MfmaFlopsF64 VALUBusy VALUUtilization; do
   rm -rf $ROOT/gpurun_out/pmc_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $ROOT/gpurun_out/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-baseline off --configs off > $ROOT/gpurun_out/pmc_$c.txt 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $ROOT/gpurun_out/pmc_$c -- python3 $ROOT/bench.py --steps 2 --warmup 1 --cpu-baseline off --configs off --dropin off > $ROOT/gpurun_out/pmc_$c.txt 2>&1
 done
 cd $ROOT
 python3 - "$TAG" <<'PY'
