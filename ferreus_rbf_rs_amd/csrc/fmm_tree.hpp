@@ -189,6 +189,8 @@ class FmmTree {
     int device() const { return device_; }
     bool tree_built_on_device() const { return tree_built_on_device_; }
     bool last_evaluate_at_sources() const { return last_eval_at_sources_; }
+    // m == N targets that are the handle's source points bit for bit, row for row (what evaluate() asks; host only)
+    bool targets_are_sources(const double *x, int64_t m, int64_t ldx) const;
     void stats(bbfmm_tree_stats *out) const;
     void set_profiling(bool on) { profiling_ = on; }
     // Resolves the recorded event pairs (synchronises the stream) and returns the totals.
@@ -395,7 +397,6 @@ class FmmTree {
     int pin_w_k_ = 0;
     int put_weights(const double *w, int64_t rows, int k, int64_t ldw);
     bool weights_match_staged(const double *w, int k, int64_t ldw) const;
-    bool targets_are_sources(const double *x, int64_t m, int64_t ldx) const;
     bool last_eval_at_sources_ = false;
     static constexpr int64_t kHostPiece = int64_t(1) << 18;  // rows per piece of the host <-> device pipelines (2 MB)
     std::vector<hipEvent_t> ev_out_;                         // per piece of the pipelined copy back

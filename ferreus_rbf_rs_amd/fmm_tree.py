@@ -375,6 +375,11 @@ class FmmTree:
         ran the resident-target path of the matvec (include/ferreus_bbfmm_hip.h, bbfmm_last_evaluate_at_sources)."""
         return bool(self._lib.bbfmm_last_evaluate_at_sources(self._h))
 
+    def debug_targets_are_sources(self, target_points) -> bool:
+        """The host-side comparison bbfmm_evaluate runs on m == N targets (bit for bit, row for row)."""
+        x = _as_f64_2d(target_points, "target_points")
+        return bool(self._lib.bbfmm_debug_targets_are_sources(self._h, x.ctypes.data, x.shape[0], max(x.shape[0], 1)))
+
     def tree_built_on_device(self) -> bool:
         return bool(self._lib.bbfmm_tree_built_on_device(self._h))
 

@@ -154,6 +154,9 @@ int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, in
  * Returns 1 when the last bbfmm_evaluate on this handle took the resident-source path, else 0.
  * BBFMM_EVAL_SOURCES_FAST=0 in the environment disables the detection (checker). */
 int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h);
+/* The comparison itself (host only, also on BBFMM_FLAG_HOST_ONLY handles): 1 when x (m x d, ldx) equals the handle's
+ * source points bit for bit and row for row, else 0. */
+int bbfmm_debug_targets_are_sources(const bbfmm_handle *h, const double *x, int64_t m, int64_t ldx);
 
 /* FmmTree::evaluate_with_gradients (utils.rs:453-461 -> bbfmm.rs:434-441).
  * grad is m x (k*d), columns [rhs0_dx, rhs0_dy, rhs0_dz, rhs1_dx, ...]. */

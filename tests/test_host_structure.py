@@ -268,3 +268,25 @@ def test_bounded_m2l_intermediate_batches_reproduce_m2l(monkeypatch, budget_mb, 
                        O._p(r.ops.perm_lookup), O._p(r.ops.ref_lookup), O._p(r.M), O._p(r.L))
     assert relerr(Lp, r.L[0]) < 1e-12
     assert st.m2l_slots_bytes_per_rhs > 0
+
+
+def test_targets_are_sources_comparison_is_bit_for_bit_and_row_for_row():
+    """What bbfmm_evaluate asks before it serves the unchanged caller (rbf.rs:1357-1364) from the resident target set:
+    the threaded host comparison alone, on a host-only handle (the device side: tests/test_gpu_unchanged_caller.py)."""
+    rng = np.random.default_rng(31)
+    n = 700_000                                                   # several 2 MB pieces per axis: every helper thread compares
+    pts = rng.random((n, 3))
+    pts[123, 2] = 0.0
+    t = F.FmmTree(pts, 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, host_only=True)
+    assert t.debug_targets_are_sources(pts) and t.debug_targets_are_sources(pts.copy())
+    x = pts.copy()
+    x[n - 1, 2] = np.nextafter(x[n - 1, 2], 2.0)                  # the very last value, one ulp
+    assert not t.debug_targets_are_sources(x)
+    x = pts.copy()
+    x[[5, 600_000]] = x[[600_000, 5]]                             # the same set of rows, two swapped
+    assert not t.debug_targets_are_sources(x)
+    x = pts.copy()
+    x[123, 2] = -0.0                                              # equal as a number, not as bits
+    assert not t.debug_targets_are_sources(x)
+    assert not t.debug_targets_are_sources(pts[:-1]) and not t.debug_targets_are_sources(np.vstack([pts, pts[:1]]))
+    assert not t.debug_targets_are_sources(pts[:, :2])            # another dimension
