@@ -189,6 +189,9 @@ class FmmTree {
     int device() const { return device_; }
     bool tree_built_on_device() const { return tree_built_on_device_; }
     bool last_evaluate_at_sources() const { return last_eval_at_sources_; }
+    int last_evaluate_path() const { return last_eval_at_sources_ ? 1 : (last_eval_rows_of_sources_ ? 2 : 0); }
+    // targets that are rows of the sources, bit for bit: their row numbers (host only; builds the point table on first use)
+    bool targets_are_rows_of_sources(const double *x, int64_t m, int64_t ldx, std::vector<int64_t> *rows);
     // m == N targets that are the handle's source points bit for bit, row for row (what evaluate() asks; host only)
     bool targets_are_sources(const double *x, int64_t m, int64_t ldx) const;
     void stats(bbfmm_tree_stats *out) const;
@@ -398,6 +401,12 @@ class FmmTree {
     int put_weights(const double *w, int64_t rows, int k, int64_t ldw);
     bool weights_match_staged(const double *w, int k, int64_t ldw) const;
     bool last_eval_at_sources_ = false;
+    bool last_eval_rows_of_sources_ = false;
+    // open-addressing table over the source points keyed by the bits of their coordinates (value: a row with those
+    // coordinates, -1: empty); built by the first evaluate() that could be a matvec_partial of the unchanged caller
+    std::vector<int32_t, DefaultInitAllocator<int32_t>> src_row_table_;
+    uint64_t src_row_mask_ = 0;
+    uint64_t point_hash(const double *x, int64_t ld, int64_t i) const;
     static constexpr int64_t kHostPiece = int64_t(1) << 18;  // rows per piece of the host <-> device pipelines (2 MB)
     std::vector<hipEvent_t> ev_out_;                         // per piece of the pipelined copy back
     TargetSet src_targets_;  // targets = sources (the matvec)

@@ -373,7 +373,12 @@ class FmmTree:
     def last_evaluate_at_sources(self) -> bool:
         """True when the last evaluate() found its targets to be the source points (bit for bit, row for row) and
         ran the resident-target path of the matvec (include/ferreus_bbfmm_hip.h, bbfmm_last_evaluate_at_sources)."""
-        return bool(self._lib.bbfmm_last_evaluate_at_sources(self._h))
+        return int(self._lib.bbfmm_last_evaluate_at_sources(self._h)) == 1
+
+    def last_evaluate_path(self) -> int:
+        """0: the general path; 1: targets = the sources (resident target set); 2: targets = rows of the sources (cached
+        plan of the index set) -- bbfmm_last_evaluate_at_sources"""
+        return int(self._lib.bbfmm_last_evaluate_at_sources(self._h))
 
     def debug_targets_are_sources(self, target_points) -> bool:
         """The host-side comparison bbfmm_evaluate runs on m == N targets (bit for bit, row for row)."""

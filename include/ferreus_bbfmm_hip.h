@@ -151,8 +151,13 @@ int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, in
  * once, M2P fused with P2L, no target upload or grouping -- and weights equal to those of the preceding
  * bbfmm_set_weights are not transferred a second time.  One differing bit (a perturbed coordinate, two rows
  * swapped, -0.0 for 0.0) takes the general path.  Results of the two paths agree to summation order (1e-12).
- * Returns 1 when the last bbfmm_evaluate on this handle took the resident-source path, else 0.
- * BBFMM_EVAL_SOURCES_FAST=0 in the environment disables the detection (checker). */
+ * The same caller's matvec_partial (rbf.rs:119-133: target_indices = Some(idx)) evaluates at
+ * select_mat_rows(source_points, idx): targets that are ROWS of the sources (one rhs, N / 2048 <= m <= N / 2 rows, each
+ * found bit for bit in a table over the source points that the first such call builds) are served by the cached plan
+ * bbfmm_fast_matrix_vector_product(target_indices) uses -- sorted targets and restricted downward pass once per index
+ * set, not once per call.  One target that is no source point takes the general path.
+ * Returns which path the last bbfmm_evaluate on this handle took: 1 the resident sources, 2 the cached plan of a row
+ * subset, 0 the general path.  BBFMM_EVAL_SOURCES_FAST=0 in the environment disables both detections (checker). */
 int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h);
 /* The comparison itself (host only, also on BBFMM_FLAG_HOST_ONLY handles): 1 when x (m x d, ldx) equals the handle's
  * source points bit for bit and row for row, else 0. */

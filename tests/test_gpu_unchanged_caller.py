@@ -154,3 +154,41 @@ def test_gradients_at_the_sources_keep_the_general_path(case):
     assert not t2.last_evaluate_at_sources()
     y0 = t2.evaluate(w, pts[:30000])
     assert t2.last_evaluate_at_sources() and relerr(y, y0) < 1e-12 and g.shape == (30000, 3)
+
+
+def test_rows_of_the_sources_take_the_cached_subset_plan(case):
+    """The unchanged caller's matvec_partial (rbf.rs:119-133 with Some(target_indices)): set_weights(w), then
+    evaluate(w, select_mat_rows(source_points, idx)).  Targets that are rows of the sources are recognised (a table over
+    the source points, bit for bit) and served by the plan bbfmm_fast_matrix_vector_product(target_indices) caches."""
+    rng, pts, t, r = case
+    n = len(pts)
+    w = rng.standard_normal((n, 1))
+    idx = np.sort(rng.choice(n, n // 8, replace=False))
+    x = pts[idx]                                                  # select_mat_rows
+    t.set_weights(w)
+    y = t.evaluate(w, x)
+    assert t.last_evaluate_path() == 2 and not t.last_evaluate_at_sources()
+    r.set_weights(w)
+    yr = r.evaluate(w, x)
+    assert relerr(y, yr) < TOL
+    ym = t.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx)      # the patched caller: the same plan
+    assert relerr(y[:, 0], ym[idx]) < 1e-12
+    y2 = t.evaluate(w, x)                                         # (the plan is cached now)
+    assert t.last_evaluate_path() == 2 and relerr(y2, y) < 1e-12
+    # unsorted rows with a repeated one: still rows of the sources, values follow the rows
+    idx2 = rng.permutation(idx)[: n // 16]
+    idx2[3] = idx2[7]
+    y3 = t.evaluate(w, pts[idx2])
+    assert t.last_evaluate_path() == 2
+    full = t.evaluate(w, pts)[:, 0]
+    assert relerr(y3[:, 0], full[idx2]) < 1e-12
+    # one target that is no source point: the general path, same values elsewhere
+    x4 = x.copy()
+    x4[11, 0] = np.nextafter(x4[11, 0], 1.0)
+    y4 = t.evaluate(w, x4)
+    assert t.last_evaluate_path() == 0
+    keep = np.arange(len(idx)) != 11
+    assert relerr(y4[keep], y[keep]) < 1e-12 and relerr(y4, r.evaluate(w, x4)) < TOL
+    # small batches (an evaluator's grid) are not looked up at all
+    t.evaluate(w, pts[:500])
+    assert t.last_evaluate_path() == 0
