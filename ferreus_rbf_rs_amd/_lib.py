@@ -85,6 +85,7 @@ SIGNATURES = {
     "bbfmm_tree_built_on_device": (ctypes.c_int, [c_p]),
     "bbfmm_last_evaluate_at_sources": (ctypes.c_int, [c_p]),
     "bbfmm_debug_targets_are_sources": (ctypes.c_int, [c_p, c_p, c_i64, c_i64]),
+    "bbfmm_debug_rows_of_sources": (ctypes.c_int, [c_p, c_p, c_i64, c_i64, c_p]),
     "bbfmm_get_cells": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_get_leaf_sources": (ctypes.c_int, [c_p, c_p, c_p]),
     "bbfmm_get_list": (ctypes.c_int, [c_p, ctypes.c_char, c_p, c_p, c_p]),

@@ -237,6 +237,17 @@ int bbfmm_get_tree_stats(const bbfmm_handle *h, bbfmm_tree_stats *out) {
 int bbfmm_debug_targets_are_sources(const bbfmm_handle *h, const double *x, int64_t m, int64_t ldx) {
     return (h && h->tree.targets_are_sources(x, m, ldx)) ? 1 : 0;
 }
+int bbfmm_debug_rows_of_sources(bbfmm_handle *h, const double *x, int64_t m, int64_t ldx, int64_t *rows_out) {
+    if (!h || !rows_out) return 0;
+    try {
+        std::vector<int64_t> rows;
+        if (!h->tree.targets_are_rows_of_sources(x, m, ldx, &rows)) return 0;
+        std::copy(rows.begin(), rows.end(), rows_out);
+        return 1;
+    } catch (...) {
+        return 0;
+    }
+}
 int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h) { return h ? h->tree.last_evaluate_path() : 0; }
 int bbfmm_tree_built_on_device(const bbfmm_handle *h) { return (h && h->tree.tree_built_on_device()) ? 1 : 0; }
 

@@ -375,6 +375,13 @@ class FmmTree:
         ran the resident-target path of the matvec (include/ferreus_bbfmm_hip.h, bbfmm_last_evaluate_at_sources)."""
         return int(self._lib.bbfmm_last_evaluate_at_sources(self._h)) == 1
 
+    def debug_rows_of_sources(self, target_points):
+        """Source rows of targets that are rows of the sources (bit for bit), or None when one of them is no source point."""
+        x = _as_f64_2d(target_points, "target_points")
+        rows = np.zeros(x.shape[0], dtype=np.int64)
+        ok = self._lib.bbfmm_debug_rows_of_sources(self._h, x.ctypes.data, x.shape[0], max(x.shape[0], 1), rows.ctypes.data)
+        return rows if ok else None
+
     def last_evaluate_path(self) -> int:
         """0: the general path; 1: targets = the sources (resident target set); 2: targets = rows of the sources (cached
         plan of the index set) -- bbfmm_last_evaluate_at_sources"""

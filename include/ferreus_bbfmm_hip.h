@@ -162,6 +162,9 @@ int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h);
 /* The comparison itself (host only, also on BBFMM_FLAG_HOST_ONLY handles): 1 when x (m x d, ldx) equals the handle's
  * source points bit for bit and row for row, else 0. */
 int bbfmm_debug_targets_are_sources(const bbfmm_handle *h, const double *x, int64_t m, int64_t ldx);
+/* ... and the lookup of targets that are rows of the sources: 1 and rows_out[j] = a source row with the coordinates of
+ * target j (rows with equal coordinates are interchangeable) when every target is a source point, else 0. */
+int bbfmm_debug_rows_of_sources(bbfmm_handle *h, const double *x, int64_t m, int64_t ldx, int64_t *rows_out);
 
 /* FmmTree::evaluate_with_gradients (utils.rs:453-461 -> bbfmm.rs:434-441).
  * grad is m x (k*d), columns [rhs0_dx, rhs0_dy, rhs0_dz, rhs1_dx, ...]. */

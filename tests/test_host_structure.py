@@ -290,3 +290,27 @@ def test_targets_are_sources_comparison_is_bit_for_bit_and_row_for_row():
     assert not t.debug_targets_are_sources(x)
     assert not t.debug_targets_are_sources(pts[:-1]) and not t.debug_targets_are_sources(np.vstack([pts, pts[:1]]))
     assert not t.debug_targets_are_sources(pts[:, :2])            # another dimension
+
+
+def test_rows_of_the_sources_lookup():
+    """The table over the source points behind the unchanged caller's matvec_partial (rbf.rs:119-133 ->
+    select_mat_rows(source_points, idx)): built once by all host threads (compare-and-swap inserts), looked up per target."""
+    rng = np.random.default_rng(32)
+    n = 300_000
+    pts = rng.random((n, 3))
+    pts[1000] = pts[7]                                             # two rows with the same coordinates
+    t = F.FmmTree(pts, 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, host_only=True)
+    idx = rng.choice(n, 40_000, replace=False)
+    rows = t.debug_rows_of_sources(pts[idx])
+    assert rows is not None and np.array_equal(pts[rows], pts[idx])          # a row with exactly these coordinates
+    keep = (idx != 7) & (idx != 1000)
+    assert np.array_equal(rows[keep], idx[keep])                               # unique points: the row itself
+    both = t.debug_rows_of_sources(pts[[7, 1000]])
+    assert both[0] == both[1] and both[0] in (7, 1000)                          # equal points are interchangeable
+    x = pts[idx].copy()
+    x[-1, 1] = np.nextafter(x[-1, 1], 2.0)
+    assert t.debug_rows_of_sources(x) is None                                  # one target that is no source point
+    assert t.debug_rows_of_sources(rng.random((100, 3))) is None
+    t2 = F.FmmTree(pts[:, :2].copy(), 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, host_only=True)
+    r2 = t2.debug_rows_of_sources(pts[idx, :2])
+    assert r2 is not None and np.array_equal(pts[r2, :2], pts[idx, :2])
