@@ -191,6 +191,13 @@ impl FmmTree {
     }
 
     /// `evaluate` (utils.rs:441-449): M_t x K potentials.
+    ///
+    /// The unchanged `ferreus_rbf::fast_matrix_vector_product` (rbf.rs:1357-1364) calls `set_weights(w)` and then
+    /// `evaluate(w, select_mat_rows(source_points, idx))`.  Nothing has to change in that caller: the library
+    /// recognises targets that are the tree's source points (all rows in order: the FGMRES matvec) or rows of them
+    /// (`matvec_partial`, rbf.rs:119-133) bit for bit and serves them from its resident / cached target sets, and
+    /// weights equal to those of the preceding `set_weights` are not transferred twice (include/ferreus_bbfmm_hip.h,
+    /// `bbfmm_evaluate`; INTEGRATION.md "What each costs": 47.2 ms against 47.0 for the patched entry point at 10M points).
     pub fn evaluate(&mut self, w: &MatRef<'_, f64>, x: &Mat<f64>) -> Result<Mat<f64>, FmmError> {
         let mut out = Mat::<f64>::zeros(x.nrows(), w.ncols());
         let mut bad: i64 = -1;
