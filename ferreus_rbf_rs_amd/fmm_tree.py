@@ -217,8 +217,16 @@ class FmmTree:
                                                            w.shape[1], w.shape[0]))
         self._nrhs = w.shape[1]           # (the column count may also have been fixed by a matvec on the C side)
 
-    def _eval(self, fn, weights, target_points, grads, leaf):
+    def _targets(self, target_points):
+        """m x d column-major targets; the C ABI takes a pointer and reads d columns, so the column count is checked here
+        (the reference's faer views panic on a missing column; found by the ASan run of scripts/sanitize_host.sh)."""
         x = _as_f64_2d(target_points, "target_points")
+        if x.shape[1] != self.dim:
+            raise ValueError(f"target_points must have {self.dim} columns, got {x.shape[1]}")
+        return x
+
+    def _eval(self, fn, weights, target_points, grads, leaf):
+        x = self._targets(target_points)
         if weights is None and leaf:
             # leaves-only calls may reuse the weights resident on the device (header: bbfmm_evaluate_leaves)
             wp, rows, k = None, self.n_points, self._nrhs
@@ -377,7 +385,7 @@ class FmmTree:
 
     def debug_rows_of_sources(self, target_points):
         """Source rows of targets that are rows of the sources (bit for bit), or None when one of them is no source point."""
-        x = _as_f64_2d(target_points, "target_points")
+        x = self._targets(target_points)
         rows = np.zeros(x.shape[0], dtype=np.int64)
         ok = self._lib.bbfmm_debug_rows_of_sources(self._h, x.ctypes.data, x.shape[0], max(x.shape[0], 1), rows.ctypes.data)
         return rows if ok else None
@@ -389,7 +397,7 @@ class FmmTree:
 
     def debug_targets_are_sources(self, target_points) -> bool:
         """The host-side comparison bbfmm_evaluate runs on m == N targets (bit for bit, row for row)."""
-        x = _as_f64_2d(target_points, "target_points")
+        x = self._targets(target_points)
         return bool(self._lib.bbfmm_debug_targets_are_sources(self._h, x.ctypes.data, x.shape[0], max(x.shape[0], 1)))
 
     def tree_built_on_device(self) -> bool:
@@ -460,7 +468,7 @@ class FmmTree:
         return perm, inv, pl, rl
 
     def points_to_leaves(self, x):
-        x = _as_f64_2d(x, "target_points")
+        x = self._targets(x)
         m = x.shape[0]
         cells = np.zeros(max(m, 1), dtype=np.int32)
         bad = ctypes.c_int64(-1)

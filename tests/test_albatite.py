@@ -159,6 +159,29 @@ def test_device_solve_of_the_reference_example_equals_the_restatement(data, name
     fit = float(np.abs(op(x)[:n] - vals).max())
     assert fit < TOLERANCE                                                    # fitted values within 0.01 of the data
     assert relerr(x[:n], xo[:n]) < 1e-6                                       # and the coefficients themselves
+    # The examples go on to evaluate the interpolant on a 5 m grid inside the data's bounding box (build_isosurface,
+    # examples/isosurface_spheroidal.rs:118-129): a second tree over the same points, adaptive, NOT sparse, with explicit
+    # extents (RBFInterpolator::_setup_fmmtree / evaluate, rbf.rs:590-630, 677-690), weights = the solved coefficients.
+    # Full mode and Leaves mode (set_local_coefficients + evaluate_leaves, rbf.rs:830-838), kernel part only.
+    ext = np.concatenate([pts.min(0), pts.max(0)])
+    rng = np.random.default_rng(9)
+    grid = np.floor(ext[:3] / 5.0) * 5.0 + 5.0 * rng.integers(1, ((ext[3:] - ext[:3]) // 5.0).astype(int) - 1, size=(6000, 3))
+    assert np.all(grid >= ext[:3]) and np.all(grid <= ext[3:])
+    coef = x[:n, None].copy()
+    te = F.FmmTree(pts, ORDER, F.KernelParams(F.KernelType(kid), base_range=br, total_sill=sill), True, False, extents=list(ext))
+    oe = O.FmmTree(pts, ORDER, kid, True, False, list(ext), None, base_range=br, total_sill=sill)
+    inject_product_operators(te, oe)
+    te.set_weights(coef)
+    oe.set_weights(coef)
+    v, vo = te.evaluate(coef, grid), oe.evaluate(coef, grid)
+    assert relerr(v, vo) < 1e-11
+    te.set_local_coefficients(coef)
+    assert relerr(te.evaluate_leaves(coef, grid), vo) < 1e-11
+    sub = rng.choice(len(grid), 300, replace=False)
+    assert relerr(v[sub], O.dense_sum(kid, br, sill, grid[sub], pts, coef)) < 1e-4   # the BBFMM's accuracy on the solved weights
+    vg, gg = te.evaluate_with_gradients(coef, grid)
+    _, go = oe.evaluate_with_gradients(coef, grid)
+    assert relerr(vg, vo) < 1e-11 and relerr(gg, go) < 1e-9
     out = os.path.join(ROOT, "gpurun_out", "albatite_solve_histories.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     rec = json.load(open(out)) if os.path.exists(out) else {}
