@@ -54,8 +54,9 @@ TSAN_RT=$(python -c "from ferreus_rbf_rs_amd import build as b; print(b.sanitize
 say "== 2. ThreadSanitizer: $(basename "$TSAN_LIB"), runtime $TSAN_RT"
 # die_after_fork=0: the fork test starts a pool in the child of a threaded parent on purpose (TSan refuses that by default: a limit
 # of its runtime, not a report)
-export TSAN_OPTIONS=halt_on_error=1:exitcode=97:report_signal_unsafe=0:die_after_fork=0
-FERREUS_BBFMM_HIP_LIB=$TSAN_LIB LD_PRELOAD=$TSAN_RT timeout 7200 python -m pytest tests/test_ddm_tree.py tests/test_host_structure.py tests/test_partition_upward.py tests/test_solvers.py -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -25 | tee -a "$LOG"
+# numpy's OpenBLAS is not instrumented (scripts/tsan_suppressions.txt): single-threaded here, and suppressed by library
+export TSAN_OPTIONS=halt_on_error=1:exitcode=97:report_signal_unsafe=0:die_after_fork=0:suppressions=$PWD/scripts/tsan_suppressions.txt
+FERREUS_BBFMM_HIP_LIB=$TSAN_LIB LD_PRELOAD=$TSAN_RT OPENBLAS_NUM_THREADS=1 timeout 7200 python -m pytest tests/test_ddm_tree.py tests/test_host_structure.py tests/test_partition_upward.py tests/test_solvers.py -q -m "not gpu" -p no:cacheprovider 2>&1 | tail -25 | tee -a "$LOG"
 rc=${PIPESTATUS[0]}
 say "   exit code $rc"
 [ "$rc" -eq 0 ] || fail=1
