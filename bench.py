@@ -642,6 +642,26 @@ def dropin_host_buffer_times(tree, pts, reps=5):
     res["unchanged_caller_general_path_ms"] = med(lambda: unchanged(x2))
     res["general_path_took_resident_path"] = bool(tree.last_evaluate_at_sources())
     res["ratio_unchanged_over_patched"] = res["unchanged_caller_ms"] / res["patched_caller_ms"]
+    # matvec_partial (rbf.rs:119-133) the same two ways, on the rows of a Schwarz coarse level (N / 512): patched =
+    # target_indices, unchanged = set_weights + evaluate at select_mat_rows(source_points, idx) (rows of the sources are
+    # recognised and served by the same cached plan)
+    idx = np.sort(np.random.default_rng(44).choice(n, max(n // 512, 1), replace=False)).astype(np.int64)
+    xs = np.asfortranarray(pts[idx])
+    m = len(idx)
+    z = np.zeros(m)
+
+    def patched_partial():
+        return lib.bbfmm_fast_matrix_vector_product(tree._h, w.ctypes.data, n, 0, idx.ctypes.data, m, None, 0, 0.0, y.ctypes.data)
+
+    def unchanged_partial():
+        rc = lib.bbfmm_set_weights(tree._h, w.ctypes.data, n, 1, n)
+        return rc or lib.bbfmm_evaluate(tree._h, w.ctypes.data, n, 1, n, xs.ctypes.data, m, m, z.ctypes.data, m, ctypes.byref(bad))
+
+    part = {"rows": m, "patched_ms": med(patched_partial)}
+    part["unchanged_ms"] = med(unchanged_partial)
+    part["unchanged_path"] = int(tree.last_evaluate_path())       # 2 = the cached plan of a row subset
+    part["rel_diff"] = float(np.abs(y[idx] - z).max() / max(np.abs(z).max(), 1e-300))
+    res["partial_product_rows_n_over_512"] = part
     return res
 
 

@@ -198,6 +198,7 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
         });
 
     double ext[6];
+    solver_tree_ = sparse && !extents;
     if (extents) {
         std::copy(extents, extents + 2 * d, ext);
     } else { // utils.rs:13-46 (min / max per axis: chunk results combined in order)
@@ -1115,10 +1116,11 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     // The unchanged caller of matvec_partial (rbf.rs:119-133: fast_matrix_vector_product with Some(target_indices), i.e.
     // set_weights(w) then evaluate(w, select_mat_rows(source_points, idx))): targets that are rows of the sources get the
     // cached plan of bbfmm_fast_matrix_vector_product(target_indices) -- sorted targets and restricted downward pass are
-    // built once per index set instead of once per call (10M points, 19.5k rows: 88 -> 38 ms).  Batches below N / 2048
-    // rows (an evaluator's grid batches) are not looked up.
+    // built once per index set instead of once per call (10M points, 19.5k rows: 88 -> 38 ms).  Only on a tree made the
+    // way the solver makes its own (sparse, extents from the data: rbf.rs:456-467) -- an evaluator's tree (explicit
+    // extents, not sparse: rbf.rs:677-690) never builds the table -- and not for batches below N / 2048 rows.
     last_eval_rows_of_sources_ = false;
-    if (sources_fast && !m2l_queued && !leaves_only && !with_grads && !have_part_ && !locals_requested_ && k == 1 && w &&
+    if (sources_fast && solver_tree_ && !m2l_queued && !leaves_only && !with_grads && !have_part_ && !locals_requested_ && k == 1 && w &&
         m < tree_.n_points && m >= std::max<int64_t>(1024, tree_.n_points / 2048) && m <= tree_.n_points / 2) {
         std::vector<int64_t> rows_of;
         if (targets_are_rows_of_sources(x, m, ldx, &rows_of)) {

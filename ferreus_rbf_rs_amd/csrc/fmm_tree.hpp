@@ -402,6 +402,7 @@ class FmmTree {
     bool weights_match_staged(const double *w, int k, int64_t ldw) const;
     bool last_eval_at_sources_ = false;
     bool last_eval_rows_of_sources_ = false;
+    bool solver_tree_ = false; // created as the solver creates its tree (rbf.rs:456-467: sparse, extents from the data)
     // open-addressing table over the source points keyed by the bits of their coordinates (value: a row with those
     // coordinates, -1: empty); built by the first evaluate() that could be a matvec_partial of the unchanged caller
     std::vector<int32_t, DefaultInitAllocator<int32_t>> src_row_table_;

@@ -152,7 +152,8 @@ int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, in
  * bbfmm_set_weights are not transferred a second time.  One differing bit (a perturbed coordinate, two rows
  * swapped, -0.0 for 0.0) takes the general path.  Results of the two paths agree to summation order (1e-12).
  * The same caller's matvec_partial (rbf.rs:119-133: target_indices = Some(idx)) evaluates at
- * select_mat_rows(source_points, idx): targets that are ROWS of the sources (one rhs, N / 2048 <= m <= N / 2 rows, each
+ * select_mat_rows(source_points, idx): on a handle created the way the solver creates its tree (sparse, extents NULL:
+ * rbf.rs:456-467), targets that are ROWS of the sources (one rhs, N / 2048 <= m <= N / 2 rows, each
  * found bit for bit in a table over the source points that the first such call builds) are served by the cached plan
  * bbfmm_fast_matrix_vector_product(target_indices) uses -- sorted targets and restricted downward pass once per index
  * set, not once per call.  One target that is no source point takes the general path.

@@ -192,3 +192,8 @@ def test_rows_of_the_sources_take_the_cached_subset_plan(case):
     # small batches (an evaluator's grid) are not looked up at all
     t.evaluate(w, pts[:500])
     assert t.last_evaluate_path() == 0
+    # nor is anything on a tree made the evaluator's way (explicit extents, not sparse: rbf.rs:677-690)
+    te = F.FmmTree(pts, 5, F.KernelParams(F.FmmKernelType.LinearRbf), True, False, extents=[0, 0, 0, 1, 1, 1])
+    te.set_weights(w)
+    ze = te.evaluate(w, x)
+    assert te.last_evaluate_path() == 0 and relerr(ze, y) < 1e-4          # (order 5: the method's accuracy)
