@@ -188,3 +188,17 @@ def test_the_stdout_line_stays_under_4_kb_and_round_trips(world, tmp_path, monke
     with open(tmp_path / "bench_detail.json") as f:
         full = json.load(f)
     assert full["configs"]["config2_spheroidal3_1M"]["phase_roofline"] and full["cpu_baseline_detail"]["note"]
+
+
+def test_full_size_cpu_figure_is_the_newest_committed_run(tmp_path, monkeypatch):
+    """cpu_baseline quotes the port's one full-size run beside its scaled sample: the newest profiles/r*_cpu_port_full_10M.json."""
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "r03_cpu_port_full_10M.json").write_text(json.dumps({"matvecs_per_s_full_size": 0.0204}))
+    (prof / "r05_cpu_port_full_10M.json").write_text(json.dumps({"matvecs_per_s_full_size": 0.0905, "threads": 64}))
+    (prof / "r05_cpu_port_full_10M.json.bak").write_text("not json")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    got = bench.measured_cpu_full_size()
+    assert got["matvecs_per_s_full_size"] == 0.0905 and got["file"].endswith("r05_cpu_port_full_10M.json")
+    real = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r05_cpu_port_full_10M.json")))
+    assert 0.05 < real["matvecs_per_s_full_size"] < 0.2 and real["threads"] in (32, 64, 128, 256)
