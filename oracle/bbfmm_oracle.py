@@ -960,6 +960,15 @@ class FmmTree:
             cur = cur[cur >= 0]
         return flags
 
+    def _zeroed(self, name, shape):
+        """A zero-filled coefficient array (reset_*_coefficients, bbfmm.rs:619-632).  In the cpu_baseline mode the array of
+        the previous pass is kept and cleared by all threads (oracle_zero) instead of taking fresh pages from the kernel."""
+        old = getattr(self, name, None)
+        if self.gemm_shaped and isinstance(old, np.ndarray) and old.shape == tuple(shape) and old.flags["C_CONTIGUOUS"]:
+            lib().oracle_zero(_p(old), I64(old.size))
+            return old
+        return np.zeros(shape)
+
     def _w(self, weights):
         w = np.asarray(weights, dtype=np.float64)
         if w.ndim == 1:
@@ -972,7 +981,7 @@ class FmmTree:
         w = self._w(weights)
         self.nrhs = K = w.shape[1]
         n, C = self.ops.n, self.C
-        self.M = np.zeros((K, C, n))
+        self.M = self._zeroed("M", (K, C, n))
         L = lib()
         leafs_with_sources = [c for c in self.leaf_cells if self.src_ptr[c + 1] > self.src_ptr[c]]
         with_src = self._ancestor_flags(leafs_with_sources)
@@ -1008,7 +1017,7 @@ class FmmTree:
     def _downward(self, w, active):
         """downward_pass, bbfmm.rs:778-857"""
         K, n, C = self.nrhs, self.ops.n, self.C
-        self.L = np.zeros((K, C, n))
+        self.L = self._zeroed("L", (K, C, n))
         L = lib()
         compressed = 0 if self.params.compression_type == COMPRESSION_NONE else 1
         for level in range(1, self.depth + 1):

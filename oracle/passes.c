@@ -30,6 +30,23 @@
 #include <omp.h>
 #endif
 
+/* Per-thread scratch that survives the parallel regions (grow-only, never freed: test infrastructure).  The passes
+ * used to malloc their work arrays at the top of every parallel region; the M2L ones are ~1 MB each, i.e. an mmap, a
+ * page fault per 4 KB and a munmap per thread, region and level -- with 128-256 threads those serialise in the kernel
+ * and the port got slower with every doubling of the thread count (2 x 64-core host of a GPU box). */
+#define TLS_SLOTS 8
+static __thread void *tls_ptr[TLS_SLOTS];
+static __thread size_t tls_len[TLS_SLOTS];
+static void *tls_buf(int slot, size_t bytes)
+{
+    if (tls_len[slot] < bytes) {
+        free(tls_ptr[slot]);
+        tls_ptr[slot] = malloc(bytes);
+        tls_len[slot] = tls_ptr[slot] ? bytes : 0;
+    }
+    return tls_ptr[slot];
+}
+
 /* ------------------------------------------------------------------ kernels */
 /* KernelType order: ferreus_rbf_utils/src/utils.rs:558-571.  100/101 are
  * extension kernels of this repo (NOT in the reference; BASELINE.json configs
@@ -370,7 +387,7 @@ void oracle_p2m(int p, int d, int64_t C, int K,
     int n = ipow(p, d);
 #pragma omp parallel
     {
-        double *row = (double *)malloc(sizeof(double) * n);
+        double *row = (double *)tls_buf(0, sizeof(double) * n);
 #pragma omp for schedule(dynamic, 4)
         for (int64_t li = 0; li < nleaf; ++li) {
             int64_t c = leaf_cells[li];
@@ -384,7 +401,6 @@ void oracle_p2m(int p, int d, int64_t C, int K,
                 }
             }
         }
-        free(row);
     }
 }
 
@@ -460,10 +476,10 @@ void oracle_m2l(int n, int64_t C, int K, const int64_t *cells, int64_t ncells,
 #pragma omp parallel
     {
         int maxv = 7 * 7 * 7;
-        double *X = (double *)malloc(sizeof(double) * (size_t)n * maxv);  /* permuted multipoles, n x kk */
-        double *Cm = (double *)malloc(sizeof(double) * (size_t)n * maxv); /* r x kk */
-        double *Y = (double *)malloc(sizeof(double) * (size_t)n * maxv);  /* n x kk */
-        int64_t *grp = (int64_t *)malloc(sizeof(int64_t) * maxv);
+        double *X = (double *)tls_buf(1, sizeof(double) * (size_t)n * maxv);  /* permuted multipoles, n x kk */
+        double *Cm = (double *)tls_buf(2, sizeof(double) * (size_t)n * maxv); /* r x kk */
+        double *Y = (double *)tls_buf(3, sizeof(double) * (size_t)n * maxv);  /* n x kk */
+        int64_t *grp = (int64_t *)tls_buf(4, sizeof(int64_t) * maxv);
 #pragma omp for schedule(dynamic, 1)
         for (int64_t ci = 0; ci < ncells; ++ci) {
             int64_t B = cells[ci];
@@ -523,7 +539,6 @@ void oracle_m2l(int n, int64_t C, int K, const int64_t *cells, int64_t ncells,
                 }
             }
         }
-        free(X); free(Cm); free(Y); free(grp);
     }
 }
 
@@ -606,10 +621,10 @@ void oracle_m2l_gemm(int n, int64_t C, int K, const int64_t *cells, int64_t ncel
 #pragma omp parallel
     {
         int maxv = 7 * 7 * 7;
-        double *X = (double *)malloc(sizeof(double) * (size_t)np8 * maxv);
-        double *Cm = (double *)malloc(sizeof(double) * (size_t)np8 * maxv);
-        double *Y = (double *)malloc(sizeof(double) * (size_t)np8 * maxv);
-        int64_t *grp = (int64_t *)malloc(sizeof(int64_t) * maxv);
+        double *X = (double *)tls_buf(1, sizeof(double) * (size_t)np8 * maxv);
+        double *Cm = (double *)tls_buf(2, sizeof(double) * (size_t)np8 * maxv);
+        double *Y = (double *)tls_buf(3, sizeof(double) * (size_t)np8 * maxv);
+        int64_t *grp = (int64_t *)tls_buf(4, sizeof(int64_t) * maxv);
         /* cells of a level come in (level, key) order: neighbours in the list share most of their V-list sources, so a
          * thread keeps a contiguous block (static) -- no queue shared by all threads, no accumulator shared by any two */
 #pragma omp for schedule(static)
@@ -646,7 +661,6 @@ void oracle_m2l_gemm(int n, int64_t C, int K, const int64_t *cells, int64_t ncel
                 }
             }
         }
-        free(X); free(Cm); free(Y); free(grp);
     }
     for (int ref = 0; ref < nref; ++ref) { free(Up[ref]); free(Vp[ref]); }
     free(Up); free(Vp); free(rp8);
@@ -665,7 +679,7 @@ void oracle_p2l(int id, double base_range, double total_sill, int n, int d, int6
     kspec_t ks = make_kspec(id, base_range, total_sill);
 #pragma omp parallel
     {
-        double *nodes = (double *)malloc(sizeof(double) * (size_t)n * d);
+        double *nodes = (double *)tls_buf(5, sizeof(double) * (size_t)n * d);
 #pragma omp for schedule(dynamic, 1)
         for (int64_t ci = 0; ci < ncells; ++ci) {
             int64_t B = cells[ci];
@@ -685,7 +699,6 @@ void oracle_p2l(int id, double base_range, double total_sill, int n, int d, int6
                 }
             }
         }
-        free(nodes);
     }
 }
 
@@ -712,9 +725,9 @@ void oracle_leaf_pass(int id, double base_range, double total_sill, int p, int d
     int n = ipow(p, d);
 #pragma omp parallel
     {
-        double *row = (double *)malloc(sizeof(double) * n);
-        double *grow = (double *)malloc(sizeof(double) * (size_t)n * d);
-        double *nodes = (double *)malloc(sizeof(double) * (size_t)n * d);
+        double *row = (double *)tls_buf(0, sizeof(double) * n);
+        double *grow = (double *)tls_buf(6, sizeof(double) * (size_t)n * d);
+        double *nodes = (double *)tls_buf(5, sizeof(double) * (size_t)n * d);
 #pragma omp for schedule(dynamic, 1)
         for (int64_t li = 0; li < nleaves; ++li) {
             int64_t B = leaves[li];
@@ -728,7 +741,7 @@ void oracle_leaf_pass(int id, double base_range, double total_sill, int p, int d
                  * the same sources in the same order per target as the loop below, in SIMD partial sums. */
                 int64_t ns = 0;
                 for (int64_t q = u_ptr[B]; q < u_ptr[B + 1]; ++q) ns += src_ptr[u_idx[q] + 1] - src_ptr[u_idx[q]];
-                double *gx = (double *)malloc(sizeof(double) * (size_t)ns * (3 + (size_t)K));
+                double *gx = (double *)tls_buf(7, sizeof(double) * (size_t)ns * (3 + (size_t)K));
                 double *gy = gx + ns, *gz = gy + ns, *gw = gz + ns;
                 int64_t at = 0;
                 for (int64_t q = u_ptr[B]; q < u_ptr[B + 1]; ++q) {
@@ -762,7 +775,6 @@ void oracle_leaf_pass(int id, double base_range, double total_sill, int p, int d
                         out[k * ldo + ti] += acc;
                     }
                 }
-                free(gx);
             } else if (flags & 1) {
                 for (int64_t q = u_ptr[B]; q < u_ptr[B + 1]; ++q) {
                     int64_t U = u_idx[q];
@@ -840,7 +852,18 @@ void oracle_leaf_pass(int id, double base_range, double total_sill, int p, int d
                 }
             }
         }
-        free(row); free(grow); free(nodes);
+    }
+}
+
+/* Zero fill by all threads (static blocks): the coefficient arrays are kept between matvecs in the cpu_baseline mode --
+ * a fresh calloc per pass means a page fault per 4 KB from every thread at once, and those serialise in the kernel
+ * (measured on the 2 x 64-core host of a GPU box: the passes got SLOWER with every doubling of the thread count). */
+void oracle_zero(double *p, int64_t n)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t b = 0; b < (n + 65535) / 65536; ++b) {
+        int64_t lo = b * 65536, hi = lo + 65536 < n ? lo + 65536 : n;
+        memset(p + lo, 0, (size_t)(hi - lo) * sizeof(double));
     }
 }
 
