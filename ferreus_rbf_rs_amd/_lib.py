@@ -48,6 +48,12 @@ SIGNATURES = {
     "bbfmm_params_defaults": (None, [c_i32, c_p]),
     "bbfmm_create": (ctypes.c_int, [c_p, c_i64, c_i32, c_i64, c_i32, c_i32, c_f64, c_f64, c_i32,
                                     c_i32, c_p, c_p, c_u32, c_p]),
+    "bbfmm_create_on_devices": (ctypes.c_int, [c_p, c_i64, c_i32, c_i64, c_i32, c_i32, c_f64, c_f64, c_i32,
+                                               c_i32, c_p, c_p, c_u32, c_p, c_i32, c_p]),
+    "bbfmm_device_count": (c_i32, [c_p]),
+    "bbfmm_part_device": (c_i32, [c_p, c_i32]),
+    "bbfmm_group_bounds": (ctypes.c_int, [c_p, c_p]),
+    "bbfmm_get_part_phase_ms": (ctypes.c_int, [c_p, c_i32, c_p, c_p]),
     "bbfmm_destroy": (None, [c_p]),
     "bbfmm_last_error": (ctypes.c_char_p, [c_p]),
     "bbfmm_set_weights": (ctypes.c_int, [c_p, c_p, c_i64, c_i32, c_i64]),

@@ -16,10 +16,10 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libferreus_bbfmm_hip.so")
 
-HOST_SOURCES = ["tree.cpp", "operators.cpp", "fmm_tree.cpp", "fmm_m2l_tables.cpp", "fmm_plans.cpp", "capi.cpp", "solver.cpp", "ddm.cpp", "ddm_solver.cpp", "schwarz.cpp"]
+HOST_SOURCES = ["tree.cpp", "operators.cpp", "fmm_tree.cpp", "fmm_m2l_tables.cpp", "fmm_plans.cpp", "device_group.cpp", "capi.cpp", "solver.cpp", "ddm.cpp", "ddm_solver.cpp", "schwarz.cpp"]
 HIP_SOURCES = ["device.hip", "ddm_kernels.hip", "targets.hip", "schwarz_kernels.hip", "tree_device.hip", "tree_lists_device.hip"]
 HEADERS = ["morton.hpp", "tree.hpp", "parallel.hpp", "kernels.hpp", "operators.hpp", "device.hpp",
-           "fmm_tree.hpp", "fmm_tree_impl.hpp", "targets.hpp", "ddm.hpp", "ddm_solver.hpp", "ddm_monomials.hpp", "schwarz_kernels.hpp", "tree_device.hpp", os.path.join(ROOT, "include", "ferreus_bbfmm_hip.h")]
+           "fmm_tree.hpp", "fmm_tree_impl.hpp", "device_group.hpp", "targets.hpp", "ddm.hpp", "ddm_solver.hpp", "ddm_monomials.hpp", "schwarz_kernels.hpp", "tree_device.hpp", os.path.join(ROOT, "include", "ferreus_bbfmm_hip.h")]
 
 
 def _digest(paths: list[str], extra: str = "") -> str:

@@ -4,20 +4,32 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
+#include <memory>
+
+#include "device_group.hpp"
 #include "ferreus_bbfmm_hip.h"
 #include "fmm_tree.hpp"
 #include "morton.hpp"
 
 struct bbfmm_handle {
-    bbfmm::FmmTree tree;
+    bbfmm::FmmTree tree;                       // the handle's tree; part 0 of its device group when there is one
+    std::unique_ptr<bbfmm::DeviceGroup> group; // several devices (or logical parts) behind this one handle
     std::string err;
 };
 
 using bbfmm::FmmTree;
 
+// A failure of the group: its message becomes the handle's.
+static int group_rc(bbfmm_handle *h, int rc) {
+    if (rc != BBFMM_OK) h->err = h->group->last_error();
+    return rc;
+}
+
 #define GUARD(h)                              \
     if (!(h)) return BBFMM_BAD_ARGUMENT;      \
     try {                                     \
+        (h)->err.clear();                     \
         (h)->tree.bind_device();
 #define END_GUARD(h)                                   \
     }                                                  \
@@ -46,33 +58,124 @@ void bbfmm_params_defaults(int32_t interpolation_order, bbfmm_params *out) {
     out->eval_chunk_size = 1024;
 }
 
-int bbfmm_create(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t interpolation_order,
-                 int32_t kernel_type, double base_range, double total_sill, int32_t adaptive_tree, int32_t sparse,
-                 const double *extents, const bbfmm_params *params, uint32_t flags, bbfmm_handle **out) {
+// bbfmm_create on an explicit device list; devices == NULL: the current device (and no group).
+static int create_impl(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t interpolation_order, int32_t kernel_type,
+                       double base_range, double total_sill, int32_t adaptive_tree, int32_t sparse, const double *extents,
+                       const bbfmm_params *params, uint32_t flags, const std::vector<int> &devices, bbfmm_handle **out) {
     if (!out) return BBFMM_BAD_ARGUMENT;
     *out = nullptr;
     bbfmm_handle *h = nullptr;
+    int cur = -1;
     try {
         h = new bbfmm_handle();
-        const int rc = h->tree.create(pts, n, d, ld, interpolation_order, kernel_type, base_range, total_sill,
-                                      adaptive_tree != 0, sparse != 0, extents, params, flags);
-        // The handle is returned even on failure so that bbfmm_last_error can be read;
-        // the caller destroys it either way.
-        *out = h;
+        *out = h; // returned even on failure so that bbfmm_last_error can be read; the caller destroys it either way
+        if (!devices.empty()) {
+            if (flags & BBFMM_FLAG_HOST_ONLY) {
+                h->err = "a device list needs devices (BBFMM_FLAG_HOST_ONLY is set)";
+                return BBFMM_BAD_ARGUMENT;
+            }
+            int ndev = 0;
+            if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+                h->err = "no HIP device available (the BBFMM passes have no CPU fallback)";
+                return BBFMM_DEVICE_ERROR;
+            }
+            for (int dev : devices)
+                if (dev < 0 || dev >= ndev) {
+                    h->err = "device " + std::to_string(dev) + " of the device list does not exist (" + std::to_string(ndev) + " visible)";
+                    return BBFMM_BAD_ARGUMENT;
+                }
+            if (devices.size() > static_cast<size_t>(bbfmm::kMaxScatterParts)) {
+                h->err = "more parts in the device list than a handle takes";
+                return BBFMM_BAD_ARGUMENT;
+            }
+            (void)hipGetDevice(&cur);
+            if (hipSetDevice(devices[0]) != hipSuccess) {
+                h->err = "hipSetDevice failed for the first device of the list";
+                return BBFMM_DEVICE_ERROR;
+            }
+        }
+        int rc = h->tree.create(pts, n, d, ld, interpolation_order, kernel_type, base_range, total_sill, adaptive_tree != 0, sparse != 0,
+                                extents, params, flags);
+        if (rc == BBFMM_OK && devices.size() > 1) {
+            h->group.reset(new bbfmm::DeviceGroup());
+            const bbfmm::GroupCreateArgs a{pts, n, d, ld, interpolation_order, kernel_type, base_range, total_sill, adaptive_tree != 0,
+                                           sparse != 0, extents, params, flags};
+            rc = h->group->init(&h->tree, a, devices);
+            if (rc != BBFMM_OK) {
+                h->err = h->group->last_error();
+                h->group.reset();
+            }
+        }
+        if (cur >= 0) (void)hipSetDevice(cur); // the caller's current device is not the library's to change
         return rc;
     } catch (const std::exception &e) {
-        if (h) {
-            h->err = std::string("exception: ") + e.what();
-            *out = h;
-        }
+        if (cur >= 0) (void)hipSetDevice(cur);
+        if (h) h->err = std::string("exception: ") + e.what();
         return BBFMM_BAD_ARGUMENT;
     } catch (...) {
-        delete h;
+        if (cur >= 0) (void)hipSetDevice(cur);
+        if (h) h->err = "unknown exception";
         return BBFMM_BAD_ARGUMENT;
     }
 }
 
-void bbfmm_destroy(bbfmm_handle *h) { delete h; }
+int bbfmm_create(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t interpolation_order,
+                 int32_t kernel_type, double base_range, double total_sill, int32_t adaptive_tree, int32_t sparse,
+                 const double *extents, const bbfmm_params *params, uint32_t flags, bbfmm_handle **out) {
+    // FERREUS_BBFMM_DEVICES: the device list of every handle this process creates through the reference's constructor,
+    // which has no argument for it ("0,1,2,3", "all", or "0,0" for logical parts on one device).  Host-only handles
+    // (structure tests) ignore it.
+    std::vector<int> devices;
+    const char *env = std::getenv("FERREUS_BBFMM_DEVICES");
+    if (env && *env && !(flags & BBFMM_FLAG_HOST_ONLY)) {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess) ndev = 0;
+        std::string perr;
+        if (!bbfmm::parse_device_list(env, ndev, &devices, &perr)) {
+            if (!out) return BBFMM_BAD_ARGUMENT;
+            bbfmm_handle *h = new (std::nothrow) bbfmm_handle();
+            if (h) h->err = "FERREUS_BBFMM_DEVICES: " + perr;
+            *out = h;
+            return BBFMM_BAD_ARGUMENT;
+        }
+    }
+    return create_impl(pts, n, d, ld, interpolation_order, kernel_type, base_range, total_sill, adaptive_tree, sparse, extents, params, flags,
+                       devices, out);
+}
+
+int bbfmm_create_on_devices(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t interpolation_order, int32_t kernel_type,
+                            double base_range, double total_sill, int32_t adaptive_tree, int32_t sparse, const double *extents,
+                            const bbfmm_params *params, uint32_t flags, const int32_t *devices, int32_t n_devices, bbfmm_handle **out) {
+    if (!out) return BBFMM_BAD_ARGUMENT;
+    *out = nullptr;
+    if (!devices || n_devices < 1) return BBFMM_BAD_ARGUMENT;
+    return create_impl(pts, n, d, ld, interpolation_order, kernel_type, base_range, total_sill, adaptive_tree, sparse, extents, params, flags,
+                       std::vector<int>(devices, devices + n_devices), out);
+}
+
+int32_t bbfmm_device_count(const bbfmm_handle *h) { return !h ? -1 : (h->group ? h->group->n_parts() : 1); }
+int32_t bbfmm_part_device(const bbfmm_handle *h, int32_t part) {
+    if (!h || part < 0) return -1;
+    if (h->group) return part < h->group->n_parts() ? h->group->part_device(part) : -1;
+    return part == 0 ? h->tree.device() : -1;
+}
+int bbfmm_group_bounds(const bbfmm_handle *h, int64_t *bounds_out) {
+    if (!h || !h->group || !bounds_out) return BBFMM_BAD_ARGUMENT;
+    const std::vector<int64_t> &b = h->group->bounds();
+    std::copy(b.begin(), b.end(), bounds_out);
+    return BBFMM_OK;
+}
+int bbfmm_get_part_phase_ms(bbfmm_handle *h, int32_t part, double *ms_out, int64_t *count_out) {
+    if (!h || !ms_out) return BBFMM_BAD_ARGUMENT;
+    if (h->group) return h->group->part_phase_ms(part, ms_out, count_out);
+    return part == 0 ? bbfmm_get_phase_ms(h, ms_out, count_out) : BBFMM_BAD_ARGUMENT;
+}
+
+void bbfmm_destroy(bbfmm_handle *h) {
+    if (!h) return;
+    h->group.reset(); // (its parts end before the primary they lean on)
+    delete h;
+}
 
 const char *bbfmm_last_error(const bbfmm_handle *h) {
     if (!h) return "null handle";
@@ -81,38 +184,68 @@ const char *bbfmm_last_error(const bbfmm_handle *h) {
 }
 
 int bbfmm_set_weights(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw) {
-    GUARD(h) return h->tree.set_weights(w, rows, k, ldw);
+    GUARD(h)
+    if (h->group) return group_rc(h, h->group->set_weights(w, rows, k, ldw));
+    return h->tree.set_weights(w, rows, k, ldw);
     END_GUARD(h)
 }
 
 int bbfmm_set_local_coefficients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw) {
-    GUARD(h) return h->tree.set_local_coefficients(w, rows, k, ldw);
+    GUARD(h)
+    if (h->group) { // the stored expansions live on the primary: it completes its multipoles first
+        const int rc = group_rc(h, h->group->prepare_primary(h->group->weights_match_staged(w, rows, k, ldw)));
+        if (rc != BBFMM_OK) return rc;
+    }
+    return h->tree.set_local_coefficients(w, rows, k, ldw);
     END_GUARD(h)
 }
 
 int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw, const double *x, int64_t m,
                    int64_t ldx, double *out, int64_t ldo, int64_t *bad_point_index) {
-    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, false, bad_point_index);
+    GUARD(h)
+    if (h->group) { // targets = sources with the weights of set_weights: partitioned over the group; anything else: the primary
+        bool handled = false;
+        int rc = group_rc(h, h->group->evaluate_at_sources(w, rows, k, ldw, x, m, ldx, out, ldo, &handled));
+        if (rc != BBFMM_OK || handled) return rc;
+        rc = group_rc(h, h->group->prepare_primary(h->group->weights_match_staged(w, rows, k, ldw)));
+        if (rc != BBFMM_OK) return rc;
+    }
+    return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, false, bad_point_index);
     END_GUARD(h)
 }
 
 int bbfmm_evaluate_with_gradients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
                                   const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo, double *grad,
                                   int64_t ldg, int64_t *bad_point_index) {
-    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, false, bad_point_index);
+    GUARD(h)
+    if (h->group) {
+        const int rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
+        if (rc != BBFMM_OK) return rc;
+    }
+    return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, false, bad_point_index);
     END_GUARD(h)
 }
 
 int bbfmm_evaluate_leaves(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw, const double *x,
                           int64_t m, int64_t ldx, double *out, int64_t ldo, int64_t *bad_point_index) {
-    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, true, bad_point_index);
+    GUARD(h)
+    if (h->group) {
+        const int rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
+        if (rc != BBFMM_OK) return rc;
+    }
+    return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, true, bad_point_index);
     END_GUARD(h)
 }
 
 int bbfmm_evaluate_leaves_with_gradients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw,
                                          const double *x, int64_t m, int64_t ldx, double *out, int64_t ldo,
                                          double *grad, int64_t ldg, int64_t *bad_point_index) {
-    GUARD(h) return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, true, bad_point_index);
+    GUARD(h)
+    if (h->group) {
+        const int rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
+        if (rc != BBFMM_OK) return rc;
+    }
+    return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, true, bad_point_index);
     END_GUARD(h)
 }
 
@@ -130,6 +263,11 @@ int bbfmm_fast_matrix_vector_product(bbfmm_handle *h, const double *w, int64_t r
                                      const int64_t *target_indices, int64_t n_target_indices, const double *poly,
                                      int64_t ldp, double nugget, double *result) {
     GUARD(h)
+    if (h->group) {
+        if (!target_indices || h->tree.is_identity_subset(target_indices, n_target_indices))
+            return group_rc(h, h->group->fast_matrix_vector_product(w, rows, basis_size, poly, ldp, nugget, result));
+        h->group->primary_state_changed(); // a row subset: the primary alone (whole upward pass, cached subset plan)
+    }
     return h->tree.fast_matrix_vector_product(w, rows, basis_size, target_indices, n_target_indices, poly, ldp, nugget,
                                               result);
     END_GUARD(h)
@@ -142,7 +280,9 @@ int bbfmm_prepare_target_subset(bbfmm_handle *h, const int64_t *target_indices, 
 
 int bbfmm_matvec_device(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_out, int64_t ldo,
                         int32_t sync) {
-    GUARD(h) return h->tree.matvec_device(d_w, ldw, k, d_out, ldo, sync != 0);
+    GUARD(h)
+    if (h->group) return group_rc(h, h->group->matvec_device(d_w, ldw, k, d_out, ldo, sync != 0));
+    return h->tree.matvec_device(d_w, ldw, k, d_out, ldo, sync != 0);
     END_GUARD(h)
 }
 
@@ -163,12 +303,22 @@ int bbfmm_target_subset_create(bbfmm_handle *h, const int64_t *target_indices, i
 }
 
 int bbfmm_matvec_subset_device(bbfmm_handle *h, int32_t subset_id, const double *d_w, double *d_y, int32_t sync) {
-    GUARD(h) return h->tree.matvec_subset_device(subset_id, d_w, d_y, sync != 0);
+    GUARD(h)
+    if (h->group) {
+        if (subset_id == -1) return group_rc(h, h->group->matvec_device(d_w, h->tree.tree().n_points, 1, d_y, h->tree.tree().n_points, sync != 0));
+        h->group->primary_state_changed(); // a registered row subset: the primary alone
+    }
+    return h->tree.matvec_subset_device(subset_id, d_w, d_y, sync != 0);
     END_GUARD(h)
 }
 
 int bbfmm_set_partition(bbfmm_handle *h, int32_t rank, int32_t world) {
-    GUARD(h) return h->tree.set_partition(rank, world);
+    GUARD(h)
+    if (h->group) {
+        h->err = "the handle spans a device group: its partition is the group's";
+        return BBFMM_BAD_ARGUMENT;
+    }
+    return h->tree.set_partition(rank, world);
     END_GUARD(h)
 }
 
@@ -192,7 +342,12 @@ int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out) {
 int64_t bbfmm_partition_coarse_count(const bbfmm_handle *h) { return h ? h->tree.partition_coarse_count() : -1; }
 
 int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse, void *comm_stream) {
-    GUARD(h) return h->tree.matvec_partition_upward(d_w, ldw, k, d_coarse, static_cast<hipStream_t>(comm_stream));
+    GUARD(h)
+    if (h->group) {
+        h->err = "the handle spans a device group: the exchange is the library's";
+        return BBFMM_BAD_ARGUMENT;
+    }
+    return h->tree.matvec_partition_upward(d_w, ldw, k, d_coarse, static_cast<hipStream_t>(comm_stream));
     END_GUARD(h)
 }
 
@@ -210,16 +365,31 @@ int bbfmm_partition_bounds(const bbfmm_handle *h, int32_t world, int64_t *bounds
     return BBFMM_OK;
 }
 int bbfmm_matvec_partition_finish_sorted(bbfmm_handle *h, const double *d_coarse, double *d_seg, int64_t ld, void *comm_stream) {
-    GUARD(h) return h->tree.matvec_partition_finish_sorted(d_coarse, d_seg, ld, static_cast<hipStream_t>(comm_stream));
+    GUARD(h)
+    if (h->group) {
+        h->err = "the handle spans a device group: the exchange is the library's";
+        return BBFMM_BAD_ARGUMENT;
+    }
+    return h->tree.matvec_partition_finish_sorted(d_coarse, d_seg, ld, static_cast<hipStream_t>(comm_stream));
     END_GUARD(h)
 }
 int bbfmm_partition_scatter(bbfmm_handle *h, const double *d_all, int32_t first_part, int32_t n_parts, int64_t m_max, int32_t k,
                             double *d_out, int64_t ldo) {
-    GUARD(h) return h->tree.partition_scatter(d_all, first_part, n_parts, m_max, k, d_out, ldo);
+    GUARD(h)
+    if (h->group) {
+        h->err = "the handle spans a device group: the exchange is the library's";
+        return BBFMM_BAD_ARGUMENT;
+    }
+    return h->tree.partition_scatter(d_all, first_part, n_parts, m_max, k, d_out, ldo);
     END_GUARD(h)
 }
 int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync, void *comm_stream) {
-    GUARD(h) return h->tree.matvec_partition_finish(d_coarse, d_out, ldo, sync != 0, static_cast<hipStream_t>(comm_stream));
+    GUARD(h)
+    if (h->group) {
+        h->err = "the handle spans a device group: the exchange is the library's";
+        return BBFMM_BAD_ARGUMENT;
+    }
+    return h->tree.matvec_partition_finish(d_coarse, d_out, ldo, sync != 0, static_cast<hipStream_t>(comm_stream));
     END_GUARD(h)
 }
 
@@ -248,7 +418,11 @@ int bbfmm_debug_rows_of_sources(bbfmm_handle *h, const double *x, int64_t m, int
         return 0;
     }
 }
-int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h) { return h ? h->tree.last_evaluate_path() : 0; }
+int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h) {
+    if (!h) return 0;
+    if (h->group && h->group->last_path()) return 1;
+    return h->tree.last_evaluate_path();
+}
 int bbfmm_tree_built_on_device(const bbfmm_handle *h) { return (h && h->tree.tree_built_on_device()) ? 1 : 0; }
 
 int bbfmm_get_cells(const bbfmm_handle *h, uint64_t *keys, uint8_t *is_leaf) {
@@ -355,7 +529,8 @@ int bbfmm_points_to_leaves(const bbfmm_handle *h, const double *x, int64_t m, in
 
 int bbfmm_set_profiling(bbfmm_handle *h, int32_t enable) {
     if (!h) return BBFMM_BAD_ARGUMENT;
-    h->tree.set_profiling(enable != 0);
+    if (h->group) h->group->set_profiling(enable != 0);
+    else h->tree.set_profiling(enable != 0);
     return BBFMM_OK;
 }
 
@@ -369,7 +544,8 @@ int bbfmm_get_phase_ms(bbfmm_handle *h, double *ms_out, int64_t *count_out) {
 
 int bbfmm_reset_phase_ms(bbfmm_handle *h) {
     if (!h) return BBFMM_BAD_ARGUMENT;
-    h->tree.reset_phase_ms();
+    if (h->group) h->group->reset_phase_ms();
+    else h->tree.reset_phase_ms();
     return BBFMM_OK;
 }
 

@@ -99,6 +99,20 @@ void launch_scatter_parts(const double *all, const ScatterParts &parts, int64_t 
     hipLaunchKernelGGL(scatter_parts_kernel, dim3(grid_for(n, 256), K), dim3(256), 0, s, all, parts, m_max, K, order, out, ldo);
 }
 
+// out[i] = slots[0][i] + slots[1][i] + ... in that order (the coarse multipoles of a device group: every device adds the
+// parts' partial sums in the same fixed order, so all of them hold the same bits)
+__global__ void sum_slots_kernel(const double *__restrict__ slots, int n_slots, int64_t len, double *__restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
+        double acc = slots[i];
+        for (int g = 1; g < n_slots; ++g) acc += slots[(int64_t)g * len + i];
+        out[i] = acc;
+    }
+}
+void launch_sum_slots(const double *slots, int n_slots, int64_t len, double *out, hipStream_t s) {
+    if (len <= 0 || n_slots < 1) return;
+    hipLaunchKernelGGL(sum_slots_kernel, dim3(grid_for(len, 256)), dim3(256), 0, s, slots, n_slots, len, out);
+}
+
 void launch_scatter_output(const double *out_sorted, int64_t n, int K, const int32_t *perm, double *out, int64_t ldo,
                            int accumulate, hipStream_t s) {
     if (n == 0) return;

@@ -81,6 +81,8 @@ struct ScatterParts {
 };
 void launch_scatter_parts(const double *all, const ScatterParts &parts, int64_t m_max, int K, const int32_t *order, double *out,
                           int64_t ldo, hipStream_t s);
+// out[i] = sum over the slots, in slot order (slots[g * len + i]): the in-process exchange of a device group
+void launch_sum_slots(const double *slots, int n_slots, int64_t len, double *out, hipStream_t s);
 void launch_scatter_output(const double *out_sorted, int64_t n, int K, const int32_t *perm,
                            double *out, int64_t ldo, int accumulate, hipStream_t s);
 void launch_gather_rows(const double *src, int64_t ld_src, int ncols, const int32_t *idx, int64_t n,

@@ -626,7 +626,7 @@ int FmmTree::ensure_pinned(size_t n) {
     h_pin_ = nullptr;
     h_pin_n_ = 0;
     pin_w_k_ = 0;
-    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_pin_), n * sizeof(double), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void **>(&h_pin_), n * sizeof(double), hipHostMallocPortable)); // (every device of a group reads it)
     h_pin_n_ = n;
     return BBFMM_OK;
 }
@@ -651,9 +651,16 @@ int FmmTree::stage_weights_to_device(const double *w, int64_t n, int k, int64_t 
         parallel_for_chunks(n, kHostPiece, [&](int64_t b, int64_t e) {
             bind_device();
             std::memcpy(pin_in + off + b, col + b, static_cast<size_t>(e - b) * sizeof(double));
-            const hipError_t r = hipMemcpyAsync(dst + off + b, pin_in + off + b, static_cast<size_t>(e - b) * sizeof(double),
-                                                hipMemcpyHostToDevice, stream_);
+            hipError_t r = hipMemcpyAsync(dst + off + b, pin_in + off + b, static_cast<size_t>(e - b) * sizeof(double),
+                                          hipMemcpyHostToDevice, stream_);
             if (r != hipSuccess) err.store(static_cast<int>(r));
+            for (const WeightMirror &mr : mirrors_) { // the other devices of a group: the same piece over their own links
+                (void)hipSetDevice(mr.device);
+                r = hipMemcpyAsync(mr.dst + off + b, pin_in + off + b, static_cast<size_t>(e - b) * sizeof(double), hipMemcpyHostToDevice,
+                                   mr.stream);
+                if (r != hipSuccess) err.store(static_cast<int>(r));
+            }
+            if (!mirrors_.empty()) bind_device();
         });
     }
     if (err.load() != 0) return hip_fail(static_cast<hipError_t>(err.load()), "hipMemcpyAsync(weights)");
@@ -697,8 +704,6 @@ template <class F> int FmmTree::download_pieces(const double *d_src, int64_t tot
     return BBFMM_OK;
 }
 
-// Host buffers above this size (weights in + values out) are not mirrored in pinned memory: pageable copies instead.
-static constexpr size_t kMaxPinnedDoubles = size_t(1) << 28; // 2 GiB
 
 // Weights of set_weights / evaluate: rows < N of k columns -> d_w_sorted_.  The pinned staging buffer keeps the last
 // staged weights; a caller that hands the same values again (rbf.rs:1357-1364: set_weights(w), evaluate(w, ..)) is
@@ -1120,7 +1125,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     // way the solver makes its own (sparse, extents from the data: rbf.rs:456-467) -- an evaluator's tree (explicit
     // extents, not sparse: rbf.rs:677-690) never builds the table -- and not for batches below N / 2048 rows.
     last_eval_rows_of_sources_ = false;
-    if (sources_fast && solver_tree_ && !m2l_queued && !leaves_only && !with_grads && !have_part_ && !locals_requested_ && k == 1 && w &&
+    if (sources_fast && solver_tree_ && !m2l_queued && !leaves_only && !with_grads && (!have_part_ || group_primary_) && !locals_requested_ && k == 1 && w &&
         m < tree_.n_points && m >= std::max<int64_t>(1024, tree_.n_points / 2048) && m <= tree_.n_points / 2) {
         std::vector<int64_t> rows_of;
         if (targets_are_rows_of_sources(x, m, ldx, &rows_of)) {
@@ -1351,6 +1356,44 @@ int FmmTree::matvec_partition_finish_sorted(const double *d_coarse, double *d_se
                                 static_cast<size_t>(ts.m) * sizeof(double), static_cast<size_t>(k), hipMemcpyDeviceToDevice, stream_));
     phase_end(kPhScatter);
     HIPCHK(hipGetLastError());
+    return BBFMM_OK;
+}
+
+int FmmTree::matvec_partition_finish_host(const double *d_coarse, double *h_seg, int64_t ld, hipStream_t comm_stream) {
+    if (!h_seg || ld < part_targets_.m) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
+    int k = 0;
+    CHK(partition_finish_core(d_coarse, comm_stream, &k));
+    const TargetSet &ts = part_targets_;
+    phase_begin();
+    if (ts.m > 0)
+        HIPCHK(hipMemcpy2DAsync(h_seg, static_cast<size_t>(ld) * sizeof(double), ts.out.p, static_cast<size_t>(ts.m) * sizeof(double),
+                                static_cast<size_t>(ts.m) * sizeof(double), static_cast<size_t>(k), hipMemcpyDeviceToHost, stream_));
+    phase_end(kPhScatter);
+    HIPCHK(hipGetLastError());
+    return BBFMM_OK;
+}
+
+int FmmTree::ensure_w_in(int k) {
+    const size_t need = static_cast<size_t>(k) * tree_.n_points;
+    if (need > d_w_in_.n) {
+        dfree(&d_w_in_);
+        CHK(dalloc(&d_w_in_, need));
+    }
+    return BBFMM_OK;
+}
+
+int FmmTree::complete_upward_from_staged(int k) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    const int64_t N = tree_.n_points;
+    if (k < 1 || static_cast<size_t>(k) * N > d_w_in_.n) return fail(BBFMM_BAD_ARGUMENT, "no staged weights");
+    part_pending_k_ = 0;
+    CHK(ensure_rhs_capacity(k));
+    phase_begin();
+    launch_gather_weights(d_w_in_.p, N, k, d_order_.p, N, d_w_sorted_.p, stream_);
+    phase_end(kPhGather);
+    nrhs_ = k;
+    have_locals_ = locals_requested_ = false;
+    CHK(upward(k));
     return BBFMM_OK;
 }
 

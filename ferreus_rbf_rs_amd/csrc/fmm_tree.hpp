@@ -133,7 +133,10 @@ struct SubsetPlan { // cached target subset of bbfmm_fast_matrix_vector_product 
     DownwardPlan dp;
 };
 
+class DeviceGroup;
+
 class FmmTree {
+    friend class DeviceGroup; // one handle over several devices (device_group.hpp): drives the parts' passes directly
   public:
     FmmTree() = default;
     ~FmmTree();
@@ -169,6 +172,9 @@ class FmmTree {
     // -- d_all[part][k][m_max] -- to their rows of d_out in one pass over the tree's permutation
     int matvec_partition_finish_sorted(const double *d_coarse, double *d_seg, int64_t ld, hipStream_t comm_stream);
     int partition_scatter(const double *d_all, int first_part, int n_parts, int64_t m_max, int k, double *d_out, int64_t ldo);
+    // the same for a device group: the owned potentials go straight to (pinned) host memory, k rows of ld doubles, as one
+    // asynchronous 2-D copy behind the passes on the handle's stream
+    int matvec_partition_finish_host(const double *d_coarse, double *h_seg, int64_t ld, hipStream_t comm_stream);
     const std::vector<int64_t> &partition_bounds() const { return part_bounds_; } // world + 1 offsets into the sorted points
     int register_subset(const int64_t *idx, int64_t n_idx, int *id_out);
     int matvec_subset_device(int id, const double *d_w, double *d_y, bool sync);
@@ -394,6 +400,18 @@ class FmmTree {
     double *h_pin_ = nullptr; // pinned staging for the host-buffer matvec (N doubles up, N down)
     size_t h_pin_n_ = 0;
     int ensure_pinned(size_t n);
+    // A device group stages the caller's weights once (in the primary's pinned buffer) and sends every piece to the other
+    // devices of the group as well: (device, stream, destination of k x N doubles) per mirror.
+    struct WeightMirror {
+        int device;
+        hipStream_t stream;
+        double *dst;
+    };
+    std::vector<WeightMirror> mirrors_;
+    int ensure_w_in(int k); // d_w_in_ holds k x N doubles
+    // the whole upward pass from the weights staged in d_w_in_ (a device group's primary before a product the group does
+    // not partition: arbitrary targets, target subsets, stored local expansions)
+    int complete_upward_from_staged(int k);
     int stage_weights_to_device(const double *w, int64_t n, int k, int64_t ldw); // host rows -> d_w_in_, staging and PCIe overlapped
     template <class F> int download_pieces(const double *d_src, int64_t total, double *pin_out, F &&consume);
     // h_pin_[0, pin_w_k_ * N) holds exactly the host weights d_w_sorted_ was gathered from (0: no such copy)
@@ -402,12 +420,15 @@ class FmmTree {
     bool weights_match_staged(const double *w, int k, int64_t ldw) const;
     bool last_eval_at_sources_ = false;
     bool last_eval_rows_of_sources_ = false;
+    bool group_primary_ = false; // part 0 of a device group: its own partition does not stand in the way of the cached-subset path
     bool solver_tree_ = false; // created as the solver creates its tree (rbf.rs:456-467: sparse, extents from the data)
     // open-addressing table over the source points keyed by the bits of their coordinates (value: a row with those
     // coordinates, -1: empty); built by the first evaluate() that could be a matvec_partial of the unchanged caller
     std::vector<int32_t, DefaultInitAllocator<int32_t>> src_row_table_;
     uint64_t src_row_mask_ = 0;
     uint64_t point_hash(const double *x, int64_t ld, int64_t i) const;
+    // Host buffers above this size (weights in + values out) are not mirrored in pinned memory: pageable copies instead.
+    static constexpr size_t kMaxPinnedDoubles = size_t(1) << 28; // 2 GiB
     static constexpr int64_t kHostPiece = int64_t(1) << 18;  // rows per piece of the host <-> device pipelines (2 MB)
     std::vector<hipEvent_t> ev_out_;                         // per piece of the pipelined copy back
     TargetSet src_targets_;  // targets = sources (the matvec)

@@ -141,13 +141,18 @@ class FmmTree:
     def __init__(self, source_points, interpolation_order: int, kernel_params: KernelParams,
                  adaptive_tree: bool, sparse: bool, *, extents=None,
                  params: Optional[FmmParams] = None, host_only: bool = False,
-                 m2l_shared_basis: bool = False, direct_small_w_leaves: bool = False, deterministic: bool = False):
+                 m2l_shared_basis: bool = False, direct_small_w_leaves: bool = False, deterministic: bool = False,
+                 devices=None):
         """m2l_shared_basis: BBFMM_FLAG_M2L_SHARED_BASIS, an extension beyond the reference (off by default):
         the M2L stages run in one orthonormal basis per level, cut at params.epsilon.
         direct_small_w_leaves: BBFMM_FLAG_DIRECT_SMALL_W_LEAVES, likewise an extension: W-list leaves with no
         more points than nodes are summed directly instead of through M2P / P2L.
         deterministic: BBFMM_FLAG_DETERMINISTIC -- fixed summation order everywhere (no f64 atomics), bitwise
-        reproducible results from run to run like the reference's."""
+        reproducible results from run to run like the reference's.
+        devices: HIP device ids of a handle that spans several devices of this process (bbfmm_create_on_devices): the
+        matvec entry points run partitioned over them, nothing else changes for the caller.  An id may repeat (logical
+        parts on one device).  None: the current device -- or the list in FERREUS_BBFMM_DEVICES, which is how the
+        unchanged Rust caller is switched."""
         lib = L.load()
         pts = _as_f64_2d(source_points, "source_points")
         n, d = pts.shape
@@ -157,15 +162,20 @@ class FmmTree:
             d = len(ext) // 2                       # bbfmm.rs:291
         cpar = params._c() if params is not None else None
         h = ctypes.c_void_p()
-        rc = lib.bbfmm_create(pts.ctypes.data, n, d, n, int(interpolation_order),
-                              int(kernel_params.kernel_type), kernel_params.base_range,
-                              kernel_params.total_sill, int(bool(adaptive_tree)), int(bool(sparse)),
-                              ext.ctypes.data if ext is not None else None,
-                              ctypes.byref(cpar) if cpar is not None else None,
-                              (L.FLAG_HOST_ONLY if host_only else 0) |
-                              (L.FLAG_M2L_SHARED_BASIS if m2l_shared_basis else 0) |
-                              (L.FLAG_DIRECT_SMALL_W_LEAVES if direct_small_w_leaves else 0) |
-                              (L.FLAG_DETERMINISTIC if deterministic else 0), ctypes.byref(h))
+        flags = ((L.FLAG_HOST_ONLY if host_only else 0) |
+                 (L.FLAG_M2L_SHARED_BASIS if m2l_shared_basis else 0) |
+                 (L.FLAG_DIRECT_SMALL_W_LEAVES if direct_small_w_leaves else 0) |
+                 (L.FLAG_DETERMINISTIC if deterministic else 0))
+        args = (pts.ctypes.data, n, d, n, int(interpolation_order),
+                int(kernel_params.kernel_type), kernel_params.base_range,
+                kernel_params.total_sill, int(bool(adaptive_tree)), int(bool(sparse)),
+                ext.ctypes.data if ext is not None else None,
+                ctypes.byref(cpar) if cpar is not None else None, flags)
+        if devices is None:
+            rc = lib.bbfmm_create(*args, ctypes.byref(h))
+        else:
+            dev = np.ascontiguousarray(np.asarray(devices, dtype=np.int32).reshape(-1))
+            rc = lib.bbfmm_create_on_devices(*args, dev.ctypes.data, len(dev), ctypes.byref(h))
         self._h = h
         self._lib = lib
         if rc != L.OK:
@@ -298,6 +308,30 @@ class FmmTree:
 
     def stream(self) -> int:
         return int(self._lib.bbfmm_stream(self._h) or 0)
+
+    # -- one handle over several devices (bbfmm_create_on_devices / FERREUS_BBFMM_DEVICES)
+    def device_count(self) -> int:
+        """Parts of the handle (1: an ordinary handle on one device)."""
+        return int(self._lib.bbfmm_device_count(self._h))
+
+    def part_device(self, part: int = 0) -> int:
+        """HIP device of a part (part 0: the handle's own device, where device-resident vectors live)."""
+        return int(self._lib.bbfmm_part_device(self._h, int(part)))
+
+    def device(self) -> int:
+        return self.part_device(0)
+
+    def group_bounds(self) -> np.ndarray:
+        """parts + 1 offsets into the tree's sorted points: part g owns [bounds[g], bounds[g + 1])."""
+        b = np.zeros(self.device_count() + 1, dtype=np.int64)
+        self._raise(self._lib.bbfmm_group_bounds(self._h, b.ctypes.data))
+        return b
+
+    def part_phase_ms(self, part: int):
+        ms = np.zeros(L.N_PHASES)
+        cnt = np.zeros(L.N_PHASES, dtype=np.int64)
+        self._raise(self._lib.bbfmm_get_part_phase_ms(self._h, int(part), ms.ctypes.data, cnt.ctypes.data))
+        return dict(zip(L.PHASE_NAMES, ms.tolist())), dict(zip(L.PHASE_NAMES, cnt.tolist()))
 
     def set_partition(self, rank: int, world: int):
         self._raise(self._lib.bbfmm_set_partition(self._h, rank, world))

@@ -124,6 +124,33 @@ int bbfmm_create(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t in
                  int32_t sparse, const double *extents, const bbfmm_params *params,
                  uint32_t flags, bbfmm_handle **out);
 
+/*
+ * One handle, several devices, ONE process (round 6).  The reference keeps a single FmmTree behind a Mutex
+ * (ferreus_rbf/src/rbf.rs:85-133) and its FGMRES is not an SPMD program, so the GPUs of a node are reached behind the
+ * unchanged method set of ferreus_rbf_utils::FmmTree (utils.rs:392-449): a handle created on a device list owns one
+ * part per list entry -- the tree on that device and one subtree partition of the matvec -- and
+ * bbfmm_set_weights + bbfmm_evaluate at the sources, bbfmm_fast_matrix_vector_product (all rows) and
+ * bbfmm_matvec_device run partitioned over the parts: weights to every device over its own link, own-subtree upward
+ * pass, the partial coarse multipoles copied to a slot on every device (peer copies beside the near field) and added in
+ * part order, restricted downward + leaf pass, the owned blocks of the potentials straight back to the host (or, for
+ * device callers, to the first device).  No caller-supplied collective, no second process.  Everything else (arbitrary
+ * targets, gradients, row subsets, stored local expansions) is served by the first device alone, with unchanged results.
+ *   devices    n_devices HIP device ids; the first one holds the handle's own tree (introspection, bbfmm_stream,
+ *              device-resident vectors).  An id may repeat: logical parts on one device -- the one-GPU rehearsal of the
+ *              N-device path (peer copies become device copies).  One entry: a plain handle on that device.
+ * bbfmm_create itself reads FERREUS_BBFMM_DEVICES ("0,1,2,3", "all", "0,0,0"; unset or empty: the current device, no
+ * group) -- the reference's constructor has no argument for a device list, so the unchanged caller is switched there.
+ * The calling thread's current device is restored before returning.
+ */
+int bbfmm_create_on_devices(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t interpolation_order,
+                            int32_t kernel_type, double base_range, double total_sill, int32_t adaptive_tree,
+                            int32_t sparse, const double *extents, const bbfmm_params *params, uint32_t flags,
+                            const int32_t *devices, int32_t n_devices, bbfmm_handle **out);
+int32_t bbfmm_device_count(const bbfmm_handle *h);              /* parts of the handle (1: no group) */
+int32_t bbfmm_part_device(const bbfmm_handle *h, int32_t part); /* HIP device of a part; part 0 = the handle's own device */
+int bbfmm_group_bounds(const bbfmm_handle *h, int64_t *bounds_out); /* parts + 1 offsets into the sorted points (group handles) */
+int bbfmm_get_part_phase_ms(bbfmm_handle *h, int32_t part, double *ms_out, int64_t *count_out); /* bbfmm_get_phase_ms of one part */
+
 void bbfmm_destroy(bbfmm_handle *h);
 
 /* Message of the last failure on this handle ("" if none). Owned by the handle. */

@@ -1,0 +1,180 @@
+"""One handle, several devices, one process (bbfmm_create_on_devices / FERREUS_BBFMM_DEVICES): the drop-in's multi-GPU
+path.  The reference keeps ONE FmmTree behind a Mutex and calls `set_weights(w)` + `evaluate(w, sources)`
+(ferreus_rbf/src/rbf.rs:85-133, 1357-1364; ferreus_rbf_utils/src/utils.rs:392-449), so the partition lives behind those
+unchanged methods.  A one-GPU box rehearses it with G logical parts on device 0 (peer copies become device copies; the
+upward plans, the slot exchange, the restricted downward passes, the per-part copies back and the host's inverse
+permutation are the N-device code).  Bars: the group = the one-part handle to 1e-12, = the oracle at 1e-11."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import ferreus_rbf_rs_amd as F
+from conftest import clustered_points, inject_product_operators, relerr
+from oracle import bbfmm_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-11
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def case():
+    rng = np.random.default_rng(606)
+    pts = np.vstack([rng.random((110000, 3)), clustered_points(rng, 12000, 3)])   # mixed levels: W / X lists live
+    kp = F.KernelParams(F.FmmKernelType.LinearRbf)
+    one = F.FmmTree(pts, 7, kp, True, True)
+    ref = O.FmmTree(pts, 7, 0, True, True)
+    inject_product_operators(one, ref)
+    assert one.stats().n_w > 0 and one.device_count() == 1
+    return rng, pts, kp, one, ref
+
+
+@pytest.mark.parametrize("parts", [2, 3, 8])
+def test_unchanged_caller_on_a_group_equals_one_part_and_the_oracle(case, parts):
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    g = F.FmmTree(pts, 7, kp, True, True, devices=[0] * parts)
+    assert g.device_count() == parts and [g.part_device(i) for i in range(parts)] == [0] * parts
+    b = g.group_bounds()
+    assert b[0] == 0 and b[-1] == n and np.all(np.diff(b) > 0)
+    w = np.asfortranarray(rng.standard_normal((n + 4, 1)))       # N + basis_size rows, as the solver's vectors (rbf.rs:1344)
+    g.set_weights(w)
+    y = g.evaluate(w, pts.copy())                                # select_mat_rows(source_points, all rows): a fresh copy
+    assert g.last_evaluate_at_sources() == 1
+    one.set_weights(w)
+    y1 = one.evaluate(w, pts)
+    assert relerr(y, y1) < 1e-12
+    ref.set_weights(w[:n])
+    assert relerr(y, ref.evaluate(w[:n], pts)) < TOL
+    # a second product on the same handle (other weights), then the patched entry point with nugget and polynomial tail
+    w2 = np.asfortranarray(rng.standard_normal((n + 4, 1)))
+    g.set_weights(w2)
+    one.set_weights(w2)
+    assert relerr(g.evaluate(w2, pts), one.evaluate(w2, pts)) < 1e-12
+    poly = np.asfortranarray(np.hstack([np.ones((n, 1)), pts]))
+    ym = g.fast_matrix_vector_product(w[:, 0].copy(), basis_size=4, polynomial_matrix=poly, nugget=0.25)
+    ym1 = one.fast_matrix_vector_product(w[:, 0].copy(), basis_size=4, polynomial_matrix=poly, nugget=0.25)
+    assert relerr(ym, ym1) < 1e-12 and np.all(ym[n:] == 0.0)
+    assert relerr(ym[:n], y1[:, 0] + 0.25 * w[:n, 0] + poly @ w[n:, 0]) < 1e-12
+
+
+def test_two_rhs_and_a_second_evaluate_behind_one_set_weights(case):
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0, 0])
+    w = np.asfortranarray(rng.standard_normal((n, 2)))
+    g.set_weights(w)
+    y = g.evaluate(w, pts)
+    assert g.last_evaluate_at_sources() == 1 and y.shape == (n, 2)
+    ref.set_weights(w)
+    assert relerr(y, ref.evaluate(w, pts)) < TOL
+    y2 = g.evaluate(w, pts)                                       # the upward pass is run again from the staged weights
+    assert g.last_evaluate_at_sources() == 1 and relerr(y2, y) < 1e-12
+    one.set_weights(w)
+    assert relerr(y, one.evaluate(w, pts)) < 1e-12
+
+
+def test_matvec_partial_row_sets_and_other_targets_are_served_by_the_first_device(case):
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0])
+    w = np.asfortranarray(rng.standard_normal((n, 1)))
+    # matvec_partial (rbf.rs:119-133), patched and unchanged caller
+    idx = np.sort(rng.choice(n, n // 7, replace=False))
+    yp = g.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx)
+    yp1 = one.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx)
+    assert relerr(yp, yp1) < 1e-12 and np.count_nonzero(yp) <= len(idx)
+    g.set_weights(w)
+    ys = g.evaluate(w, pts[idx])
+    assert g.last_evaluate_at_sources() in (0, 2)
+    one.set_weights(w)
+    assert relerr(ys, one.evaluate(w, pts[idx])) < 1e-12
+    assert relerr(ys[:, 0], yp[idx]) < 1e-12
+    # the group's own path still works afterwards
+    y = g.evaluate(w, pts)
+    assert g.last_evaluate_at_sources() == 1
+    y1 = one.evaluate(w, pts)
+    assert relerr(y, y1) < 1e-12
+    # arbitrary targets, gradients, and the reference's mixture (other weights in evaluate than in set_weights)
+    x = rng.random((5000, 3))
+    g.set_weights(w)
+    assert relerr(g.evaluate(w, x), one.evaluate(w, x)) < 1e-12
+    v, gr = g.evaluate_with_gradients(w, x)
+    v1, gr1 = one.evaluate_with_gradients(w, x)
+    assert relerr(v, v1) < 1e-12 and relerr(gr, gr1) < 1e-10
+    w2 = np.asfortranarray(rng.standard_normal((n, 1)))
+    g.set_weights(w)
+    one.set_weights(w)
+    ymix = g.evaluate(w2, pts)                                    # old multipoles, new near field (bbfmm.rs:444-507)
+    assert g.last_evaluate_at_sources() == 0
+    assert relerr(ymix, one.evaluate(w2, pts)) < 1e-12
+    # Leaves mode on a group handle
+    g.set_weights(w)
+    g.set_local_coefficients(w)
+    one.set_weights(w)
+    one.set_local_coefficients(w)
+    assert relerr(g.evaluate_leaves(w, x), one.evaluate_leaves(w, x)) < 1e-12
+    # and a partition of the caller's own is refused: the group owns it
+    with pytest.raises(ValueError, match="device group"):
+        g.set_partition(0, 2)
+
+
+def test_device_resident_vectors_on_a_group(case):
+    import torch
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0, 0, 0, 0])
+    for k in (1, 3):
+        w = torch.from_numpy(np.ascontiguousarray(rng.standard_normal((k, n)))).cuda()
+        out = torch.zeros((k, n), dtype=torch.float64, device="cuda")
+        out1 = torch.zeros_like(out)
+        torch.cuda.synchronize()
+        g.matvec_device(w.data_ptr(), n, k, out.data_ptr(), n, sync=True)
+        one.matvec_device(w.data_ptr(), n, k, out1.data_ptr(), n, sync=True)
+        assert relerr(out.cpu().numpy(), out1.cpu().numpy()) < 1e-12
+    # a host-buffer product right behind the device-resident one (the staged weights were replaced)
+    wh = np.asfortranarray(rng.standard_normal((n, 1)))
+    g.set_weights(wh)
+    one.set_weights(wh)
+    assert relerr(g.evaluate(wh, pts), one.evaluate(wh, pts)) < 1e-12
+
+
+def test_the_environment_switch_reaches_the_unchanged_constructor():
+    """FERREUS_BBFMM_DEVICES is read by bbfmm_create itself: what the Rust shim (and this binding without `devices`) calls."""
+    code = r"""
+import numpy as np, ferreus_rbf_rs_amd as F
+rng = np.random.default_rng(1)
+pts = rng.random((30000, 3)); w = rng.standard_normal((30000, 1))
+t = F.FmmTree(pts, 5, F.KernelParams(F.FmmKernelType.ThinPlateSplineRbf), True, True)
+assert t.device_count() == 3, t.device_count()
+t.set_weights(w); y = t.evaluate(w, pts)
+assert t.last_evaluate_at_sources() == 1
+import os; os.environ.pop("FERREUS_BBFMM_DEVICES")
+u = F.FmmTree(pts, 5, F.KernelParams(F.FmmKernelType.ThinPlateSplineRbf), True, True)
+assert u.device_count() == 1
+u.set_weights(w); y1 = u.evaluate(w, pts)
+print("REL", float(np.abs(y - y1).max() / np.abs(y1).max()))
+"""
+    env = dict(os.environ, FERREUS_BBFMM_DEVICES="0,0,0", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    rel = float(out.stdout.decode().split("REL")[1])
+    assert rel < 1e-12
+
+
+def test_deterministic_group_is_bitwise_reproducible(case):
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    w = np.asfortranarray(rng.standard_normal((n, 1)))
+    ys = []
+    for _ in range(2):
+        g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0, 0], deterministic=True)
+        g.set_weights(w)
+        ys.append(g.evaluate(w, pts))
+        del g
+    assert np.array_equal(ys[0], ys[1])
+    ref.set_weights(w)
+    assert relerr(ys[0], ref.evaluate(w, pts)) < TOL
