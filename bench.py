@@ -116,6 +116,13 @@ def parse():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "gloo"],
                     help="gloo: CPU-staged exchange; ranks may then share a GPU (LOCAL_RANK modulo the device "
                          "count) -- for exercising the N > 1 path on a one-GPU box, never a scaling number")
+    ap.add_argument("--inprocess", action="store_true",
+                    help="ONE process, one handle over --gpus devices (bbfmm_create_on_devices): the drop-in's own multi-GPU "
+                         "path, exchange inside the library (peer copies).  A labelled second entry; the default N > 1 path "
+                         "stays one process per GPU over RCCL so that the two can be compared")
+    ap.add_argument("--devices", default="",
+                    help="with --inprocess: explicit device list, e.g. 0,0,0,0 = four logical parts on device 0 (a functional "
+                         "rehearsal on a one-GPU box, never a scaling number); default 0..gpus-1")
     ap.add_argument("--detail-file", default=os.path.join(ROOT, "bench_detail.json"),
                     help="where the full record goes (the stdout line is the compact one)")
     return ap.parse_args()
@@ -712,6 +719,9 @@ def compact_line(detail: dict) -> dict:
     keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data")
     line = {k: _sig(detail[k], 7) for k in keep if k in detail}
+    for k in ("entry", "value_host_buffers", "ms_per_step_host_buffers", "part_sum_ms"):   # --inprocess; value_host_buffers on every N = 1 line
+        if detail.get(k) is not None:
+            line[k] = [_sig(v) for v in detail[k]] if isinstance(detail[k], list) else _sig(detail[k])
     cfg = detail.get("config", {})
     line["config"] = {k: cfg[k] for k in ("workload", "points", "kernel", "order", "nrhs", "parallelism") if k in cfg}
     roof = detail.get("roofline") or {}
@@ -804,6 +814,100 @@ def run_config3_solve(F, points=10_000_000, defaults_outer=4):
     return out
 
 
+def main_inprocess(args):
+    """`--inprocess`: one process, ONE handle over the devices (bbfmm_create_on_devices).  `value` is the
+    device-resident product (weights and result in the HBM of the first device, as the default line), `value_host_buffers`
+    the unchanged caller's sequence on host buffers (bbfmm_set_weights + bbfmm_evaluate at the sources, PCIe inclusive) --
+    the path a ferreus_rbf caller actually takes.  Phase times are per part (each on its own device's stream)."""
+    import ctypes
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    import ferreus_rbf_rs_amd as F
+    from ferreus_rbf_rs_amd import _lib as L
+    devices = [int(x) for x in args.devices.split(",")] if args.devices else list(range(args.gpus))
+    logical = len(set(devices)) < len(devices)
+    torch.cuda.set_device(devices[0])
+    dev = torch.device("cuda", devices[0])
+    N, K = args.points, args.nrhs
+    pts = np.random.default_rng(42).random((N, 3))
+    t0 = time.time()
+    tree = F.FmmTree(pts, args.order, F.KernelParams(F.KernelType[args.kernel], base_range=args.base_range,
+                                                     total_sill=args.total_sill), True, True, devices=devices)
+    t_build = time.time() - t0
+    G = tree.device_count()
+    stats = tree.stats()
+    w = torch.from_numpy(np.random.default_rng(43).random((K, N))).to(dev)
+    out = torch.zeros((K, N), dtype=torch.float64, device=dev)
+    stream = torch.cuda.ExternalStream(tree.stream(), device=dev)
+
+    def sync():
+        torch.cuda.synchronize()
+        stream.synchronize()
+
+    for _ in range(args.warmup):
+        tree.matvec_device(w.data_ptr(), N, K, out.data_ptr(), N, sync=False)
+    sync()
+    tree.set_profiling(True)
+    tree.phase_ms(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tree.matvec_device(w.data_ptr(), N, K, out.data_ptr(), N, sync=False)
+    sync()
+    elapsed = time.perf_counter() - t0
+    parts = []
+    for g in range(G):
+        ms, cnt = tree.part_phase_ms(g)
+        parts.append({k: ms[k] / args.steps for k in ms})
+    tree.set_profiling(False)
+    err = dense_rows_err(torch, dev, args.kernel, args.base_range, args.total_sill, pts, w, out)
+    # the unchanged caller on host buffers through the same handle
+    lib = L.load()
+    x = np.asfortranarray(pts)
+    wh = np.asfortranarray(w.cpu().numpy().T.copy())
+    yh = np.zeros((N, K), order="F")
+    bad = ctypes.c_int64(-1)
+
+    def unchanged():
+        rc = lib.bbfmm_set_weights(tree._h, wh.ctypes.data, N, K, N)
+        return rc or lib.bbfmm_evaluate(tree._h, wh.ctypes.data, N, K, N, x.ctypes.data, N, N, yh.ctypes.data, N, ctypes.byref(bad))
+
+    assert unchanged() == 0 and tree.last_evaluate_at_sources() == 1
+    ts = []
+    for _ in range(max(args.steps, 3)):
+        t0 = time.perf_counter()
+        unchanged()
+        ts.append(time.perf_counter() - t0)
+    host_ms = sorted(ts)[len(ts) // 2] * 1e3
+    host_vs_device = float(np.abs(yh.T - out.cpu().numpy()).max() / np.abs(yh).max())
+    sums = [sum(p.values()) for p in parts]
+    slow = int(np.argmax(sums))
+    per_launch = parts[slow]
+    dominant, roofline = roofline_of(stats, N, K, args.kernel, per_launch, G, None, None)
+    roofline["part"] = slow
+    line = {
+        "metric": "BBFMM matvecs/s", "value": args.steps / elapsed, "unit": "matvecs/s", "n_gpus": len(set(devices)),
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "entry": "inprocess (one process, one handle over the devices; not the default one-process-per-GPU line)",
+        "value_host_buffers": 1e3 / host_ms, "ms_per_step_host_buffers": host_ms,
+        "host_vs_device_resident_rel_diff": host_vs_device,
+        "config": {"workload": f"{N} uniform 3D points, {args.kernel}, order {args.order}, {K} rhs, adaptive sparse tree, "
+                               f"ACA eps=1e-{args.order}, set_weights + evaluate at the sources",
+                   "points": N, "kernel": args.kernel, "order": args.order, "nrhs": K,
+                   "parallelism": f"ONE process, device group {devices}: slot exchange of the coarse multipoles by peer copies, "
+                                  "owned blocks back to the first device (device-resident) / to the host (host buffers)"
+                                  + ("; LOGICAL parts on one device: a functional rehearsal, never a scaling number" if logical else "")},
+        "roofline": roofline, "dense_rows_rel_err": err, "dense_rows": 32,
+        "phase_ms_per_step_per_part": parts, "part_sum_ms": sums,
+        "tree": {"depth": stats.depth, "cells": stats.n_cells, "leaves": stats.n_leaves, "build_s_all_parts": t_build},
+        "group_bounds": [int(b) for b in tree.group_bounds()],
+        "source_hash": source_hash(),
+    }
+    write_outputs(line, real_stdout, args.detail_file)
+
+
 def write_outputs(detail, stdout_fd, path=None):
     """The full record to `bench_detail.json` beside this file (best effort: a read-only tree only loses the file) and to
     stderr; the compact line -- one line, under 4 KB -- to the real stdout."""
@@ -829,6 +933,10 @@ def write_outputs(detail, stdout_fd, path=None):
 
 def main():
     args = parse()
+    if args.inprocess:
+        if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+            sys.exit("--inprocess is one process: start it without a launcher")
+        return main_inprocess(args)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args))        # nothing has touched the GPU in this process
 

@@ -2,6 +2,7 @@
 #include "device_group.hpp"
 
 #include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -45,14 +46,15 @@ bool parse_device_list(const char *text, int n_devices, std::vector<int> *out, s
             out->clear();
             return false;
         }
-        if (n_devices >= 0 && v >= n_devices) {
-            *err = "device " + tok + " of the device list '" + s + "' does not exist (" + std::to_string(n_devices) + " visible)";
-            out->clear();
-            return false;
-        }
         out->push_back(static_cast<int>(v));
         pos = comma + 1;
     }
+    for (int v : *out) // (the syntax of the whole list first: a typo is reported as one even where no device is visible)
+        if (n_devices >= 0 && v >= n_devices) {
+            *err = "device " + std::to_string(v) + " of the device list '" + s + "' does not exist (" + std::to_string(n_devices) + " visible)";
+            out->clear();
+            return false;
+        }
     if (out->size() > static_cast<size_t>(kMaxScatterParts)) {
         *err = "more parts in the device list than a handle takes (" + std::to_string(kMaxScatterParts) + ")";
         out->clear();
@@ -388,6 +390,8 @@ int DeviceGroup::run_upward(int k, const double *d_w_primary, int64_t ld_primary
 // Second half on every part; the owned blocks land in the primary's pinned buffer (sorted order, k rows of N) and
 // consume(begin, end, h_sorted) is called on row chunks by the host threads once all of them are there.
 template <class F> int DeviceGroup::finish_to_host(int k, F &&consume) {
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     FmmTree &P = *parts_[0].t;
     double *h_sorted = P.h_pin_ + static_cast<size_t>(k) * n_; // behind the staged weights (sized 2 k N by the staging)
     int rc = for_parts([&](int g) -> int {
@@ -404,7 +408,13 @@ template <class F> int DeviceGroup::finish_to_host(int k, F &&consume) {
         GHIP(hipEventSynchronize(p.ev_done));
     }
     P.bind_device();
+    const auto t_1 = std::chrono::steady_clock::now();
     parallel_for_chunks(n_, int64_t(1) << 16, [&](int64_t b, int64_t e) { consume(b, e, h_sorted); });
+    if (verbose) {
+        const auto t_2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm] device group: downward + leaf passes and the blocks' way back %.3f ms, rows written by the host threads %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(t_1 - t_0).count(), std::chrono::duration<double, std::milli>(t_2 - t_1).count());
+    }
     return BBFMM_OK;
 }
 
@@ -418,9 +428,18 @@ int DeviceGroup::set_weights(const double *w, int64_t rows, int k, int64_t ldw) 
         primary_state_changed();
         return rc == BBFMM_OK ? rc : part_fail(parts_[0], rc);
     }
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     CHK(ensure_capacity(k, false));
     CHK(stage(w, rows, k, ldw));
-    return run_upward(k, nullptr, 0);
+    const auto t_1 = std::chrono::steady_clock::now();
+    const int rc = run_upward(k, nullptr, 0);
+    if (verbose) {
+        const auto t_2 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[bbfmm] device group: set_weights staged the weights in %.3f ms, queued the upward passes and the exchange in %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(t_1 - t_0).count(), std::chrono::duration<double, std::milli>(t_2 - t_1).count());
+    }
+    return rc;
 }
 
 int DeviceGroup::evaluate_at_sources(const double *w, int64_t rows, int k, int64_t ldw, const double *x, int64_t m, int64_t ldx,
@@ -433,8 +452,13 @@ int DeviceGroup::evaluate_at_sources(const double *w, int64_t rows, int k, int64
     last_path_ = 0;
     FmmTree &P = *parts_[0].t;
     if (!sources_fast || staged_k_ < 1 || k != staged_k_ || m != n_ || !x || !out || ldx < m || ldo < m) return BBFMM_OK;
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     if (!P.targets_are_sources(x, m, ldx)) return BBFMM_OK;
     if (!weights_match_staged(w, rows, k, ldw)) return BBFMM_OK; // other weights than set_weights': the primary's mixture
+    if (verbose)
+        std::fprintf(stderr, "[bbfmm] device group: targets and weights compared with the sources / the staged weights in %.3f ms\n",
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_0).count());
     if (pending_k_ != k) CHK(run_upward(k, nullptr, 0));         // (a second evaluate behind one set_weights)
     const int32_t *inv = inv_order_.data();
     const int64_t N = n_;
