@@ -96,6 +96,11 @@ pub const BBFMM_FLAG_DIRECT_SMALL_W_LEAVES: u32 = 4;
 /// `BBFMM_FLAG_DETERMINISTIC` (`FERREUS_BBFMM_DETERMINISTIC=1`): fixed summation order everywhere (no f64 atomics), so
 /// that two runs give bitwise equal results, as the reference's per-target sums do.
 pub const BBFMM_FLAG_DETERMINISTIC: u32 = 8;
+/// Multi-GPU needs nothing here: `bbfmm_create` itself reads `FERREUS_BBFMM_DEVICES` ("0,1,2,3", "all", or "0,0" for
+/// logical parts on one device) and then returns ONE handle that spans those devices of this process -- `set_weights` +
+/// `evaluate` at the sources, `fast_matrix_vector_product` run partitioned over them with the exchange inside the
+/// library (include/ferreus_bbfmm_hip.h: bbfmm_create_on_devices).  `FmmTree::new` has no argument for a device list
+/// (utils.rs:392-421), so the environment is where an unchanged caller says it.
 fn creation_flags() -> u32 {
     let on = |name: &str| matches!(std::env::var(name), Ok(v) if v == "1");
     (if on("FERREUS_BBFMM_M2L_SHARED_BASIS") { BBFMM_FLAG_M2L_SHARED_BASIS } else { 0 })
