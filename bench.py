@@ -335,12 +335,18 @@ def cpu_baseline(args, kernel_id):
     over = None
     if full and full.get("matvecs_per_s_full_size"):
         over = (1.0 / t) * scale / full["matvecs_per_s_full_size"]
+    # what a reader must not miss comes FIRST in `sample` and again under keys of its own (the line's 200-character
+    # cut took exactly the clause that said the scaled sample overstates the port)
     entry = {
         "value": (1.0 / t) * scale, "unit": "matvecs/s", "cores": threads, "kind": "port",
-        "sample": (f"median of {reps} matvecs on {n_cpu} uniform points ({t:.2f} s each, {threads} of {hw} threads"
-                   + (f", host CPU quota {quota:g}" if quota else "") + "), rate x "
-                   f"{n_cpu}/{args.points}; GEMM-shaped C/OpenMP port, not the Rust binary"
-                   + (f"; overstates the port at the full size by {over:.1f}x (measured once at 10M)" if over else "")),
+        "host_cpu_quota": quota,                                       # CPUs the box's cgroup grants (`cores` = THREADS run on them)
+        "overstates_full_size_by": over,                               # scaled sample / the one measured full-size run
+        "measured_full_size_value": (full or {}).get("matvecs_per_s_full_size"),
+        "sample": ((f"overstates the full-size port {over:.1f}x ({full['matvecs_per_s_full_size']:.3f} matvecs/s measured once at 10M); "
+                    if over else "")
+                   + (f"{quota:g}-CPU cgroup quota, {threads} threads; " if quota else f"{threads} of {hw} threads; ")
+                   + f"median of {reps} matvecs on {n_cpu} uniform points ({t:.2f} s each), rate x {n_cpu}/{args.points}; "
+                     "GEMM-shaped C/OpenMP port, not the Rust binary"),
     }
     detail = {
         **entry, "seconds_per_matvec_on_sample": t, "sample_points": n_cpu, "host_threads": hw, "host_cpu_quota": quota,
@@ -739,9 +745,14 @@ def compact_line(detail: dict) -> dict:
     cb = detail.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: _sig(cb.get(k)) for k in ("value", "unit", "cores", "kind", "sample")}
+        for k in ("host_cpu_quota", "overstates_full_size_by", "measured_full_size_value"):   # never cut: keys of their own
+            if cb.get(k) is not None:
+                line["cpu_baseline"][k] = _sig(cb[k])
         line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:200]
     line["dense_rows_rel_err"] = _sig(detail.get("dense_rows_rel_err"))
     dh = detail.get("dropin_host_buffers")
+    if dh and "error" not in dh and dh.get("unchanged_caller_ms"):   # what the reference's own caller gets (rbf.rs:1357-1364)
+        line["value_host_buffers"] = _sig(1e3 / dh["unchanged_caller_ms"])
     if dh and "error" not in dh:   # PCIe-inclusive, host buffers: the patched and the unchanged caller (never `value`)
         line["dropin_host_buffers_ms"] = {"patched": _sig(dh.get("patched_caller_ms")), "unchanged": _sig(dh.get("unchanged_caller_ms")),
                                           "unchanged_general_path": _sig(dh.get("unchanged_caller_general_path_ms"))}

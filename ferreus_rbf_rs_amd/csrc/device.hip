@@ -1075,6 +1075,156 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
     }
 }
 
+// ---- the workgroup kernel for WHOLE big leaves, one right-hand side (round 6).  The kernel above takes a leaf of 153
+// rows (40M points) as four jobs of 38-39: every job stages the same tiles and flushes the same column sums again, and its
+// eight waves get five rows each, computed as six (rows per wave are padded to the pass) -- 0.80 of the pair arithmetic
+// it executes is real, and the potentials are written 54 times over (profiles/r05_final_config5_size_*_counters.txt).
+// Here a job is a leaf (bigger ones than p2p_sym3_rows_per_job() in equal parts): its rows are dealt to the waves
+// evenly (counts differ by one at most), a wave runs them against a tile as full passes of SYM_TR rows plus ONE pass of
+// exactly the remaining rows (six instances of the pass, selected by a wave-uniform switch): no padded row is ever
+// evaluated.  A pass reduces its row sums across the wave and adds them to the potentials at once -- accumulators that
+// lived over all tiles cost the kernel its occupancy (111 VGPRs for three passes' worth, 164 for five: 11.1 and 19.9 ms
+// at 5M Spheroidal3 points against 12.4 for the chunk kernel); column sums collect in the tile's LDS accumulator over
+// all of the leaf's rows and leave with one atomic per source and (leaf, tile).
+// One pass: NR rows (sorted sources g0 .. g0 + NR, wave-uniform) against the tile.  ALLCOLS: every column takes its column
+// sum (the nodes of W cells); otherwise only the two-sided ones (cidx >= 0).  The rows' sums over this tile are reduced
+// across the wave and added to out[row0 + r] at once (rows outside [win_lo, win_hi) are dropped: a partition's window) --
+// the accumulators do not outlive the pass, so the kernel holds NR of them whatever the size of the leaf.
+template <int KID, int NR, bool ALLCOLS>
+__device__ inline void sym3_pass(const KernelSpec &ks, SymTile<1> &tile, int fill, int lane, int g0, int row0, const Xyz &src,
+                                 const double *__restrict__ ws, double *__restrict__ out, int win_lo, int win_hi) {
+    double tx[NR], ty[NR], tz[NR], tw[NR], racc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) { // wave-uniform: scalar loads, SGPR operands
+        tx[r] = src.x[g0 + r], ty[r] = src.y[g0 + r], tz[r] = src.z[g0 + r];
+        tw[r] = ws[g0 + r];
+        racc[r] = 0.0;
+    }
+    for (int j = lane; j < fill; j += 64) {
+        const double xs = tile.x[j], ys = tile.y[j], zs = tile.z[j], wj = tile.w[0][j];
+        double csum = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const double dx = tx[r] - xs, dy = ty[r] - ys, dz = tz[r] - zs;
+            const double v = kernel_value_r2<KID>(ks, dx * dx + dy * dy + dz * dz);
+            racc[r] += v * wj;
+            csum += v * tw[r];
+        }
+        if (ALLCOLS || tile.cidx[j] >= 0) unsafeAtomicAdd(&tile.col[0][j], csum);
+    }
+    double mine = 0.0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const double sres = wave_sum(racc[r]);
+        if (lane == r) mine = sres;
+    }
+    const int o = row0 + lane;
+    if (lane < NR && o >= win_lo && o < win_hi) unsafeAtomicAdd(&out[o], mine);
+}
+
+// A wave's nr rows in passes of at most MAXR rows, all of sz or sz + 1 rows (equal passes: a pass of one or two rows costs
+// a third of a full one -- the tile's LDS reads and the column bookkeeping do not shrink with it: 153-row leaves as single
+// jobs with passes 6 + 6 + 6 + 1 ran 15.2 ms against 10.9 for two half leaves)
+template <int KID, int MAXR, bool ALLCOLS>
+__device__ inline void sym3_rows(const KernelSpec &ks, SymTile<1> &tile, int fill, int lane, int g_lo, int row_lo, int nr,
+                                 const Xyz &src, const double *__restrict__ ws, double *__restrict__ out, int win_lo, int win_hi) {
+    const int npass = (nr + MAXR - 1) / MAXR;
+    const int sz = npass > 0 ? nr / npass : 0, big = nr - sz * npass;
+    int row = 0;
+    for (int p = 0; p < npass; ++p) {
+        const int cnt = sz + (p < big ? 1 : 0);
+        const int g0 = g_lo + row, row0 = row_lo + row;
+        switch (cnt) { // wave-uniform
+        case 1: sym3_pass<KID, 1, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        case 2: sym3_pass<KID, 2, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        case 3: sym3_pass<KID, 3, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        case 4: sym3_pass<KID, 4, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        case 5: sym3_pass<KID, 5, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        case 6: sym3_pass<KID, 6, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        case 7: if constexpr (MAXR >= 7) sym3_pass<KID, 7, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        case 8: if constexpr (MAXR >= 8) sym3_pass<KID, 8, ALLCOLS>(ks, tile, fill, lane, g0, row0, src, ws, out, win_lo, win_hi); break;
+        default: break;
+        }
+        row += cnt;
+    }
+}
+
+template <int KID, int MAXR>
+__global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym3_kernel(KernelSpec ks, SymJobs jobs, Xyz src,
+                                                                 const double *__restrict__ ws, double *__restrict__ out) {
+    constexpr int T = sym_tile<1>();
+    __shared__ SymTile<1> tile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int job = blockIdx.x;
+    const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
+    const int rows = t1 - t0, base = rows / SYM_WAVES, extra = rows - base * SYM_WAVES;
+    const int nr = base + (wave < extra ? 1 : 0);
+    const int r_lo = t0 + wave * base + min(wave, extra);
+    const int g_lo = jobs.tgt_off + r_lo;                       // sorted source index of the wave's first row
+    int64_t q = jobs.run_range[2 * job];
+    const int64_t q1 = jobs.run_range[2 * job + 1];
+    int pos = 0;
+    while (q < q1) {
+        __syncthreads(); // the previous tile has been read and its columns flushed
+        if (wave == 0) { // the tile's segment table, as in p2p_sym_kernel
+            const int64_t r = q + lane;
+            const bool valid = r < q1;
+            int bq = valid ? jobs.runs[3 * r] : 0;
+            const int e = valid ? jobs.runs[3 * r + 1] : 0;
+            const int two = valid ? jobs.runs[3 * r + 2] : 0;
+            if (lane == 0) bq += pos;
+            const int len = e - bq;
+            int incl = len;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int up = __shfl_up(incl, d, 64);
+                if (lane >= d) incl += up;
+            }
+            const int excl = incl - len;
+            const int take = min(len, max(T - excl, 0));
+            tile.seg_src[lane] = bq;
+            tile.seg_off[lane] = excl;
+            tile.seg_two[lane] = two;
+            const unsigned long long used = __ballot(take > 0);
+            const int nseg = __popcll(used);
+            if (lane == nseg - 1) {
+                const bool full = take == len;
+                tile.fill = excl + take;
+                tile.nseg = nseg;
+                tile.next_q = q + lane + (full ? 1 : 0);
+                tile.next_pos = full ? 0 : ((lane == 0 ? pos : 0) + take);
+            }
+        }
+        __syncthreads();
+        const int fill = tile.fill, nseg = tile.nseg;
+        q = tile.next_q;
+        pos = tile.next_pos;
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
+            int lo = 0, hi = nseg;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (tile.seg_off[mid] <= j) lo = mid;
+                else hi = mid;
+            }
+            const int g = tile.seg_src[lo] + (j - tile.seg_off[lo]);
+            tile.x[j] = src.x[g];
+            tile.y[j] = src.y[g];
+            tile.z[j] = src.z[g];
+            tile.w[0][j] = ws[g];
+            tile.col[0][j] = 0.0;
+            tile.cidx[j] = tile.seg_two[lo] ? g - jobs.tgt_off : -1;
+        }
+        __syncthreads();
+        sym3_rows<KID, MAXR, false>(ks, tile, fill, lane, g_lo, r_lo, nr, src, ws, out, 0, 0x7fffffff);
+        __syncthreads();
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
+            const int c = tile.cidx[j];
+            if (c >= 0) unsafeAtomicAdd(&out[c], tile.col[0][j]);
+        }
+    }
+}
+
 // ---- the same unordered-pair sums, one WAVE per job (round 3).  The workgroup version above spends a third of its
 // busy cycles around the pair arithmetic (three workgroup barriers per tile, one wave building the segment table while
 // seven wait, column sums through LDS atomics, six-row reductions per wave) and leaves the vector ALU idle a quarter of
@@ -1454,6 +1604,56 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym_kernel(KernelSpec ks, W
                 }
             }
         }
+    }
+}
+
+// The fused M2P + P2L pass for ONE right-hand side on whole leaves (round 6): like p2p_sym3_kernel with the Chebyshev nodes
+// of a chunk of the leaf's W cells as columns.  A job = (all rows of a leaf -- up to wx_sym3_rows_per_job(), bigger ones in
+// equal parts) x (a chunk of its W list): the nodes of a cell are staged and their column sums flushed to L once per leaf
+// instead of once per 48 rows, and no padded row is evaluated.
+template <int KID, int MAXR>
+__global__ __launch_bounds__(64 * SYM_WAVES) void wx_sym3_kernel(KernelSpec ks, WxJobs jobs, const DevCheb *__restrict__ chp,
+                                                                const double *__restrict__ centers,
+                                                                const double *__restrict__ lengths, Xyz src,
+                                                                const double *__restrict__ ws, const double *__restrict__ M,
+                                                                double *__restrict__ L, double *__restrict__ out, int out_off,
+                                                                int out_n) {
+    constexpr int T = sym_tile<1>();
+    __shared__ SymTile<1> tile;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int job = blockIdx.x;
+    const int p = chp->p, d = chp->d, n = chp->n, n_pad = chp->n_pad;
+    int P0, P1, P2;
+    axis_sizes(p, d, P0, P1, P2);
+    const int t0 = jobs.tgt_begin[job], t1 = jobs.tgt_end[job];
+    const int rows = t1 - t0, base_r = rows / SYM_WAVES, extra = rows - base_r * SYM_WAVES;
+    const int nr = base_r + (wave < extra ? 1 : 0);
+    const int r_lo = t0 + wave * base_r + min(wave, extra); // sorted source position of the wave's first row
+    const int64_t q0 = jobs.w_range[2 * job], q1 = jobs.w_range[2 * job + 1];
+    const int64_t total = (q1 - q0) * n;
+    for (int64_t base = 0; base < total; base += T) {
+        const int fill = static_cast<int>(min<int64_t>(T, total - base));
+        __syncthreads();
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) {
+            const int64_t P = base + j;
+            const int ci = static_cast<int>(P / n), I = static_cast<int>(P - static_cast<int64_t>(ci) * n);
+            const int cell = jobs.w_cells[q0 + ci];
+            const double half = lengths[cell] * 0.5;
+            const int i2 = I % P2, i1 = (I / P2) % P1, i0 = I / (P2 * P1); // scale_cheb_nodes_to_cell, chebyshev.rs:951-968
+            tile.x[j] = centers[cell * 3] + half * chp->nodes[i0];
+            tile.y[j] = d > 1 ? centers[cell * 3 + 1] + half * chp->nodes[i1] : 0.0;
+            tile.z[j] = d > 2 ? centers[cell * 3 + 2] + half * chp->nodes[i2] : 0.0;
+            tile.w[0][j] = M[static_cast<int64_t>(cell) * n_pad + I];
+            tile.col[0][j] = 0.0;
+            tile.cidx[j] = cell * n_pad + I;
+        }
+        __syncthreads();
+        // (a partition's output holds its own rows only: out_off = first owned row; the rows of a leaf outside are here for
+        // their column sums -- P2L into the partition's cells -- alone)
+        sym3_rows<KID, MAXR, true>(ks, tile, fill, lane, r_lo, r_lo - out_off, nr, src, ws, out, 0, out_n);
+        __syncthreads();
+        for (int j = tid; j < fill; j += 64 * SYM_WAVES) unsafeAtomicAdd(&L[tile.cidx[j]], tile.col[0][j]);
     }
 }
 
@@ -2094,14 +2294,24 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
 // instance).  Measured at 10M points, LinearRbf (scripts/p2p_rhs_sweep.py): 4.4 / 5.1 / 7.3 ms for 1 / 2 / 4 rhs; an
 // 8-slot instance (two rows per chunk, 222 VGPRs, two waves per SIMD; also with point-major weights and software-pipelined
 // row loads) took 16.6 ms per pass against 2 x 7.3: not kept.
+int p2p_sym3_passes();
+static int p2p_sym3_max_rows_per_pass() {
+    static const int v = [] {
+        const char *e = std::getenv("BBFMM_P2P_SYM_LEAF_PASS");
+        return e && std::atoi(e) == 8 ? 8 : 6;
+    }();
+    return v;
+}
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                    const int64_t *run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
+                    const int64_t *run_range, int n_leaf_jobs, const int32_t *l_tgt_begin, const int32_t *l_tgt_end,
+                    const int64_t *l_run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
                     const int64_t *w_run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
                     const double *w_sorted, int64_t ldw, int K, double *out_sorted, int64_t ldo, hipStream_t s) {
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
         const SymJobs wj{n_wave_jobs, w_tgt_begin, w_tgt_end, w_run_range, runs3, tgt_off};
         const SymJobs gj{n_jobs, tgt_begin, tgt_end, run_range, runs3, tgt_off};
+        const SymJobs lj{n_leaf_jobs, l_tgt_begin, l_tgt_end, l_run_range, runs3, tgt_off};
         const Xyz src = make_xyz(src_xyz);
         for (int k0 = 0; k0 < K; k0 += kSymMaxRhs) {
             const int kb = std::min(kSymMaxRhs, K - k0);
@@ -2112,7 +2322,12 @@ void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, 
         if (n_wave_jobs > 0)                                                                                          \
             hipLaunchKernelGGL((p2p_sym2_kernel<ID, KBV>), dim3((n_wave_jobs + SYM2_WAVES - 1) / SYM2_WAVES),          \
                                dim3(64 * SYM2_WAVES), 0, s, ks, wj, src, w, ldw, kb, o, ldo);                         \
-        if (n_jobs > 0)                                                                                               \
+        if (KBV == 1 && n_leaf_jobs > 0) { /* one rhs: whole big leaves (the same rows as the chunk jobs below) */     \
+            if (p2p_sym3_max_rows_per_pass() == 8)                                                                    \
+                hipLaunchKernelGGL((p2p_sym3_kernel<ID, 8>), dim3(n_leaf_jobs), dim3(64 * SYM_WAVES), 0, s, ks, lj, src, w, o); \
+            else                                                                                                      \
+                hipLaunchKernelGGL((p2p_sym3_kernel<ID, 6>), dim3(n_leaf_jobs), dim3(64 * SYM_WAVES), 0, s, ks, lj, src, w, o); \
+        } else if (n_jobs > 0)                                                                                        \
             hipLaunchKernelGGL((p2p_sym_kernel<ID, KBV>), dim3(n_jobs), dim3(64 * SYM_WAVES), 0, s, ks, gj, src, w,    \
                                ldw, kb, o, ldo);                                                                      \
     } while (0)
@@ -2137,14 +2352,36 @@ int p2p_sym_wave_rows() {
 }
 
 int p2p_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
+// Whole-leaf jobs of the one-rhs workgroup kernel: rows per job (BBFMM_P2P_SYM_LEAF=<rows>; 0: no such jobs, the chunk
+// jobs serve one rhs too).  A job of R rows gives each of the eight waves R / 8 of them.
+int p2p_sym3_passes() {
+    static const int v = [] {
+        const char *e = std::getenv("BBFMM_P2P_SYM_LEAF");
+        const int x = e ? std::atoi(e) : 256;
+        return x <= 0 ? 0 : std::max(x, SYM_WAVES * SYM_TR);
+    }();
+    return v;
+}
+int p2p_sym3_rows_per_job() { return p2p_sym3_passes(); }
 int wx_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
+// rows per whole-leaf job of the one-rhs fused pass (BBFMM_WX_SYM_LEAF=<rows>; 0: none, the chunk jobs serve one rhs too)
+int wx_sym3_rows_per_job() {
+    static const int v = [] {
+        const char *e = std::getenv("BBFMM_WX_SYM_LEAF");
+        const int x = e ? std::atoi(e) : 256;
+        return x <= 0 ? 0 : std::max(x, SYM_WAVES * SYM_TR);
+    }();
+    return v;
+}
 
 void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                   const int64_t *w_range, const int32_t *w_cells, const double *centers, const double *lengths,
+                   const int64_t *w_range, int n_leaf_jobs, const int32_t *l_tgt_begin, const int32_t *l_tgt_end,
+                   const int64_t *l_w_range, const int32_t *w_cells, const double *centers, const double *lengths,
                    const double *const *src_xyz, const double *w_sorted, int64_t ldw, int K, const double *M, double *L,
                    int64_t ld_ml, double *out_sorted, int64_t ldo, int out_off, int out_n, hipStream_t s) {
     if (n_jobs == 0) return;
     const WxJobs jobs{n_jobs, tgt_begin, tgt_end, w_range, w_cells};
+    const WxJobs ljobs{n_leaf_jobs, l_tgt_begin, l_tgt_end, l_w_range, w_cells};
     dispatch_kernel_id(ks.id, [&](auto idc) {
         constexpr int ID = decltype(idc)::value;
         for (int k0 = 0; k0 < K; k0 += kSymMaxRhs) { // (an 8-slot instance would be bound by its LDS traffic)
@@ -2154,7 +2391,11 @@ void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const in
                        lengths, make_xyz(src_xyz), w_sorted + static_cast<int64_t>(k0) * ldw, ldw, kb,                 \
                        M + static_cast<int64_t>(k0) * ld_ml, L + static_cast<int64_t>(k0) * ld_ml, ld_ml,               \
                        out_sorted + static_cast<int64_t>(k0) * ldo, ldo, out_off, out_n)
-            if (kb == 1) WX_GO(1);
+            if (kb == 1 && n_leaf_jobs > 0) // one rhs: whole leaves (the same rows and W cells as the chunk jobs)
+                hipLaunchKernelGGL((wx_sym3_kernel<ID, 6>), dim3(n_leaf_jobs), dim3(64 * SYM_WAVES), 0, s, ks, ljobs, ch.dev, centers, lengths,
+                                   make_xyz(src_xyz), w_sorted + static_cast<int64_t>(k0) * ldw, M + static_cast<int64_t>(k0) * ld_ml,
+                                   L + static_cast<int64_t>(k0) * ld_ml, out_sorted + static_cast<int64_t>(k0) * ldo, out_off, out_n);
+            else if (kb == 1) WX_GO(1);
             else if (kb == 2) WX_GO(2);
             else WX_GO(4);
 #undef WX_GO

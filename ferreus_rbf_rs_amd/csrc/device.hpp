@@ -157,18 +157,27 @@ void launch_p2p(const KernelSpec &ks, int d, const DirectJobs &jobs, const doubl
 // K right-hand sides (rhs k: weights w_sorted + k * ldw, sums out_sorted + k * ldo) go in passes of at most
 // kSymMaxRhs, one kernel evaluation per unordered pair and pass.
 constexpr int kSymMaxRhs = 4;
+// (n_leaf_jobs, l_*): the big leaves again as WHOLE-leaf jobs (at most p2p_sym3_rows_per_job() rows: bigger leaves in
+// equal parts) for the one-rhs workgroup kernel (round 6); a pass of one rhs takes these instead of the chunk jobs
+// (0 of them: the chunk jobs serve one rhs too).
 void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                    const int64_t *run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
+                    const int64_t *run_range, int n_leaf_jobs, const int32_t *l_tgt_begin, const int32_t *l_tgt_end,
+                    const int64_t *l_run_range, int n_wave_jobs, const int32_t *w_tgt_begin, const int32_t *w_tgt_end,
                     const int64_t *w_run_range, const int32_t *runs3, int32_t tgt_off, const double *const *src_xyz,
                     const double *w_sorted, int64_t ldw, int K, double *out_sorted, int64_t ldo, hipStream_t s);
 int p2p_sym_rows_per_job();
+int p2p_sym3_rows_per_job(); // 0: no whole-leaf jobs (BBFMM_P2P_SYM_LEAF=0)
 int p2p_sym_wave_rows(); // 0: no wave jobs (BBFMM_P2P_SYM_WAVE=0)
 int wx_sym_rows_per_job();
+int wx_sym3_rows_per_job(); // 0: no whole-leaf jobs (BBFMM_WX_SYM_LEAF=0)
 // M2P + P2L in one pass for targets = all sources (X = W^T; K rhs in passes of kSymMaxRhs: rhs k at w_sorted + k * ldw,
 // M / L + k * ld_ml, out_sorted + k * ldo): jobs are row chunks of the leaves that have a
 // W list, w_range their ranges in w_cells; row sums go to out_sorted (M2P), column sums to L (P2L), both atomically.
+// (n_leaf_jobs, l_*): the same rows and W cells as whole-leaf jobs (at most wx_sym3_rows_per_job() rows) for a pass of one
+// rhs (round 6; 0 of them: the chunk jobs serve one rhs too)
 void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const int32_t *tgt_begin, const int32_t *tgt_end,
-                   const int64_t *w_range, const int32_t *w_cells, const double *centers, const double *lengths,
+                   const int64_t *w_range, int n_leaf_jobs, const int32_t *l_tgt_begin, const int32_t *l_tgt_end,
+                   const int64_t *l_w_range, const int32_t *w_cells, const double *centers, const double *lengths,
                    const double *const *src_xyz, const double *w_sorted, int64_t ldw, int K, const double *M, double *L,
                    int64_t ld_ml, double *out_sorted, int64_t ldo, int out_off, int out_n, hipStream_t s);
 // M2P: sources are the Chebyshev nodes of the W-list cells, weights their multipoles.  Job i

@@ -56,14 +56,14 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
     // wave-per-job kernel (no barriers, columns in registers: faster where a leaf's work is small); bigger leaves go
     // in chunks of at most p2p_sym_rows_per_job() rows to the workgroup-per-job kernel, whose per-job overhead is
     // spread over eight waves (faster there).
-    const int64_t max_rows = p2p_sym_rows_per_job(), wave_rows = p2p_sym_wave_rows();
+    const int64_t max_rows = p2p_sym_rows_per_job(), wave_rows = p2p_sym_wave_rows(), leaf_rows = p2p_sym3_rows_per_job();
     const int64_t nj_cells = static_cast<int64_t>(job_cells.size());
     // per chunk of leaves into local buffers (threads), concatenated in order
     constexpr int64_t kChunkS = 2048;
     const int64_t nch = (nj_cells + kChunkS - 1) / kChunkS;
     struct Part {
-        std::vector<int32_t> runs, tb, te, wtb, wte;
-        std::vector<int64_t> range, wrange; // run ranges relative to the part's first run
+        std::vector<int32_t> runs, tb, te, wtb, wte, ltb, lte;
+        std::vector<int64_t> range, wrange, lrange; // run ranges relative to the part's first run
     };
     std::vector<Part> parts(static_cast<size_t>(std::max<int64_t>(nch, 1)));
     parallel_for_chunks(nj_cells, kChunkS, [&](int64_t lo, int64_t hi) {
@@ -101,12 +101,21 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
                         P.range.push_back(first);
                         P.range.push_back(last);
                     }
+                    if (leaf_rows > 0) { // and whole (one rhs): as few equal parts as the kernel's accumulators allow
+                        const int64_t nl = (na + leaf_rows - 1) / leaf_rows;
+                        for (int64_t i = 0; i < nl; ++i) {
+                            P.ltb.push_back(static_cast<int32_t>(a0 - pb + na * i / nl));
+                            P.lte.push_back(static_cast<int32_t>(a0 - pb + na * (i + 1) / nl));
+                            P.lrange.push_back(first);
+                            P.lrange.push_back(last);
+                        }
+                    }
                 }
             }
         }
     });
-    std::vector<int64_t> range, wrange;
-    std::vector<int32_t> runs, tb, te, wtb, wte;
+    std::vector<int64_t> range, wrange, lrange;
+    std::vector<int32_t> runs, tb, te, wtb, wte, ltb, lte;
     {
         size_t nr = 0, njobs = 0, nwjobs = 0;
         for (const Part &P : parts) nr += P.runs.size(), njobs += P.tb.size(), nwjobs += P.wtb.size();
@@ -126,8 +135,15 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
             wtb.insert(wtb.end(), P.wtb.begin(), P.wtb.end());
             wte.insert(wte.end(), P.wte.begin(), P.wte.end());
             for (int64_t v : P.wrange) wrange.push_back(base + v);
+            ltb.insert(ltb.end(), P.ltb.begin(), P.ltb.end());
+            lte.insert(lte.end(), P.lte.begin(), P.lte.end());
+            for (int64_t v : P.lrange) lrange.push_back(base + v);
         }
     }
+    static const int order_mask = [] {
+        const char *e = std::getenv("BBFMM_SYM_JOB_ORDER");
+        return e ? std::atoi(e) : 15;
+    }();
     ts->n_wx_jobs = 0;
     const bool whole = pb == 0 && pe == t.n_points;
     if ((whole || part_active) && !t.w.idx.empty() &&
@@ -136,8 +152,9 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
         // column sums that fall on cells outside its subtree are never read) and the leaves outside whose W list holds
         // a cell of its subtree (column sums = P2L into that cell; their row sums are dropped by the kernel's output
         // window).  X = W^T (linear_tree.rs:388-392), so this covers the X lists of the partition's cells.
-        std::vector<int32_t> wtb, wte;
-        std::vector<int64_t> wr;
+        std::vector<int32_t> wtb, wte, ltb2, lte2;
+        std::vector<int64_t> wr, lr2;
+        std::vector<int32_t> wx_leaves; // the leaves that take part
         const std::vector<int32_t> &cand = whole ? job_cells : src_leaves_;
         for (size_t j = 0; j < cand.size(); ++j) {
             const int32_t c = cand[j];
@@ -151,6 +168,7 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
             // jobs = (row chunk of the leaf) x (chunk of its W list): a nearly uniform tree has a few dozen coarse
             // leaves with long W lists (10M uniform points: 90 leaves of 250 points, about 100 W cells each), and whole-list
             // jobs would be a handful of long workgroups (0.96 ms for 0.6e9 kernel evaluations); both sums are atomic
+            wx_leaves.push_back(c);
             const int64_t max_rows_wx = wx_sym_rows_per_job(), max_cells_wx = 16;
             const int64_t a0 = t.pt_begin[c], na = t.pt_end[c] - a0, nj = (na + max_rows_wx - 1) / max_rows_wx;
             const int64_t w0 = t.w.ptr[c], nw = t.w.ptr[c + 1] - w0, nwj = (nw + max_cells_wx - 1) / max_cells_wx;
@@ -162,15 +180,93 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
                     wr.push_back(w0 + nw * (jw + 1) / nwj);
                 }
         }
+        // whole-leaf jobs for one rhs: all rows of a leaf (bigger ones than the kernel takes in equal parts) x a chunk of its W
+        // list; the chunks shrink until there are a few jobs per CU (a nearly uniform tree has a few dozen leaves with long lists)
+        const int64_t leaf_rows_wx = wx_sym3_rows_per_job();
+        if (leaf_rows_wx > 0 && !wx_leaves.empty()) {
+            int64_t cells_per_job = 16;
+            for (;;) {
+                int64_t nj_total = 0;
+                for (int32_t c : wx_leaves) {
+                    const int64_t na = t.pt_end[c] - t.pt_begin[c], nw = t.w.ptr[c + 1] - t.w.ptr[c];
+                    nj_total += ((na + leaf_rows_wx - 1) / leaf_rows_wx) * ((nw + cells_per_job - 1) / cells_per_job);
+                }
+                if (nj_total >= 4 * static_cast<int64_t>(n_cu_) || cells_per_job == 1) break;
+                cells_per_job = std::max<int64_t>(1, cells_per_job / 2);
+            }
+            for (int32_t c : wx_leaves) {
+                const int64_t a0 = t.pt_begin[c], na = t.pt_end[c] - a0, nj = (na + leaf_rows_wx - 1) / leaf_rows_wx;
+                const int64_t w0 = t.w.ptr[c], nw = t.w.ptr[c + 1] - w0, nwj = (nw + cells_per_job - 1) / cells_per_job;
+                for (int64_t i = 0; i < nj; ++i)
+                    for (int64_t jw = 0; jw < nwj; ++jw) {
+                        ltb2.push_back(static_cast<int32_t>(a0 + na * i / nj));
+                        lte2.push_back(static_cast<int32_t>(a0 + na * (i + 1) / nj));
+                        lr2.push_back(w0 + nw * jw / nwj);
+                        lr2.push_back(w0 + nw * (jw + 1) / nwj);
+                    }
+            }
+        }
+        auto wx_longest_first = [&](std::vector<int32_t> *b, std::vector<int32_t> *e, std::vector<int64_t> *rg) { // rows x W cells
+            const size_t n = b->size();
+            std::vector<int32_t> perm(n), b2(n), e2(n);
+            std::vector<int64_t> r2(2 * n);
+            for (size_t i = 0; i < n; ++i) perm[i] = static_cast<int32_t>(i);
+            std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) {
+                return static_cast<int64_t>((*e)[x] - (*b)[x]) * ((*rg)[2 * x + 1] - (*rg)[2 * x]) >
+                       static_cast<int64_t>((*e)[y] - (*b)[y]) * ((*rg)[2 * y + 1] - (*rg)[2 * y]);
+            });
+            for (size_t i = 0; i < n; ++i) {
+                const size_t s0 = static_cast<size_t>(perm[i]);
+                b2[i] = (*b)[s0], e2[i] = (*e)[s0], r2[2 * i] = (*rg)[2 * s0], r2[2 * i + 1] = (*rg)[2 * s0 + 1];
+            }
+            b->swap(b2), e->swap(e2), rg->swap(r2);
+        };
+        if (order_mask & 8) wx_longest_first(&ltb2, &lte2, &lr2);
+        ts->n_wxl_jobs = static_cast<int>(ltb2.size());
+        CHK(dupload(&ts->wxl_tb, ltb2));
+        CHK(dupload(&ts->wxl_te, lte2));
+        CHK(dupload(&ts->wxl_range, lr2));
+        if (order_mask & 8) wx_longest_first(&wtb, &wte, &wr);
         ts->n_wx_jobs = static_cast<int>(wtb.size());
         CHK(dupload(&ts->wx_tb, wtb));
         CHK(dupload(&ts->wx_te, wte));
         CHK(dupload(&ts->wx_range, wr));
     }
+    // Job order.  The lists above are in Morton order, and the hardware starts workgroups in index order: the duration of
+    // a job varies with its place in that order (a leaf's two-sided runs are the neighbours AFTER it), and whole 153-row
+    // leaves in Morton order left the SQs idle for a quarter of the launch (5M Spheroidal3 points: 13.5 ms; shuffled 10.6;
+    // longest first 10.5 -- profiles/r06_e_*).  Longest first (rows x columns) is the classic remedy for such a tail.
+    // BBFMM_SYM_JOB_ORDER: bit 0 whole-leaf jobs, bit 1 chunk jobs, bit 2 wave jobs, bit 3 the fused M2P + P2L jobs (default 15: all).
+    auto longest_first = [&](std::vector<int32_t> *b, std::vector<int32_t> *e, std::vector<int64_t> *rg) {
+        const size_t n = b->size();
+        std::vector<int64_t> work(n);
+        parallel_for(static_cast<int64_t>(n), 1024, [&](int64_t i) {
+            int64_t cols = 0;
+            for (int64_t r = (*rg)[2 * i]; r < (*rg)[2 * i + 1]; ++r) cols += runs[3 * r + 1] - runs[3 * r];
+            work[static_cast<size_t>(i)] = cols * ((*e)[static_cast<size_t>(i)] - (*b)[static_cast<size_t>(i)]);
+        });
+        std::vector<int32_t> perm(n);
+        for (size_t i = 0; i < n; ++i) perm[i] = static_cast<int32_t>(i);
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t x, int32_t y) { return work[static_cast<size_t>(x)] > work[static_cast<size_t>(y)]; });
+        std::vector<int32_t> b2(n), e2(n);
+        std::vector<int64_t> r2(2 * n);
+        for (size_t i = 0; i < n; ++i) {
+            const size_t s0 = static_cast<size_t>(perm[i]);
+            b2[i] = (*b)[s0], e2[i] = (*e)[s0], r2[2 * i] = (*rg)[2 * s0], r2[2 * i + 1] = (*rg)[2 * s0 + 1];
+        }
+        b->swap(b2), e->swap(e2), rg->swap(r2);
+    };
+    if (order_mask & 1) longest_first(&ltb, &lte, &lrange);
+    if (order_mask & 2) longest_first(&tb, &te, &range);
+    if (order_mask & 4) longest_first(&wtb, &wte, &wrange);
     ts->n_symw_jobs = static_cast<int>(wtb.size());
     CHK(dupload(&ts->symw_tb, wtb));
     CHK(dupload(&ts->symw_te, wte));
     CHK(dupload(&ts->symw_ptr, wrange));
+    ts->n_syml_jobs = static_cast<int>(ltb.size());
+    CHK(dupload(&ts->syml_tb, ltb));
+    CHK(dupload(&ts->syml_te, lte));
+    CHK(dupload(&ts->syml_ptr, lrange));
     ts->n_sym_jobs = static_cast<int>(tb.size());
     CHK(dupload(&ts->sym_tb, tb));
     CHK(dupload(&ts->sym_te, te));
@@ -391,10 +487,18 @@ void FmmTree::free_target_set(TargetSet *ts) {
     dfree(&ts->symw_te);
     dfree(&ts->symw_ptr);
     ts->n_symw_jobs = 0;
+    dfree(&ts->syml_tb);
+    dfree(&ts->syml_te);
+    dfree(&ts->syml_ptr);
+    ts->n_syml_jobs = 0;
     dfree(&ts->wx_tb);
     dfree(&ts->wx_te);
     dfree(&ts->wx_range);
     ts->n_wx_jobs = 0;
+    dfree(&ts->wxl_tb);
+    dfree(&ts->wxl_te);
+    dfree(&ts->wxl_range);
+    ts->n_wxl_jobs = 0;
     ts->sym = false;
 }
 
@@ -738,23 +842,34 @@ void FmmTree::free_downward_plan(DownwardPlan *dp) {
 // preconditioner asks for the same index sets (its levels' points) in every iteration, so the
 // sorted targets and the restricted downward pass are built once per distinct index set and kept
 // (8 sets, least recently used evicted).
+// hash of an index set: chunk hashes computed in parallel, combined in order
+uint64_t FmmTree::subset_key(const int64_t *idx, int64_t n_idx) const {
+    uint64_t h = 1469598103934665603ull ^ static_cast<uint64_t>(n_idx);
+    constexpr int64_t kChunk = int64_t(1) << 16;
+    const int64_t nch = (n_idx + kChunk - 1) / kChunk;
+    std::vector<uint64_t> part(static_cast<size_t>(std::max<int64_t>(nch, 1)), 0);
+    parallel_for_chunks(n_idx, kChunk, [&](int64_t b, int64_t e) {
+        for (int64_t c = b; c < e; c += kChunk) { // (a single-threaded host gets one call for everything)
+            uint64_t hc = 1469598103934665603ull;
+            for (int64_t j = c; j < std::min(e, c + kChunk); ++j) hc = (hc ^ static_cast<uint64_t>(idx[j])) * 1099511628211ull;
+            part[static_cast<size_t>(c / kChunk)] = hc;
+        }
+    });
+    for (uint64_t hc : part) h = (h ^ hc) * 1099511628211ull;
+    return h;
+}
+
+bool FmmTree::subset_plan_cached(const int64_t *idx, int64_t n_idx, uint64_t key) const {
+    for (const auto &sp : subset_plans_)
+        if (sp->key == key && sp->n_idx == n_idx &&
+            (n_idx == 0 || std::memcmp(sp->idx.data(), idx, static_cast<size_t>(n_idx) * sizeof(int64_t)) == 0))
+            return true;
+    return false;
+}
+
 int FmmTree::subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out) {
     const int64_t N = tree_.n_points;
-    // hash of the index set: chunk hashes computed in parallel, combined in order
-    uint64_t h = 1469598103934665603ull ^ static_cast<uint64_t>(n_idx);
-    {
-        constexpr int64_t kChunk = int64_t(1) << 16;
-        const int64_t nch = (n_idx + kChunk - 1) / kChunk;
-        std::vector<uint64_t> part(static_cast<size_t>(std::max<int64_t>(nch, 1)), 0);
-        parallel_for_chunks(n_idx, kChunk, [&](int64_t b, int64_t e) {
-            for (int64_t c = b; c < e; c += kChunk) { // (a single-threaded host gets one call for everything)
-                uint64_t hc = 1469598103934665603ull;
-                for (int64_t j = c; j < std::min(e, c + kChunk); ++j) hc = (hc ^ static_cast<uint64_t>(idx[j])) * 1099511628211ull;
-                part[static_cast<size_t>(c / kChunk)] = hc;
-            }
-        });
-        for (uint64_t hc : part) h = (h ^ hc) * 1099511628211ull;
-    }
+    const uint64_t h = subset_key(idx, n_idx);
     ++subset_clock_;
     for (auto &sp : subset_plans_)
         if (sp->key == h && sp->n_idx == n_idx &&

@@ -197,6 +197,21 @@ int FmmTree::create(const double *pts, int64_t n, int d, int64_t ld, int order, 
             std::memcpy(&pts_[static_cast<size_t>(a) * n + b], pts + a * ld + b, static_cast<size_t>(e - b) * sizeof(double));
         });
 
+    { // A NaN coordinate would slip through every comparison below (the reference's saturating casts send it to cell 0:
+      // not a behaviour worth keeping); infinities are caught with it instead of by the radius check further down.
+        std::atomic<int64_t> bad{-1};
+        parallel_for_chunks(static_cast<int64_t>(pts_.size()), int64_t(1) << 18, [&](int64_t b, int64_t e) {
+            for (int64_t i = b; i < e; ++i)
+                if (!std::isfinite(pts_[static_cast<size_t>(i)])) {
+                    int64_t expect = -1;
+                    bad.compare_exchange_strong(expect, i);
+                    return;
+                }
+        });
+        if (bad.load() >= 0)
+            return fail(BBFMM_BAD_ARGUMENT, "source_points hold a non-finite coordinate (row " + std::to_string(bad.load() % n) + ", column " +
+                                                std::to_string(bad.load() / n) + ")");
+    }
     double ext[6];
     solver_tree_ = sparse && !extents;
     if (extents) {
@@ -950,7 +965,8 @@ int FmmTree::downward_tail(int k, const DownwardPlan *dp, const TargetSet *wx) {
     const int64_t C = t.n_cells();
     phase_begin();
     if (t.adaptive && wx) { // targets = all sources: P2L and M2P share their kernel evaluations (X = W^T)
-        launch_wx_sym(kernel_, cheb_, wx->n_wx_jobs, wx->wx_tb.p, wx->wx_te.p, wx->wx_range.p, d_w_idx_.p, d_centers_.p,
+        launch_wx_sym(kernel_, cheb_, wx->n_wx_jobs, wx->wx_tb.p, wx->wx_te.p, wx->wx_range.p, wx->n_wxl_jobs, wx->wxl_tb.p, wx->wxl_te.p,
+                      wx->wxl_range.p, d_w_idx_.p, d_centers_.p,
                       d_lengths_.p, src_ptr_, d_w_sorted_.p, t.n_points, k, d_M_.p, d_L_.p, C * cheb_.n_pad, wx->out.p,
                       static_cast<int64_t>(wx->m), wx->sym_off, static_cast<int>(wx->m), stream_);
     } else if (t.adaptive) {
@@ -999,7 +1015,8 @@ int FmmTree::leaf_pass_near(const TargetSet &ts, int k, bool with_grads, hipStre
         }();
         if (timed) phase_begin();
         if (ts.sym && sym_on && !deterministic_ && !with_grads) // targets = sources: every unordered pair once, for all rhs
-            launch_p2p_sym(kernel_, ts.n_sym_jobs, ts.sym_tb.p, ts.sym_te.p, ts.sym_ptr.p, ts.n_symw_jobs, ts.symw_tb.p, ts.symw_te.p,
+            launch_p2p_sym(kernel_, ts.n_sym_jobs, ts.sym_tb.p, ts.sym_te.p, ts.sym_ptr.p, ts.n_syml_jobs, ts.syml_tb.p, ts.syml_te.p,
+                           ts.syml_ptr.p, ts.n_symw_jobs, ts.symw_tb.p, ts.symw_te.p,
                            ts.symw_ptr.p, ts.sym_runs.p, ts.sym_off, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, ts.m, st);
         else
             launch_p2p(kernel_, d_, jobs, ts.xyz_ptr, ts.m, src_ptr_, d_w_sorted_.p, t.n_points, k, ts.out.p, grad, st);
@@ -1076,7 +1093,9 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     }();
     bool m2l_queued = false;
     last_eval_at_sources_ = false;
-    if (sources_fast && !leaves_only && !with_grads && !have_part_ && m == tree_.n_points && src_targets_.m == m && w && rows >= m &&
+    // (not in Leaves mode: the early M2L rewrites L, and a call that then fails -- a target outside the tree -- would leave the
+    // stored expansions half written)
+    if (sources_fast && !leaves_only && !with_grads && !have_part_ && !locals_requested_ && m == tree_.n_points && src_targets_.m == m && w && rows >= m &&
         ldw >= rows && static_cast<size_t>(2) * k * m <= kMaxPinnedDoubles) {
         CHK(ensure_rhs_capacity(k));
         CHK(downward_m2l(k, nullptr));
@@ -1128,7 +1147,15 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     if (sources_fast && solver_tree_ && !m2l_queued && !leaves_only && !with_grads && (!have_part_ || group_primary_) && !locals_requested_ && k == 1 && w &&
         m < tree_.n_points && m >= std::max<int64_t>(1024, tree_.n_points / 2048) && m <= tree_.n_points / 2) {
         std::vector<int64_t> rows_of;
-        if (targets_are_rows_of_sources(x, m, ldx, &rows_of)) {
+        // A plan (sorted targets + restricted downward pass) is built on the SECOND sighting of an index set: a caller that
+        // never repeats one pays the lookup only and keeps the plans of those who do.
+        bool known = false;
+        if (tree_.n_points <= (int64_t(1) << 26) && targets_are_rows_of_sources(x, m, ldx, &rows_of)) {
+            const uint64_t key = subset_key(rows_of.data(), m);
+            known = subset_plan_cached(rows_of.data(), m, key) || key == last_subset_miss_;
+            if (!known) last_subset_miss_ = key;
+        }
+        if (known) {
             SubsetPlan *sp = nullptr;
             CHK(subset_plan(rows_of.data(), m, &sp));
             CHK(put_weights(w, rows, 1, ldw));

@@ -75,6 +75,9 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     DevBuf<int32_t> sym_tb, sym_te; // jobs: row chunks of the leaves
     DevBuf<int64_t> sym_ptr;        // 2 per job: run range of the job's leaf
     DevBuf<int32_t> sym_runs;
+    int n_syml_jobs = 0;            // the big leaves again as whole-leaf jobs (one rhs; device.hpp launch_p2p_sym)
+    DevBuf<int32_t> syml_tb, syml_te;
+    DevBuf<int64_t> syml_ptr;
     int n_symw_jobs = 0;            // whole small leaves: one wave each (device.hpp launch_p2p_sym)
     DevBuf<int32_t> symw_tb, symw_te;
     DevBuf<int64_t> symw_ptr;
@@ -82,6 +85,9 @@ struct TargetSet { // targets sorted by leaf, resident on the device
     int n_wx_jobs = 0;
     DevBuf<int32_t> wx_tb, wx_te;
     DevBuf<int64_t> wx_range;
+    int n_wxl_jobs = 0;             // the same as whole-leaf jobs (one rhs; device.hpp launch_wx_sym)
+    DevBuf<int32_t> wxl_tb, wxl_te;
+    DevBuf<int64_t> wxl_range;
 };
 
 // The part of the downward pass a set of target leaves needs (a partition of the sources, or the
@@ -320,6 +326,9 @@ class FmmTree {
     int part_pending_k_ = 0; // rhs count of a matvec_partition_upward that still waits for its finish
     void free_downward_plan(DownwardPlan *dp);
     int subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out);
+    uint64_t subset_key(const int64_t *idx, int64_t n_idx) const;
+    bool subset_plan_cached(const int64_t *idx, int64_t n_idx, uint64_t key) const;
+    uint64_t last_subset_miss_ = 0; // key of the last index set evaluate() saw without a plan (a plan is built on the second sighting)
     int fill_subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan *sp);
     std::vector<std::unique_ptr<SubsetPlan>> registered_plans_; // bbfmm_target_subset_create: kept for the handle's life
 

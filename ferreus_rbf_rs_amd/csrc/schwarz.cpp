@@ -98,9 +98,14 @@ int level_step(Schwarz &S, size_t li, bool have_sl, bool coarse, bool add_poly, 
     };
     auto t0 = now();
     const double *src = S.d_rg;
+    const bool sharded = !coarse && S.world > 1;
+    // A sharded level ends in a collective: a rank that failed on the way there must still take part in it, or its peers
+    // wait forever.  Its contribution is poisoned (NaN) instead, and every rank reads the verdict out of the sum.
+    int local_rc = BBFMM_OK;
     if (have_sl) { // rg - matvec_partial(sl, level rows)  (schwarz.rs:53-59, 63-67)
         const int rc = bbfmm_matvec_subset_device(S.tree, S.subset_id[li], S.d_sl, S.d_y, 0);
-        if (rc) return rc;
+        if (rc && !sharded) return rc;
+        if (rc) local_rc = rc;
         launch_schwarz_residual(S.d_rg, S.d_y, S.d_sl, S.nugget, rows, nl, S.d_res, S.stream);
         src = S.d_res;
         if (S.verbose) {
@@ -110,17 +115,25 @@ int level_step(Schwarz &S, size_t li, bool have_sl, bool coarse, bool add_poly, 
             t0 = now();
         }
     }
-    const bool sharded = !coarse && S.world > 1;
     if (sharded) launch_schwarz_scatter_rows(nullptr, rows, nl, S.d_out, S.stream); // rows of the other ranks' domains: 0
-    int rc = lv.n_dom > 0 ? ddm_level_solve(lv, src, S.d_out, coarse, S.stream) : BBFMM_OK;
-    if (rc) return rc;
+    int rc = (lv.n_dom > 0 && local_rc == BBFMM_OK) ? ddm_level_solve(lv, src, S.d_out, coarse, S.stream) : BBFMM_OK;
+    if (rc && !sharded) return rc;
+    if (rc) local_rc = rc;
     if (sharded) { // the level's correction = the sum over the ranks of their domains' rows (disjoint: exact)
-        if (nl > S.xchg_cap) return BBFMM_BAD_ARGUMENT;
-        launch_schwarz_gather_rows(S.d_out, rows, nl, S.d_xchg, S.stream);
-        HIPOK(hipStreamSynchronize(S.stream));
+        if (nl > S.xchg_cap) return BBFMM_BAD_ARGUMENT; // (the same on every rank: they hold the same decomposition)
+        if (local_rc == BBFMM_OK && hipGetLastError() != hipSuccess) local_rc = BBFMM_DEVICE_ERROR;
+        if (local_rc == BBFMM_OK)
+            launch_schwarz_gather_rows(S.d_out, rows, nl, S.d_xchg, S.stream);
+        else // all-ones bytes = NaN: whatever the peers add to it stays NaN
+            (void)hipMemsetAsync(S.d_xchg, 0xFF, static_cast<size_t>(nl) * sizeof(double), S.stream);
+        if (hipStreamSynchronize(S.stream) != hipSuccess && local_rc == BBFMM_OK) local_rc = BBFMM_DEVICE_ERROR;
         const auto tx = std::chrono::steady_clock::now();
-        if ((rc = S.allreduce(S.allreduce_user, nl)) != 0) return BBFMM_DEVICE_ERROR;
+        if (S.allreduce(S.allreduce_user, nl) != 0) return BBFMM_DEVICE_ERROR; // (the collective itself failed: nothing to agree through)
         S.t_exchange += std::chrono::duration<double>(std::chrono::steady_clock::now() - tx).count();
+        double first = 0.0;
+        if (nl > 0) HIPOK(hipMemcpy(&first, S.d_xchg, sizeof(double), hipMemcpyDeviceToHost));
+        if (local_rc != BBFMM_OK) return local_rc;
+        if (std::isnan(first)) return BBFMM_DEVICE_ERROR; // a peer failed in this level (or the iteration has diverged)
         launch_schwarz_scatter_rows(S.d_xchg, rows, nl, S.d_out, S.stream);
     }
     if (!coarse) { // solve_fine_level, schwarz.rs:84-126: internal points written back, then orthogonalised

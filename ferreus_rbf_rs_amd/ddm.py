@@ -131,7 +131,13 @@ class SchwarzPreconditioner:
             import torch.distributed as dist
             group = None if shard_group is True else shard_group
             self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
-            dev = torch.device("cuda", tree.device()) if hasattr(tree, "device") else torch.device("cuda", torch.cuda.current_device())
+            # The ranks run the replicated parts of the sweep (partial products, coarse solve) and the solver around it in
+            # lock step: a default tree accumulates with f64 atomics, ranks would differ in their last bits, an FGMRES run
+            # near its tolerance could end on one rank while the others wait in the next all-reduce.
+            if self.world > 1 and not getattr(tree, "deterministic", False):
+                raise ValueError("a sharded preconditioner needs a tree created with deterministic=True (BBFMM_FLAG_DETERMINISTIC): "
+                                 "the ranks must take the same branches")
+            dev = torch.device("cuda", tree.device())              # the handle's own device (bbfmm_part_device), not torch's current one
             self._xchg = torch.zeros(n, dtype=torch.float64, device=dev)
             staged = dist.get_backend(group) == "gloo"
             host = torch.zeros(n, dtype=torch.float64).pin_memory() if staged else None
@@ -152,13 +158,23 @@ class SchwarzPreconditioner:
 
             self._allreduce_cb = L.ALLREDUCE_FN(_allreduce)
         if self.world > 1:
-            torch.cuda.synchronize()
+            torch.cuda.synchronize(dev)
             rc = lib.bbfmm_schwarz_create_sharded(tree._h, pts.ctypes.data, n, d, n, ctypes.byref(st), ctypes.byref(prm),
                                                   self.rank, self.world, self._xchg.data_ptr(), n,
                                                   ctypes.cast(self._allreduce_cb, ctypes.c_void_p), None, ctypes.byref(h))
         else:
             rc = lib.bbfmm_schwarz_create(tree._h, pts.ctypes.data, n, d, n, ctypes.byref(st), ctypes.byref(prm),
                                           ctypes.byref(h))
+        if self.world > 1:
+            # every rank raises, or none does: a rank that failed alone (a local system that is not positive definite, out of
+            # memory) would leave its peers waiting in the first level's all-reduce
+            ok = torch.tensor([1 if rc == L.OK else 0], dtype=torch.int64, device="cpu" if staged else dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+            if int(ok.item()) == 0:
+                if rc == L.OK and h:
+                    lib.bbfmm_schwarz_destroy(h)
+                raise ValueError(f"bbfmm_schwarz_create_sharded failed on a rank of the group (this rank: status {rc})"
+                                 + (" (a local system is not positive definite)" if rc == L.UNSUPPORTED else ""))
         if rc != L.OK:
             raise ValueError(f"bbfmm_schwarz_create failed with status {rc}"
                              + (" (a local system is not positive definite)" if rc == L.UNSUPPORTED else ""))

@@ -192,6 +192,7 @@ class FmmTree:
         self.sparse = bool(sparse)
         self.n_points = n
         self.dim = d
+        self.deterministic = bool(deterministic)
         self._nrhs = 0
         self._compressed = params is None or params.compression_type != M2LCompressionType.None_
 

@@ -559,6 +559,13 @@ int bbfmm_schwarz_create(bbfmm_handle *tree, const double *points, int64_t n, in
  *   d_exchange: DEVICE buffer of the caller, exchange_capacity >= the largest fine level (N) doubles;
  *   allreduce(user, count): sum d_exchange[0 .. count) over the ranks in place (ncclAllReduce / torch.distributed);
  *     called from bbfmm_schwarz_apply with the library's stream idle, must return with the result visible to the device.
+ * The ranks run the replicated parts (the partial products through `tree`, the coarse solve, the solver around the sweep)
+ * in LOCK STEP: `tree` must be a BBFMM_FLAG_DETERMINISTIC handle on every rank (the default path's f64 atomics leave the
+ * ranks' replicated results different in their last bits, and a solver near its tolerance could stop on one rank while
+ * the others wait in the next all-reduce), or the caller broadcasts the solver's decisions.  A rank that fails inside a
+ * sharded level still takes part in the level's all-reduce with a poisoned (NaN) contribution, so every rank returns an
+ * error from that bbfmm_schwarz_apply instead of one returning and the others waiting; after a failed CREATE the caller
+ * must agree on the status itself before the first apply (ddm.py does: MIN over the group).
  * rank 0 / world 1 (no exchange) is bbfmm_schwarz_create. */
 typedef int (*bbfmm_allreduce_fn)(void *user, int64_t count);
 int bbfmm_schwarz_create_sharded(bbfmm_handle *tree, const double *points, int64_t n, int32_t d, int64_t ld,

@@ -142,7 +142,10 @@ def _synthetic_detail(world=1):
             "roofline": roof, "phase_ms_per_step": ms, "tree": {"depth": 6}, "source_hash": bench.source_hash(),
             "phase_roofline": bench.phase_roofline(S, 10_000_000, 1, 7, "LinearRbf", ms, 3.1e13),
             "dense_rows_rel_err": 9.390407276931204e-09, "configs": cfgs,
-            "cpu_baseline": {"value": 0.03216402327044833, "unit": "matvecs/s", "cores": 128, "kind": "port", "sample": "s" * 400},
+            "cpu_baseline": {"value": 0.1374, "unit": "matvecs/s", "cores": 32, "kind": "port", "host_cpu_quota": 16.0,
+                             "overstates_full_size_by": 1.2962, "measured_full_size_value": 0.106,
+                             "sample": "overstates the full-size port 1.3x (0.106 matvecs/s measured once at 10M); 16-CPU cgroup quota, "
+                                       "32 threads; " + "s" * 400},
             "cpu_baseline_detail": {"note": "n" * 600},
             "dropin_host_buffers": {"points": 10_000_000, "patched_caller_ms": 46.322698937729, "unchanged_caller_ms": 46.43676499836147,
                                     "unchanged_caller_general_path_ms": 57.23296804353595, "unchanged_caller_took_resident_path": True}}
@@ -169,7 +172,14 @@ def test_the_stdout_line_stays_under_4_kb_and_round_trips(world, tmp_path, monke
     assert line["n_gpus"] == world and line["config"]["workload"].startswith("10000000 uniform")
     assert set(line["roofline"]) >= {"kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "mfma_util_pct"}
     assert abs(line["value"] - detail["value"]) < 1e-5 * detail["value"]
-    assert set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"} and len(line["cpu_baseline"]["sample"]) <= 200
+    cb = line["cpu_baseline"]
+    assert set(cb) == {"value", "unit", "cores", "kind", "sample", "host_cpu_quota", "overstates_full_size_by", "measured_full_size_value"}
+    assert len(cb["sample"]) <= 200
+    # the two clauses the 200-character cut must never take -- in keys of their own AND at the front of `sample`
+    assert cb["host_cpu_quota"] == 16.0 and abs(cb["overstates_full_size_by"] - 1.2962) < 1e-3 and cb["measured_full_size_value"] == 0.106
+    assert cb["sample"].startswith("overstates the full-size port 1.3x") and "16-CPU cgroup quota" in cb["sample"]
+    # and the unchanged caller's rate beside `value` (host buffers, PCIe inclusive)
+    assert abs(line["value_host_buffers"] - 1e3 / 46.43676499836147) < 1e-3 and line["value_host_buffers"] < line["value"]
     assert line["p2p"]["frac_hbm"] < 0.5 and 0 < line["p2p"]["frac_fp64_valu"] < 1
     # round 5: config 4's Gaussian-extension instance and the shared-basis extension ride on the default N = 1 line; the
     # drop-in boundary's host-buffer figures (patched and unchanged caller) as one small entry

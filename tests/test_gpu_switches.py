@@ -24,6 +24,10 @@ SWITCHES = [
     ("s2_no_ksplit", {"BBFMM_M2L_S2_KSPLIT": "1"}, []),
     ("operators_host_fill", {"BBFMM_M2L_ASSEMBLE_HOST": "1"}, []),
     ("evaluate_at_sources_general_path", {"BBFMM_EVAL_SOURCES_FAST": "0"}, []),
+    ("near_field_chunk_jobs_for_one_rhs", {"BBFMM_P2P_SYM_LEAF": "0", "BBFMM_WX_SYM_LEAF": "0"}, []),   # round 6: no whole-leaf jobs
+    ("near_field_jobs_in_morton_order", {"BBFMM_SYM_JOB_ORDER": "0"}, []),
+    ("near_field_no_wave_jobs", {"BBFMM_P2P_SYM_WAVE": "0"}, []),                                       # every leaf in the workgroup kernels
+    ("near_field_no_wave_jobs_chunks", {"BBFMM_P2P_SYM_WAVE": "0", "BBFMM_P2P_SYM_LEAF": "0"}, []),
     ("deterministic", {}, ["deterministic"]),
     ("deterministic_again", {}, ["deterministic"]),
 ]

@@ -166,8 +166,11 @@ def test_rows_of_the_sources_take_the_cached_subset_plan(case):
     idx = np.sort(rng.choice(n, n // 8, replace=False))
     x = pts[idx]                                                  # select_mat_rows
     t.set_weights(w)
-    y = t.evaluate(w, x)
+    y_first = t.evaluate(w, x)                                    # first sighting of the index set: recognised, but no plan is
+    assert t.last_evaluate_path() == 0                            # built for a caller that may never come back (round 6)
+    y = t.evaluate(w, x)                                          # second sighting: the plan is built and kept
     assert t.last_evaluate_path() == 2 and not t.last_evaluate_at_sources()
+    assert relerr(y_first, y) < 1e-12
     r.set_weights(w)
     yr = r.evaluate(w, x)
     assert relerr(y, yr) < TOL
@@ -178,6 +181,7 @@ def test_rows_of_the_sources_take_the_cached_subset_plan(case):
     # unsorted rows with a repeated one: still rows of the sources, values follow the rows
     idx2 = rng.permutation(idx)[: n // 16]
     idx2[3] = idx2[7]
+    t.evaluate(w, pts[idx2])
     y3 = t.evaluate(w, pts[idx2])
     assert t.last_evaluate_path() == 2
     full = t.evaluate(w, pts)[:, 0]
@@ -227,5 +231,6 @@ def test_leading_dimensions_larger_than_the_row_counts(case):
     t.set_weights(wbuf[:n])
     assert relerr(y_all, t.evaluate(wbuf[:n], pts)) < 1e-12
     idx = np.sort(rng.choice(n, n // 10, replace=False))
-    y_sub = run(idx)
+    run(idx)
+    y_sub = run(idx)                                              # (second sighting of the row set: the cached-plan path)
     assert t.last_evaluate_path() == 2 and relerr(y_sub, y_all[idx]) < 1e-12

@@ -315,3 +315,13 @@ def test_rows_of_the_sources_lookup():
     t2 = F.FmmTree(pts[:, :2].copy(), 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, host_only=True)
     r2 = t2.debug_rows_of_sources(pts[idx, :2])
     assert r2 is not None and np.array_equal(pts[r2, :2], pts[idx, :2])
+
+
+@pytest.mark.parametrize("bad", [np.nan, np.inf, -np.inf])
+def test_non_finite_source_coordinates_are_refused_with_a_message(bad):
+    """A NaN passes every comparison of the extents and the tree build (the reference's saturating casts would send it to
+    cell 0): bbfmm_create says which row and column instead (a NaN coordinate was accepted silently)."""
+    pts = np.random.default_rng(3).random((500, 3))
+    pts[123, 1] = bad
+    with pytest.raises(ValueError, match=r"non-finite coordinate \(row 123, column 1\)"):
+        F.FmmTree(pts, 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, host_only=True)
