@@ -87,6 +87,7 @@ SIGNATURES = {
     "bbfmm_matvec_partition_finish_sorted": (ctypes.c_int, [c_p, c_p, c_p, c_i64, c_p]),
     "bbfmm_partition_scatter": (ctypes.c_int, [c_p, c_p, c_i32, c_i32, c_i64, c_i32, c_p, c_i64]),
     "bbfmm_debug_partition_upward_counts": (ctypes.c_int, [c_p, c_p, c_p, c_p]),
+    "bbfmm_debug_host_copy_rates": (ctypes.c_int, [c_i64, c_p]),
     "bbfmm_get_tree_stats": (ctypes.c_int, [c_p, c_p]),
     "bbfmm_tree_built_on_device": (ctypes.c_int, [c_p]),
     "bbfmm_last_evaluate_at_sources": (ctypes.c_int, [c_p]),

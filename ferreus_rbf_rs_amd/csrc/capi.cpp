@@ -4,6 +4,8 @@
 #include <string>
 #include <vector>
 
+#include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <memory>
 
@@ -565,6 +567,48 @@ int bbfmm_mfma_f64_selftest(double *tflops, int32_t *layout_errors, double *info
     if (tflops) *tflops = tf;
     if (layout_errors) *layout_errors = errs;
     return rc == 0 ? BBFMM_OK : BBFMM_DEVICE_ERROR;
+}
+
+// Host-side legs of the host-buffer entry points, by themselves (scripts/host_buffer_legs.py): n doubles copied by the
+// pool in 2 MB pieces (the staging copy), gathered through a random permutation (the row writes of a device group),
+// scattered through it.  out4 = {memcpy ms, gather ms, scatter ms, threads}; medians of five.
+int bbfmm_debug_host_copy_rates(int64_t n, double *out4) {
+    if (n < 1 || !out4) return BBFMM_BAD_ARGUMENT;
+    try {
+        std::vector<double, bbfmm::DefaultInitAllocator<double>> a(static_cast<size_t>(n)), b(static_cast<size_t>(n));
+        std::vector<int32_t> perm(static_cast<size_t>(n));
+        bbfmm::parallel_for_chunks(n, int64_t(1) << 18, [&](int64_t lo, int64_t hi) {
+            for (int64_t i = lo; i < hi; ++i) a[static_cast<size_t>(i)] = static_cast<double>(i), b[static_cast<size_t>(i)] = 0.0, perm[static_cast<size_t>(i)] = static_cast<int32_t>(i);
+        });
+        uint64_t st = 88172645463325252ull;
+        for (int64_t i = n; i > 1; --i) {
+            st ^= st << 13, st ^= st >> 7, st ^= st << 17;
+            std::swap(perm[static_cast<size_t>(i - 1)], perm[static_cast<size_t>(st % static_cast<uint64_t>(i))]);
+        }
+        auto med5 = [&](auto &&fn) {
+            double t[5];
+            for (double &v : t) {
+                const auto t0 = std::chrono::steady_clock::now();
+                fn();
+                v = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            std::sort(t, t + 5);
+            return t[2];
+        };
+        out4[0] = med5([&] {
+            bbfmm::parallel_for_chunks(n, int64_t(1) << 18, [&](int64_t lo, int64_t hi) { std::memcpy(&b[static_cast<size_t>(lo)], &a[static_cast<size_t>(lo)], static_cast<size_t>(hi - lo) * 8); });
+        });
+        out4[1] = med5([&] {
+            bbfmm::parallel_for_chunks(n, int64_t(1) << 16, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) b[static_cast<size_t>(i)] = a[static_cast<size_t>(perm[static_cast<size_t>(i)])]; });
+        });
+        out4[2] = med5([&] {
+            bbfmm::parallel_for_chunks(n, int64_t(1) << 16, [&](int64_t lo, int64_t hi) { for (int64_t i = lo; i < hi; ++i) b[static_cast<size_t>(perm[static_cast<size_t>(i)])] = a[static_cast<size_t>(i)]; });
+        });
+        out4[3] = static_cast<double>(bbfmm::host_threads());
+        return BBFMM_OK;
+    } catch (...) {
+        return BBFMM_BAD_ARGUMENT;
+    }
 }
 
 // Test hooks (host only): dense M2M matrix of the reference and the stacked-table M2L.

@@ -67,26 +67,26 @@ inline KernelSpec make_kernel_spec(int id, double base_range, double total_sill)
     return k;
 }
 
-// sqrt / 1/sqrt / 1/x for the pair loops.  Host: libm and IEEE division.  Device: v_rsq_f64 /
-// v_rcp_f64 seeds refined by Goldschmidt / Newton steps built from FMAs (1-2 ulp; the correctly
-// rounded library sqrt and division are 24-30 instructions each; measured 96 -> ~56 cycles per
-// wave for sqrt on MI355X).  x >= 0 always (sums of squares).
-// x = 0 (a point against itself): only the argument of rsq is clamped (to 1e-300), so the seed
-// stays finite and g = x * y = 0 carries an exact zero through the refinement; the select that
-// would otherwise guard 0 * inf costs three instructions per pair.
+// sqrt / 1/sqrt / 1/x for the pair loops.  Host: libm and IEEE division.  Device: v_rsq_f64 / v_rcp_f64 seeds refined by
+// FMAs.  x >= 0 always (sums of squares).
+// Round 6: ONE cubic step instead of the two-stage Goldschmidt refinement of rounds 1-5.  The seed y = v_rsq_f64(x) is good to
+// 5.2e-8 (scripts/rsq_accuracy.hip), e = 1 - x y^2 is twice that, and 1 / sqrt(1 - e) = 1 + e/2 + 3 e^2/8 + O(e^3) leaves a
+// truncation of 3e-22: the result is within 2 ulp of the correctly rounded root (measured: rsq_accuracy.hip), for five
+// instructions behind the seed where the two-stage form took seven (sqrt) and ten (sqrt and 1/sqrt) -- 17 -> 15 FP64
+// instructions per LinearRbf pair, 28 -> 24 per Spheroidal3 pair, in kernels that run at the FP64 issue roof.  The reference's
+// own sqrt is the correctly rounded one; two ulp per kernel value sit five orders below the 1e-11 the parity tests hold.
+// x = 0 (a point against itself): only the argument of rsq is clamped (to 1e-300), so the seed stays finite and x * y = 0
+// carries an exact zero through (sqrt(0) = 0 exactly); the select that would otherwise guard 0 * inf costs three
+// instructions per pair.
 BBFMM_HD inline void bb_sqrt_rsqrt(double x, double *s, double *rs) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
-    double g = x * y, h = 0.5 * y;
-    double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double d = fma(-g, g, x);
-    g = fma(d, h, g);          // sqrt(x)
-    r = fma(-h, g, 0.5);
-    h = fma(h, r, h);          // 1 / (2 sqrt(x))
-    *s = g;
-    *rs = h + h;
+    const double t = x * y;
+    const double e = fma(-t, y, 1.0);      // 1 - x y^2
+    const double p = fma(0.375, e, 0.5);
+    const double r = fma(y * e, p, y);     // 1 / sqrt(x)
+    *rs = r;
+    *s = x * r;                            // sqrt(x)
 #else
     *s = sqrt(x);
     *rs = 1.0 / *s;
@@ -95,12 +95,10 @@ BBFMM_HD inline void bb_sqrt_rsqrt(double x, double *s, double *rs) {
 BBFMM_HD inline double bb_sqrt(double x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const double y = __builtin_amdgcn_rsq(fmax(x, 1e-300));
-    double g = x * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    const double d = fma(-g, g, x);
-    return fma(d, h, g);
+    const double t = x * y;                // sqrt(x) to the seed's accuracy
+    const double e = fma(-t, y, 1.0);
+    const double p = fma(0.375, e, 0.5);
+    return fma(t * e, p, t);
 #else
     return sqrt(x);
 #endif

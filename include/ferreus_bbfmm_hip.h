@@ -330,6 +330,11 @@ int bbfmm_partition_scatter(bbfmm_handle *h, const double *d_all, int32_t first_
  * coarse level must hold its true count already. */
 int bbfmm_debug_partition_upward_counts(const bbfmm_handle *h, int64_t *counts_out, uint8_t *reads_out, int64_t *info_out);
 
+/* Host-side legs of the host-buffer entry points by themselves (scripts/host_buffer_legs.py; no device needed): n doubles
+ * copied by the library's thread pool in 2 MB pieces, gathered through a random permutation, scattered through it.
+ * out4 = {copy ms, gather ms, scatter ms, pool threads}. */
+int bbfmm_debug_host_copy_rates(int64_t n, double *out4);
+
 /* ---- introspection (tests, bench statistics; host side, no device needed) ---- */
 typedef struct {
     int32_t d, order, n_nodes, depth;
