@@ -2546,7 +2546,7 @@ static int device_cu_count() { // of the current device (every entry point binds
 // blockIdx.z walks the column blocks, the chunk plan splits a block.
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf, int64_t cbuf_len,
-                       hipStream_t s, bool own_blocks) {
+                       hipStream_t s, bool own_blocks, int max_blocks) {
     if (n_tiles == 0) return;
     int slot_t = 16; // LDS slot-table width: power of two covering the transfer vectors of any block
     while (slot_t < max_slot_t) slot_t *= 2;
@@ -2557,9 +2557,12 @@ void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const 
     // column-block walk each; z is chosen so that the last, partially filled round is short (a per-workgroup
     // overhead of about half a percent of a walk keeps z small).  Measured at 10M points (2,336 tiles): z = 2 18.2 ms,
     // 3 18.0, 4 17.75, 7 18.0, 13 18.3.
+    // A launch that does not fill the chip even at z = 8 (a small tree: 16 tiles at 36k points, where a workgroup's walk of
+    // four column blocks WAS the stage: 0.155 ms of a 0.46 ms matvec) may split the walk down to one block per workgroup.
+    const int zmax = n_tiles * 8 < n_cu ? std::max(8, std::min(max_blocks, 32)) : 8;
     int zsplit = 1;
     double best = 1e300;
-    for (int z = 1; z <= 8; ++z) {
+    for (int z = 1; z <= zmax; ++z) {
         const double rounds = std::ceil(static_cast<double>(n_tiles) * z / n_cu);
         const double cost = rounds / z * (1.0 + 0.005 * z);
         if (cost < best - 1e-12) {

@@ -104,7 +104,7 @@ int launch_l2l(const ChebRef &ch, int K, int64_t C, const int32_t *cells, int n_
 // (tile.first indexes tile_idx; a partition's compact source tiles)
 void launch_m2l_stage1(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int max_slot_t, int K, int64_t C, const double *M, double *cbuf,
-                       int64_t cbuf_len, hipStream_t s, bool own_blocks = false);
+                       int64_t cbuf_len, hipStream_t s, bool own_blocks = false, int max_blocks = 8);
 void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const int32_t *tile_idx, int n_tiles,
                        int n_pad, int K, int64_t C, const double *cbuf, int64_t cbuf_len,
                        const uint16_t *qlist, double *L, hipStream_t s, bool allow_ksplit = true);

@@ -247,6 +247,7 @@ int FmmTree::build_m2l_tables() {
             }
             // per column block: first transfer-vector position, and the packed row table
             const int n_blk = hc.r_pad16 / kM2lS1Block;
+            m2l_max_blocks_ = std::max(m2l_max_blocks_, n_blk);
             hc.blk_t0.assign(n_blk, 0);
             hc.row_dst.assign(hc.r_pad16, -1);
             for (int b = 0; b < n_blk; ++b) {

@@ -932,12 +932,12 @@ int FmmTree::downward_m2l(int k, const DownwardPlan *dp) {
                                          cbuf_batch_len_, stream_);
             if (dp) { // whole-operator tiles, then the tiles of single column blocks (sources in the halo of the target set)
                 launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p + t1_first, dp->d_tile_idx.p, t1_count, m2l_len, m2l_slot_t_, kb,
-                                  C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, false);
+                                  C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, false, m2l_max_blocks_);
                 launch_m2l_stage1(d_m2l_classes_.p, dp->d_tiles1.p + dp->batch_t1[4 * b + 2], dp->d_tile_idx.p, dp->batch_t1[4 * b + 3],
-                                  m2l_len, m2l_slot_t_, kb, C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, true);
+                                  m2l_len, m2l_slot_t_, kb, C, m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, true, m2l_max_blocks_);
             } else
                 launch_m2l_stage1(d_m2l_classes_.p, d_m2l_tiles1_.p + t1_first, d_tile_idx1_.p, t1_count, m2l_len, m2l_slot_t_, kb, C,
-                                  m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, false);
+                                  m_chunk, d_cbuf_.p, cbuf_batch_len_, stream_, false, m2l_max_blocks_);
             phase_end(kPhM2L1);
             phase_begin();
             if (dp)
@@ -1049,11 +1049,21 @@ int FmmTree::set_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     pin_w_k_ = 0;
+    static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
+    const auto t_0 = std::chrono::steady_clock::now();
     CHK(put_weights(w, rows, k, ldw));
+    const auto t_1 = std::chrono::steady_clock::now();
     nrhs_ = k; // bbfmm.rs:384
     have_locals_ = locals_requested_ = false; // the stored local expansions belong to the old weights
     CHK(upward(k));
+    const auto t_2 = std::chrono::steady_clock::now();
     HIPCHK(hipStreamSynchronize(stream_));
+    if (verbose) {
+        const auto t_3 = std::chrono::steady_clock::now();
+        auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[bbfmm] set_weights: weights staged and their copies queued %.3f ms, upward pass queued %.3f ms, waited for the device %.3f ms\n",
+                     ms(t_0, t_1), ms(t_1, t_2), ms(t_2, t_3));
+    }
     return BBFMM_OK;
 }
 
@@ -1105,6 +1115,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
             const TargetSet &ts = src_targets_;
             const auto t_cmp = std::chrono::steady_clock::now();
             CHK(put_weights(w, rows, k, ldw)); // the weights of set_weights again: recognised, nothing moves
+            const auto t_put = std::chrono::steady_clock::now();
             static const bool wx_on = [] {
                 const char *e = std::getenv("BBFMM_WX_FUSED");
                 const char *e2 = std::getenv("BBFMM_P2P_SYM");
@@ -1120,6 +1131,11 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
             phase_end(kPhScatter);
             HIPCHK(hipGetLastError());
             double *pin_out = h_pin_ + static_cast<size_t>(k) * N; // behind the staged weights (put_weights sized the buffer)
+            const auto t_queued = std::chrono::steady_clock::now();
+            if (verbose) { // (the device's share, by itself: costs the overlap of the copies with the last kernels)
+                HIPCHK(hipStreamSynchronize(stream_));
+            }
+            const auto t_dev = std::chrono::steady_clock::now();
             CHK(download_pieces(d_out_.p, static_cast<int64_t>(k) * N, pin_out, [&](int64_t pb, int64_t pe) {
                 while (pb < pe) { // a piece may run over a column boundary
                     const int64_t col = pb / N, row = pb - col * N, len = std::min(pe - pb, N - row);
@@ -1130,9 +1146,11 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
             last_eval_at_sources_ = true;
             if (verbose) {
                 const auto t_end = std::chrono::steady_clock::now();
-                std::fprintf(stderr, "[bbfmm] evaluate: the %lld targets are the sources (compared in %.3f ms beside the M2L); total %.3f ms\n",
-                             static_cast<long long>(m), std::chrono::duration<double, std::milli>(t_cmp - t_begin).count(),
-                             std::chrono::duration<double, std::milli>(t_end - t_begin).count());
+                auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+                std::fprintf(stderr, "[bbfmm] evaluate: the %lld targets are the sources (M2L queued and targets compared in %.3f ms beside it, weights "
+                                     "compared %.3f ms, rest queued %.3f ms, waited for the device %.3f ms, potentials home %.3f ms); total %.3f ms\n",
+                             static_cast<long long>(m), ms(t_begin, t_cmp), ms(t_cmp, t_put), ms(t_put, t_queued), ms(t_queued, t_dev), ms(t_dev, t_end),
+                             ms(t_begin, t_end));
             }
             return BBFMM_OK;
         }

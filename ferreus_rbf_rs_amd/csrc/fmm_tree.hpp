@@ -312,6 +312,7 @@ class FmmTree {
     int device_ = -1;     // the HIP device that was current in create(): every entry point binds its thread to it
     std::vector<M2lTileDesc> m2l_tiles2_h_; // stage-2 launch list: m2l_tiles_h_ with the tail of every batch split
     int m2l_slot_t_ = 1; // most transfer vectors any stage-1 column block touches
+    int m2l_max_blocks_ = 1; // most stage-1 column blocks any class has (how far a small launch may split the walk)
     // partition
     int part_rank_ = 0, part_world_ = 1;
     std::vector<int64_t> part_rows_, part_bounds_;
