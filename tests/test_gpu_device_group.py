@@ -178,3 +178,50 @@ def test_deterministic_group_is_bitwise_reproducible(case):
     assert np.array_equal(ys[0], ys[1])
     ref.set_weights(w)
     assert relerr(ys[0], ref.evaluate(w, pts)) < TOL
+
+
+@pytest.mark.parametrize("d,adaptive,kind", [(2, True, F.FmmKernelType.ThinPlateSplineRbf), (3, False, F.FmmKernelType.CubicRbf),
+                                             (1, True, F.FmmKernelType.LinearRbf)])
+def test_other_dimensions_and_regular_trees_on_a_group(d, adaptive, kind):
+    """2-D and 1-D clouds and a regular (non-adaptive) tree through a four-part group: no W / X lists in the regular tree, a
+    shallow exchange prefix in 1-D -- the group equals the one-part handle whatever the tree looks like."""
+    rng = np.random.default_rng(40 + d)
+    n = 60000 if d > 1 else 20000
+    pts = rng.random((n, d))
+    kp = F.KernelParams(kind)
+    one = F.FmmTree(pts, 6, kp, adaptive, True)
+    g = F.FmmTree(pts, 6, kp, adaptive, True, devices=[0, 0, 0, 0])
+    w = np.asfortranarray(rng.standard_normal((n, 2)))
+    g.set_weights(w)
+    one.set_weights(w)
+    y, y1 = g.evaluate(w, pts), one.evaluate(w, pts)
+    assert g.last_evaluate_at_sources() == 1 and relerr(y, y1) < 1e-12
+    ym, ym1 = g.fast_matrix_vector_product(w[:, 0].copy()), one.fast_matrix_vector_product(w[:, 0].copy())
+    assert relerr(ym, ym1) < 1e-12
+
+
+def test_a_device_that_does_not_exist_is_refused_with_a_message():
+    import torch
+    nd = torch.cuda.device_count()
+    with pytest.raises(ValueError, match="does not exist"):
+        F.FmmTree(np.random.default_rng(0).random((2000, 3)), 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, devices=[0, nd])
+    t = F.FmmTree(np.random.default_rng(0).random((2000, 3)), 4, F.KernelParams(F.FmmKernelType.LinearRbf), True, True, devices=[0])
+    assert t.device_count() == 1 and t.part_device(0) == 0          # one entry: a plain handle on that device
+
+
+def test_the_solver_drivers_run_on_a_group_handle(case):
+    """bbfmm_fgmres with bbfmm_rbf_system_apply (= bbfmm_fast_matrix_vector_product per iteration, rbf.rs:105-117) on a group
+    handle: the same iterates as on one part (the matvecs agree to 1e-12, so do a few FGMRES iterations)."""
+    from ferreus_rbf_rs_amd import solvers as S
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0, 0])
+    rhs = rng.standard_normal(n)
+    hist = {}
+    for name, t in (("group", g), ("one", one)):
+        op = S.RbfSystemOperator(t, 0, None, 0.0)
+        x, h = S.fgmres(op, rhs, None, None, 1, 4, S.FittingAccuracy(1e-30))
+        hist[name] = (x, [r for _, r in h])
+    assert len(hist["group"][1]) == len(hist["one"][1]) == 4
+    assert np.allclose(hist["group"][1], hist["one"][1], rtol=1e-9)
+    assert relerr(hist["group"][0], hist["one"][0]) < 1e-8
