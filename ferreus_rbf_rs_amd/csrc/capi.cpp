@@ -194,8 +194,11 @@ int bbfmm_set_weights(bbfmm_handle *h, const double *w, int64_t rows, int32_t k,
 
 int bbfmm_set_local_coefficients(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, int64_t ldw) {
     GUARD(h)
-    if (h->group) { // the stored expansions live on the primary: it completes its multipoles first
-        const int rc = group_rc(h, h->group->prepare_primary(h->group->weights_match_staged(w, rows, k, ldw)));
+    if (h->group) { // the weights of set_weights: every part stores the whole-tree expansions (Leaves mode over the group)
+        bool handled = false;
+        int rc = group_rc(h, h->group->set_local_coefficients_all(w, rows, k, ldw, &handled));
+        if (rc != BBFMM_OK || handled) return rc;
+        rc = group_rc(h, h->group->prepare_primary(false)); // other weights: the primary alone
         if (rc != BBFMM_OK) return rc;
     }
     return h->tree.set_local_coefficients(w, rows, k, ldw);
@@ -209,6 +212,8 @@ int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, in
         bool handled = false;
         int rc = group_rc(h, h->group->evaluate_at_sources(w, rows, k, ldw, x, m, ldx, out, ldo, &handled));
         if (rc != BBFMM_OK || handled) return rc;
+        rc = h->group->evaluate_sharded(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, false, bad_point_index, &handled);
+        if (rc != BBFMM_OK || handled) return group_rc(h, rc);
         rc = group_rc(h, h->group->prepare_primary(h->group->weights_match_staged(w, rows, k, ldw)));
         if (rc != BBFMM_OK) return rc;
     }
@@ -221,7 +226,10 @@ int bbfmm_evaluate_with_gradients(bbfmm_handle *h, const double *w, int64_t rows
                                   int64_t ldg, int64_t *bad_point_index) {
     GUARD(h)
     if (h->group) {
-        const int rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
+        bool handled = false;
+        int rc = h->group->evaluate_sharded(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, false, bad_point_index, &handled);
+        if (rc != BBFMM_OK || handled) return group_rc(h, rc);
+        rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
         if (rc != BBFMM_OK) return rc;
     }
     return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, false, bad_point_index);
@@ -232,7 +240,10 @@ int bbfmm_evaluate_leaves(bbfmm_handle *h, const double *w, int64_t rows, int32_
                           int64_t m, int64_t ldx, double *out, int64_t ldo, int64_t *bad_point_index) {
     GUARD(h)
     if (h->group) {
-        const int rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
+        bool handled = false;
+        int rc = h->group->evaluate_sharded(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, true, bad_point_index, &handled);
+        if (rc != BBFMM_OK || handled) return group_rc(h, rc);
+        rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
         if (rc != BBFMM_OK) return rc;
     }
     return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, true, bad_point_index);
@@ -244,7 +255,10 @@ int bbfmm_evaluate_leaves_with_gradients(bbfmm_handle *h, const double *w, int64
                                          double *grad, int64_t ldg, int64_t *bad_point_index) {
     GUARD(h)
     if (h->group) {
-        const int rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
+        bool handled = false;
+        int rc = h->group->evaluate_sharded(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, true, bad_point_index, &handled);
+        if (rc != BBFMM_OK || handled) return group_rc(h, rc);
+        rc = group_rc(h, h->group->prepare_primary(!w || h->group->weights_match_staged(w, rows, k, ldw)));
         if (rc != BBFMM_OK) return rc;
     }
     return h->tree.evaluate(w, rows, k, ldw, x, m, ldx, out, ldo, grad, ldg, true, true, bad_point_index);
@@ -422,7 +436,7 @@ int bbfmm_debug_rows_of_sources(bbfmm_handle *h, const double *x, int64_t m, int
 }
 int bbfmm_last_evaluate_at_sources(const bbfmm_handle *h) {
     if (!h) return 0;
-    if (h->group && h->group->last_path()) return 1;
+    if (h->group && h->group->last_path()) return h->group->last_path(); // 1: partitioned at the sources, 3: targets sharded over the parts
     return h->tree.last_evaluate_path();
 }
 int bbfmm_tree_built_on_device(const bbfmm_handle *h) { return (h && h->tree.tree_built_on_device()) ? 1 : 0; }

@@ -155,6 +155,7 @@ int DeviceGroup::init(FmmTree *primary, const GroupCreateArgs &a, const std::vec
         const char *e = std::getenv("BBFMM_GROUP_THREADS"); // 0: the calling thread queues every part's work (checker)
         threads_ = !e || std::atoi(e) != 0;
     }
+    if (const char *e = std::getenv("BBFMM_GROUP_SHARD_MIN")) shard_min_rows_ = std::max<int64_t>(1, std::atoll(e));
     parts_.resize(static_cast<size_t>(G));
     parts_[0].t = primary;
     bool distinct = true;
@@ -302,6 +303,7 @@ int DeviceGroup::stage(const double *w, int64_t rows, int k, int64_t ldw) {
     (void)rows;
     FmmTree &P = *parts_[0].t;
     staged_k_ = 0;
+    all_complete_ = all_locals_ = false;
     // parts that share a device read its owner's copy: the new weights wait until the last product's parts have read the old
     for (size_t g = 0; g < parts_.size(); ++g) {
         Part &p = parts_[g];
@@ -338,7 +340,7 @@ int DeviceGroup::stage(const double *w, int64_t rows, int k, int64_t ldw) {
 int DeviceGroup::run_upward(int k, const double *d_w_primary, int64_t ld_primary) {
     const int G = n_parts();
     const size_t len = static_cast<size_t>(k) * static_cast<size_t>(cnt_);
-    primary_complete_ = false;
+    primary_complete_ = all_complete_ = all_locals_ = false; // (the parts' coarse multipoles become partial sums, L the restricted pass's)
     pending_k_ = 0;
     int rc = for_parts([&](int g) -> int {
         Part &p = parts_[static_cast<size_t>(g)];
@@ -452,6 +454,7 @@ int DeviceGroup::evaluate_at_sources(const double *w, int64_t rows, int k, int64
     last_path_ = 0;
     FmmTree &P = *parts_[0].t;
     if (!sources_fast || staged_k_ < 1 || k != staged_k_ || m != n_ || !x || !out || ldx < m || ldo < m) return BBFMM_OK;
+    if (all_locals_ || P.locals_requested_) return BBFMM_OK; // Leaves mode: the partitioned downward pass would overwrite the stored expansions
     static const bool verbose = std::getenv("BBFMM_VERBOSE") != nullptr;
     const auto t_0 = std::chrono::steady_clock::now();
     if (!P.targets_are_sources(x, m, ldx)) return BBFMM_OK;
@@ -514,6 +517,7 @@ int DeviceGroup::matvec_device(const double *d_w, int64_t ldw, int k, double *d_
     last_path_ = 0;
     CHK(ensure_capacity(k, true));
     staged_k_ = 0; // the owners' staging buffers are overwritten with the caller's device weights
+    all_complete_ = all_locals_ = false;
     P.bind_device();
     GHIP(hipEventRecord(ev_in_, P.stream_));
     for (int g = 1; g < G; ++g) {
@@ -561,6 +565,78 @@ int DeviceGroup::matvec_device(const double *d_w, int64_t ldw, int k, double *d_
     return BBFMM_OK;
 }
 
+// The whole upward pass on every part, each from its device's copy of the staged weights.
+int DeviceGroup::complete_all(int k) {
+    if (all_complete_) return BBFMM_OK;
+    const int rc = for_parts([&](int g) -> int {
+        Part &p = parts_[static_cast<size_t>(g)];
+        const Part &o = parts_[static_cast<size_t>(p.owner)];
+        if (p.owner != g) PHIP(hipStreamWaitEvent(p.t->stream_, o.ev_w, 0));
+        const int prc = p.t->complete_upward_from(o.t->d_w_in_.p, k);
+        if (prc != BBFMM_OK) return prc;
+        PHIP(hipEventRecord(p.ev_up, p.t->stream_)); // (the part has read the staged copy)
+        return BBFMM_OK;
+    });
+    if (rc != BBFMM_OK) return rc;
+    parts_[0].t->pin_w_k_ = staged_k_;
+    all_complete_ = primary_complete_ = true;
+    pending_k_ = 0;
+    return BBFMM_OK;
+}
+
+int DeviceGroup::evaluate_sharded(const double *w, int64_t rows, int k, int64_t ldw, const double *x, int64_t m, int64_t ldx, double *out,
+                                  int64_t ldo, double *grad, int64_t ldg, bool with_grads, bool leaves_only, int64_t *bad_point_index,
+                                  bool *handled) {
+    *handled = false;
+    const int G = n_parts();
+    last_path_ = 0;
+    if (staged_k_ < 1 || k != staged_k_ || m < shard_min_rows_ * G || !x || !out || ldx < m || ldo < m) return BBFMM_OK;
+    if (with_grads && (!grad || ldg < m)) return BBFMM_OK;
+    if (w ? !weights_match_staged(w, rows, k, ldw) : !leaves_only) return BBFMM_OK; // other weights: the primary's mixture
+    if (leaves_only && !all_locals_) return BBFMM_OK;
+    if (!leaves_only) CHK(complete_all(k));
+    std::vector<int64_t> bad(static_cast<size_t>(G), -1);
+    std::vector<int> prc(static_cast<size_t>(G), BBFMM_OK);
+    const int rc = for_parts([&](int g) -> int {
+        FmmTree &t = *parts_[static_cast<size_t>(g)].t;
+        const int64_t r0 = m * g / G, r1 = m * (g + 1) / G;
+        t.group_weights_resident_ = true;
+        prc[static_cast<size_t>(g)] = t.evaluate(w, rows, k, ldw, x + r0, r1 - r0, ldx, out + r0, ldo, grad ? grad + r0 : nullptr, ldg, with_grads,
+                                                 leaves_only, &bad[static_cast<size_t>(g)]);
+        t.group_weights_resident_ = false;
+        return BBFMM_OK; // (the parts' verdicts are combined below: the first offending row of the whole call wins)
+    });
+    if (rc != BBFMM_OK) return rc;
+    for (int g = 0; g < G; ++g) { // parts in row order: the first failure is the one the reference would report
+        const int e = prc[static_cast<size_t>(g)];
+        if (e == BBFMM_OK) continue;
+        if (e == BBFMM_POINT_OUTSIDE_TREE && bad_point_index) *bad_point_index = m * g / G + bad[static_cast<size_t>(g)];
+        *handled = true;
+        return part_fail(parts_[static_cast<size_t>(g)], e);
+    }
+    *handled = true;
+    last_path_ = 3;
+    return BBFMM_OK;
+}
+
+int DeviceGroup::set_local_coefficients_all(const double *w, int64_t rows, int k, int64_t ldw, bool *handled) {
+    *handled = false;
+    all_locals_ = false;
+    if (staged_k_ < 1 || k != staged_k_ || !weights_match_staged(w, rows, k, ldw)) return BBFMM_OK;
+    CHK(complete_all(k));
+    const int rc = for_parts([&](int g) -> int {
+        FmmTree &t = *parts_[static_cast<size_t>(g)].t;
+        t.group_weights_resident_ = true;
+        const int prc = t.set_local_coefficients(w, rows, k, ldw);
+        t.group_weights_resident_ = false;
+        return prc;
+    });
+    if (rc != BBFMM_OK) return rc;
+    all_locals_ = true;
+    *handled = true;
+    return BBFMM_OK;
+}
+
 int DeviceGroup::prepare_primary(bool same_weights) {
     FmmTree &P = *parts_[0].t;
     last_path_ = 0;
@@ -572,7 +648,10 @@ int DeviceGroup::prepare_primary(bool same_weights) {
         primary_complete_ = true;
         pending_k_ = 0;
     }
-    if (!same_weights) staged_k_ = 0; // the primary is about to stage others (the reference's mixture: old multipoles, new near field)
+    if (!same_weights) { // the primary is about to stage others (the reference's mixture: old multipoles, new near field)
+        staged_k_ = 0;
+        all_complete_ = all_locals_ = false;
+    }
     return BBFMM_OK;
 }
 

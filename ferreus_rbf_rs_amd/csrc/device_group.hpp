@@ -16,9 +16,10 @@
 //               device callers: blocks peer-copied to the primary, one scatter pass there
 //
 // No collective is supplied by the caller and no second process exists.  Parts may share a device ("0,0,0": logical
-// parts, the one-GPU rehearsal of the N-device path; peer copies degenerate to device copies).  Everything the group does
-// not partition (arbitrary targets, gradients, target subsets, stored local expansions) is served by part 0 alone after
-// it has completed its multipoles from the staged weights.
+// parts, the one-GPU rehearsal of the N-device path; peer copies degenerate to device copies).  Arbitrary targets (values,
+// gradients, Leaves mode) with the weights of set_weights are sharded by target rows: every part completes its own
+// multipoles from its device's copy of the staged weights and evaluates a contiguous share.  What remains (few targets,
+// other weights than set_weights', target subsets) is served by part 0 alone after it has completed its multipoles.
 #pragma once
 #include <memory>
 #include <string>
@@ -64,10 +65,19 @@ class DeviceGroup {
     int fast_matrix_vector_product(const double *w, int64_t rows, int64_t basis_size, const double *poly, int64_t ldp, double nugget,
                                    double *result);
     int matvec_device(const double *d_w, int64_t ldw, int k, double *d_out, int64_t ldo, bool sync);
+    // Arbitrary targets (Full mode, gradients, Leaves mode) with the weights of set_weights: part g evaluates the g-th
+    // contiguous share of the target rows on its device from complete multipoles of its own (every part runs the whole
+    // upward pass from its device's copy of the staged weights: replicated, side by side).  *handled = false: too few
+    // targets, other weights, or no stored expansions on the parts -- the caller serves the call on the primary.
+    int evaluate_sharded(const double *w, int64_t rows, int k, int64_t ldw, const double *x, int64_t m, int64_t ldx, double *out,
+                         int64_t ldo, double *grad, int64_t ldg, bool with_grads, bool leaves_only, int64_t *bad_point_index,
+                         bool *handled);
+    // set_local_coefficients on every part (Leaves mode over the group); *handled = false: other weights than set_weights'
+    int set_local_coefficients_all(const double *w, int64_t rows, int k, int64_t ldw, bool *handled);
     // Before a call that part 0 serves alone.  same_weights: the call brings the weights of set_weights (or none).
     int prepare_primary(bool same_weights);
     // the primary has been given other weights / another product behind the group's back: nothing staged is valid any more
-    void primary_state_changed() { staged_k_ = 0; pending_k_ = 0; primary_complete_ = true; }
+    void primary_state_changed() { staged_k_ = 0; pending_k_ = 0; primary_complete_ = true; all_complete_ = all_locals_ = false; }
     bool weights_match_staged(const double *w, int64_t rows, int k, int64_t ldw) const;
     int last_path() const { return last_path_; } // 1: the last evaluate ran partitioned over the group, 0: on the primary
     void set_profiling(bool on);
@@ -113,6 +123,10 @@ class DeviceGroup {
     int staged_k_ = 0;              // the pinned buffer of the primary and every owner's d_w_in_ hold the weights of set_weights
     int pending_k_ = 0;             // upward + exchange queued for them, not consumed yet
     bool primary_complete_ = false; // the primary holds the complete multipoles of the staged weights
+    bool all_complete_ = false;     // every part does
+    bool all_locals_ = false;       // every part holds the whole-tree local expansions of the staged weights (Leaves mode)
+    int64_t shard_min_rows_ = 16384; // targets per part below which a call is not worth sharding (BBFMM_GROUP_SHARD_MIN)
+    int complete_all(int k);
     bool threads_ = true;
     int last_path_ = 0;
 };

@@ -725,6 +725,7 @@ template <class F> int FmmTree::download_pieces(const double *d_src, int64_t tot
 // recognised by a threaded bit-for-bit comparison and pays no second transfer.
 int FmmTree::put_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     const int64_t N = tree_.n_points;
+    if (group_weights_resident_ && k == nrhs_) return BBFMM_OK; // (a device group has checked them against its staged copy)
     if (!w || rows < N || ldw < rows || k < 1) return fail(BBFMM_BAD_ARGUMENT, "weights must be rows x k with rows >= N");
     if (weights_match_staged(w, k, ldw)) return BBFMM_OK;
     if (static_cast<size_t>(2) * k * N > kMaxPinnedDoubles) {
@@ -1428,13 +1429,18 @@ int FmmTree::ensure_w_in(int k) {
 }
 
 int FmmTree::complete_upward_from_staged(int k) {
+    if (k < 1 || static_cast<size_t>(k) * tree_.n_points > d_w_in_.n) return fail(BBFMM_BAD_ARGUMENT, "no staged weights");
+    return complete_upward_from(d_w_in_.p, k);
+}
+
+int FmmTree::complete_upward_from(const double *d_w, int k) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     const int64_t N = tree_.n_points;
-    if (k < 1 || static_cast<size_t>(k) * N > d_w_in_.n) return fail(BBFMM_BAD_ARGUMENT, "no staged weights");
+    if (k < 1 || !d_w) return fail(BBFMM_BAD_ARGUMENT, "no staged weights");
     part_pending_k_ = 0;
     CHK(ensure_rhs_capacity(k));
     phase_begin();
-    launch_gather_weights(d_w_in_.p, N, k, d_order_.p, N, d_w_sorted_.p, stream_);
+    launch_gather_weights(d_w, N, k, d_order_.p, N, d_w_sorted_.p, stream_);
     phase_end(kPhGather);
     nrhs_ = k;
     have_locals_ = locals_requested_ = false;

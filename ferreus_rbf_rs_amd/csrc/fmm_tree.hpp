@@ -422,6 +422,11 @@ class FmmTree {
     // the whole upward pass from the weights staged in d_w_in_ (a device group's primary before a product the group does
     // not partition: arbitrary targets, target subsets, stored local expansions)
     int complete_upward_from_staged(int k);
+    // the same from a copy of the staged weights that lives elsewhere on this device (k rows of N, the group's owner part)
+    int complete_upward_from(const double *d_w, int k);
+    // the sorted weights on the device ARE the caller's (a device group has compared them with the staged copy): evaluate /
+    // set_local_coefficients skip their transfer while this is set
+    bool group_weights_resident_ = false;
     int stage_weights_to_device(const double *w, int64_t n, int k, int64_t ldw); // host rows -> d_w_in_, staging and PCIe overlapped
     template <class F> int download_pieces(const double *d_src, int64_t total, double *pin_out, F &&consume);
     // h_pin_[0, pin_w_k_ * N) holds exactly the host weights d_w_sorted_ was gathered from (0: no such copy)

@@ -426,8 +426,9 @@ class FmmTree:
         return rows if ok else None
 
     def last_evaluate_path(self) -> int:
-        """0: the general path; 1: targets = the sources (resident target set); 2: targets = rows of the sources (cached
-        plan of the index set) -- bbfmm_last_evaluate_at_sources"""
+        """0: the general path; 1: targets = the sources (resident target set; partitioned over the parts of a device group);
+        2: targets = rows of the sources (cached plan of the index set); 3: arbitrary targets sharded over the parts of a
+        device group -- bbfmm_last_evaluate_at_sources"""
         return int(self._lib.bbfmm_last_evaluate_at_sources(self._h))
 
     def debug_targets_are_sources(self, target_points) -> bool:

@@ -133,8 +133,11 @@ int bbfmm_create(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t in
  * bbfmm_matvec_device run partitioned over the parts: weights to every device over its own link, own-subtree upward
  * pass, the partial coarse multipoles copied to a slot on every device (peer copies beside the near field) and added in
  * part order, restricted downward + leaf pass, the owned blocks of the potentials straight back to the host (or, for
- * device callers, to the first device).  No caller-supplied collective, no second process.  Everything else (arbitrary
- * targets, gradients, row subsets, stored local expansions) is served by the first device alone, with unchanged results.
+ * device callers, to the first device).  No caller-supplied collective, no second process.  Arbitrary targets (values,
+ * gradients, Leaves mode after bbfmm_set_local_coefficients) with the weights of bbfmm_set_weights are SHARDED by target rows
+ * when there are at least 16384 per part (BBFMM_GROUP_SHARD_MIN): every part completes its own multipoles from its
+ * device's copy of the weights and evaluates a contiguous share of the rows (bbfmm_last_evaluate_at_sources: 3).  Everything
+ * else (few targets, other weights than set_weights', row subsets) is served by the first device alone, with unchanged results.
  *   devices    n_devices HIP device ids; the first one holds the handle's own tree (introspection, bbfmm_stream,
  *              device-resident vectors).  An id may repeat: logical parts on one device -- the one-GPU rehearsal of the
  *              N-device path (peer copies become device copies).  One entry: a plain handle on that device.

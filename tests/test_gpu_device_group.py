@@ -225,3 +225,55 @@ def test_the_solver_drivers_run_on_a_group_handle(case):
     assert len(hist["group"][1]) == len(hist["one"][1]) == 4
     assert np.allclose(hist["group"][1], hist["one"][1], rtol=1e-9)
     assert relerr(hist["group"][0], hist["one"][0]) < 1e-8
+
+
+def test_arbitrary_targets_are_sharded_over_the_parts(case, monkeypatch):
+    """Evaluator use (many targets that are no sources; rbf.rs:677-690, 836-838): with the weights of set_weights every part
+    completes its own multipoles and evaluates a contiguous share of the target rows -- values, gradients and Leaves mode
+    equal the one-part handle's; a target outside the tree is reported with the smallest offending row of the WHOLE call."""
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    monkeypatch.setenv("BBFMM_GROUP_SHARD_MIN", "2000")             # (read when the group is created; default 16384 rows per part)
+    g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0, 0])
+    w = np.asfortranarray(rng.standard_normal((n, 2)))
+    x = rng.random((9001, 3))
+    g.set_weights(w)
+    one.set_weights(w)
+    y, y1 = g.evaluate(w, x), one.evaluate(w, x)
+    assert g.last_evaluate_path() == 3 and relerr(y, y1) < 1e-12
+    ref.set_weights(w)
+    assert relerr(y, ref.evaluate(w, x)) < TOL
+    v, gr = g.evaluate_with_gradients(w, x)
+    v1, gr1 = one.evaluate_with_gradients(w, x)
+    assert g.last_evaluate_path() == 3 and relerr(v, v1) < 1e-12 and relerr(gr, gr1) < 1e-10
+    # few targets: not worth sharding
+    g.evaluate(w, x[:500])
+    assert g.last_evaluate_path() == 0
+    # the at-sources product still runs partitioned afterwards, and another sharded call after that
+    assert relerr(g.evaluate(w, pts), one.evaluate(w, pts)) < 1e-12 and g.last_evaluate_path() == 1
+    assert relerr(g.evaluate(w, x), y1) < 1e-12 and g.last_evaluate_path() == 3
+    # Leaves mode over the group; weights resident (w = None) and passed again
+    g.set_local_coefficients(w)
+    one.set_local_coefficients(w)
+    z1 = one.evaluate_leaves(w, x)
+    assert relerr(g.evaluate_leaves(w, x), z1) < 1e-12 and g.last_evaluate_path() == 3
+    assert relerr(g.evaluate_leaves(None, x), z1) < 1e-12
+    zg, gg = g.evaluate_leaves_with_gradients(w, x)
+    z1g, g1g = one.evaluate_leaves_with_gradients(w, x)
+    assert relerr(zg, z1g) < 1e-12 and relerr(gg, g1g) < 1e-10
+    # Leaves mode: an evaluate at the sources must not destroy the stored expansions (it is not partitioned then)
+    assert relerr(g.evaluate(w, pts), one.evaluate(w, pts)) < 1e-12
+    assert relerr(g.evaluate_leaves(w, x), z1) < 1e-12
+    # a target outside the tree, in the last part's share and one in the second part's: the smaller row is reported
+    xb = x.copy()
+    xb[8000] = [5.0, 5.0, 5.0]
+    xb[4000] = [7.0, 0.5, 0.5]
+    g.set_weights(w)
+    with pytest.raises(F.PointOutsideTree) as e:
+        g.evaluate(w, xb)
+    assert e.value.point_index == 4000
+    # other weights than set_weights': the reference's mixture, on the first device
+    w2 = np.asfortranarray(rng.standard_normal((n, 2)))
+    g.set_weights(w)
+    one.set_weights(w)
+    assert relerr(g.evaluate(w2, x), one.evaluate(w2, x)) < 1e-12 and g.last_evaluate_path() == 0
