@@ -212,6 +212,8 @@ int bbfmm_evaluate(bbfmm_handle *h, const double *w, int64_t rows, int32_t k, in
         bool handled = false;
         int rc = group_rc(h, h->group->evaluate_at_sources(w, rows, k, ldw, x, m, ldx, out, ldo, &handled));
         if (rc != BBFMM_OK || handled) return rc;
+        rc = h->group->evaluate_rows_of_sources(w, rows, k, ldw, x, m, ldx, out, &handled); // the unchanged caller's matvec_partial
+        if (rc != BBFMM_OK || handled) return group_rc(h, rc);
         rc = h->group->evaluate_sharded(w, rows, k, ldw, x, m, ldx, out, ldo, nullptr, 0, false, false, bad_point_index, &handled);
         if (rc != BBFMM_OK || handled) return group_rc(h, rc);
         rc = group_rc(h, h->group->prepare_primary(h->group->weights_match_staged(w, rows, k, ldw)));
@@ -282,7 +284,8 @@ int bbfmm_fast_matrix_vector_product(bbfmm_handle *h, const double *w, int64_t r
     if (h->group) {
         if (!target_indices || h->tree.is_identity_subset(target_indices, n_target_indices))
             return group_rc(h, h->group->fast_matrix_vector_product(w, rows, basis_size, poly, ldp, nugget, result));
-        h->group->primary_state_changed(); // a row subset: the primary alone (whole upward pass, cached subset plan)
+        // a row subset (matvec_partial, rbf.rs:119-133): every part takes the rows of the set it owns
+        return group_rc(h, h->group->fast_matvec_subset(w, rows, basis_size, target_indices, n_target_indices, poly, ldp, nugget, result));
     }
     return h->tree.fast_matrix_vector_product(w, rows, basis_size, target_indices, n_target_indices, poly, ldp, nugget,
                                               result);

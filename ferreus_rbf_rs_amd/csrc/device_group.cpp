@@ -337,7 +337,7 @@ int DeviceGroup::stage(const double *w, int64_t rows, int k, int64_t ldw) {
     return BBFMM_OK;
 }
 
-int DeviceGroup::run_upward(int k, const double *d_w_primary, int64_t ld_primary) {
+int DeviceGroup::run_upward(int k, const double *d_w_primary, int64_t ld_primary, bool near_field) {
     const int G = n_parts();
     const size_t len = static_cast<size_t>(k) * static_cast<size_t>(cnt_);
     primary_complete_ = all_complete_ = all_locals_ = false; // (the parts' coarse multipoles become partial sums, L the restricted pass's)
@@ -356,7 +356,7 @@ int DeviceGroup::run_upward(int k, const double *d_w_primary, int64_t ld_primary
         } else if (p.owner != g) {
             PHIP(hipStreamWaitEvent(t.stream_, o.ev_w, 0));
         }
-        const int prc = t.matvec_partition_upward(dw, ld, k, p.d_send, p.comm);
+        const int prc = t.matvec_partition_upward(dw, ld, k, p.d_send, p.comm, near_field);
         if (prc != BBFMM_OK) return prc;
         PHIP(hipEventRecord(p.ev_up, t.stream_));
         if (len > 0) {
@@ -385,7 +385,134 @@ int DeviceGroup::run_upward(int k, const double *d_w_primary, int64_t ld_primary
         });
         if (rc != BBFMM_OK) return rc;
     }
-    pending_k_ = k;
+    pending_k_ = near_field ? k : -k; // (negative: the owned targets' near field was not queued -- a partial product's upward pass)
+    return BBFMM_OK;
+}
+
+// An index set dealt to the parts: row r belongs to the part that owns its sorted position.  Cached (8 sets, least
+// recently used evicted): the Schwarz sweep asks for the same five sets in every apply.
+int DeviceGroup::subset_split(const int64_t *idx, int64_t n_idx, SubsetSplit **out) {
+    FmmTree &P = *parts_[0].t;
+    const uint64_t key = P.subset_key(idx, n_idx);
+    ++split_clock_;
+    for (auto &sp : splits_)
+        if (sp->key == key && static_cast<int64_t>(sp->idx.size()) == n_idx &&
+            (n_idx == 0 || std::memcmp(sp->idx.data(), idx, static_cast<size_t>(n_idx) * sizeof(int64_t)) == 0)) {
+            sp->last_use = split_clock_;
+            *out = sp.get();
+            return BBFMM_OK;
+        }
+    for (int64_t j = 0; j < n_idx; ++j)
+        if (idx[j] < 0 || idx[j] >= n_) return fail(BBFMM_BAD_ARGUMENT, "target index out of range");
+    if (splits_.size() >= 8) {
+        size_t victim = 0;
+        for (size_t i = 1; i < splits_.size(); ++i)
+            if (splits_[i]->last_use < splits_[victim]->last_use) victim = i;
+        splits_.erase(splits_.begin() + static_cast<std::ptrdiff_t>(victim));
+    }
+    const int G = n_parts();
+    std::unique_ptr<SubsetSplit> sp(new SubsetSplit());
+    sp->key = key;
+    sp->last_use = split_clock_;
+    sp->idx.assign(idx, idx + n_idx);
+    sp->rows.resize(static_cast<size_t>(G));
+    sp->where.resize(static_cast<size_t>(G));
+    for (int64_t j = 0; j < n_idx; ++j) {
+        const int64_t pos = inv_order_[static_cast<size_t>(idx[j])];
+        const int g = static_cast<int>(std::upper_bound(bounds_.begin() + 1, bounds_.end() - 1, pos) - (bounds_.begin() + 1));
+        sp->rows[static_cast<size_t>(g)].push_back(idx[j]);
+        sp->where[static_cast<size_t>(g)].push_back(j);
+    }
+    sp->offset.assign(static_cast<size_t>(G) + 1, 0);
+    for (int g = 0; g < G; ++g) sp->offset[static_cast<size_t>(g) + 1] = sp->offset[static_cast<size_t>(g)] + static_cast<int64_t>(sp->rows[static_cast<size_t>(g)].size());
+    *out = sp.get();
+    splits_.push_back(std::move(sp));
+    return BBFMM_OK;
+}
+
+// The parts' shares of a partial product behind the staged weights: upward + exchange unless one is pending, then every
+// part's restricted passes on its rows of the set; consume(j, row, value) for every row once all blocks are home.
+template <class F> int DeviceGroup::subset_product(SubsetSplit *sp, bool upward_pending, F &&consume) {
+    FmmTree &P = *parts_[0].t;
+    if (!upward_pending) CHK(run_upward(1, nullptr, 0, false));
+    double *h_out = P.h_pin_ + n_; // (behind the staged weights; sized 2 N by the staging)
+    const int rc = for_parts([&](int g) -> int {
+        Part &p = parts_[static_cast<size_t>(g)];
+        const std::vector<int64_t> &r = sp->rows[static_cast<size_t>(g)];
+        const int prc = p.t->partition_subset_finish(p.d_sum, r.data(), static_cast<int64_t>(r.size()), h_out + sp->offset[static_cast<size_t>(g)], p.comm);
+        if (prc != BBFMM_OK) return prc;
+        PHIP(hipEventRecord(p.ev_done, p.t->stream_));
+        return BBFMM_OK;
+    });
+    pending_k_ = 0;
+    if (rc != BBFMM_OK) return rc;
+    for (Part &p : parts_) {
+        p.t->bind_device();
+        GHIP(hipEventSynchronize(p.ev_done));
+    }
+    P.bind_device();
+    const int G = n_parts();
+    for (int g = 0; g < G; ++g) {
+        const std::vector<int64_t> &r = sp->rows[static_cast<size_t>(g)], &wh = sp->where[static_cast<size_t>(g)];
+        const double *h = h_out + sp->offset[static_cast<size_t>(g)];
+        parallel_for_chunks(static_cast<int64_t>(r.size()), int64_t(1) << 15, [&](int64_t b, int64_t e) {
+            for (int64_t j = b; j < e; ++j) consume(wh[static_cast<size_t>(j)], r[static_cast<size_t>(j)], h[j]);
+        });
+    }
+    return BBFMM_OK;
+}
+
+int DeviceGroup::fast_matvec_subset(const double *w, int64_t rows, int64_t basis_size, const int64_t *idx, int64_t n_idx, const double *poly,
+                                    int64_t ldp, double nugget, double *result) {
+    const int64_t N = n_;
+    if (!w || !result || basis_size < 0 || rows != N + basis_size) return fail(BBFMM_BAD_ARGUMENT, "weights must have N + basis_size rows");
+    if (poly && ldp < N) return fail(BBFMM_BAD_ARGUMENT, "polynomial matrix needs N rows");
+    if (!idx || n_idx < 0) return fail(BBFMM_BAD_ARGUMENT, "bad target index array");
+    last_path_ = 0;
+    if (static_cast<size_t>(2) * N > FmmTree::kMaxPinnedDoubles) return fail(BBFMM_UNSUPPORTED, "too many points for the pinned mirror of a device group");
+    SubsetSplit *sp = nullptr;
+    CHK(subset_split(idx, n_idx, &sp));
+    std::fill(result, result + rows, 0.0); // rbf.rs:1346
+    if (n_idx == 0) return BBFMM_OK;
+    CHK(ensure_capacity(1, false));
+    CHK(stage(w, N, 1, N));
+    CHK(subset_product(sp, false, [&](int64_t, int64_t i, double v) { // rbf.rs:1366-1376
+        double r = v + w[i] * nugget;
+        if (poly) {
+            double sacc = 0.0;
+            for (int64_t q = 0; q < basis_size; ++q) sacc += poly[q * ldp + i] * w[N + q];
+            r += sacc;
+        }
+        result[i] = r;
+    }));
+    last_path_ = 2;
+    return BBFMM_OK;
+}
+
+int DeviceGroup::evaluate_rows_of_sources(const double *w, int64_t rows, int k, int64_t ldw, const double *x, int64_t m, int64_t ldx, double *out,
+                                          bool *handled) {
+    *handled = false;
+    FmmTree &P = *parts_[0].t;
+    last_path_ = 0;
+    // (the conditions under which a single handle looks its targets up: a solver's tree, one rhs, N / 2048 .. N / 2 rows)
+    if (!P.solver_tree_ || k != 1 || staged_k_ != 1 || !w || !x || !out || ldx < m || m >= n_ || m < std::max<int64_t>(1024, n_ / 2048) ||
+        m > n_ / 2 || n_ > (int64_t(1) << 26) || all_locals_ || P.locals_requested_)
+        return BBFMM_OK;
+    if (!weights_match_staged(w, rows, 1, ldw)) return BBFMM_OK;
+    std::vector<int64_t> rows_of;
+    if (!P.targets_are_rows_of_sources(x, m, ldx, &rows_of)) return BBFMM_OK;
+    const uint64_t key = P.subset_key(rows_of.data(), m);
+    bool known = key == last_rows_miss_;
+    for (const auto &sp : splits_) known = known || (sp->key == key && static_cast<int64_t>(sp->idx.size()) == m);
+    if (!known) { // first sighting of the set: no plans for a caller that may never come back (as on one device)
+        last_rows_miss_ = key;
+        return BBFMM_OK;
+    }
+    SubsetSplit *sp = nullptr;
+    CHK(subset_split(rows_of.data(), m, &sp));
+    CHK(subset_product(sp, pending_k_ == 1 || pending_k_ == -1, [&](int64_t j, int64_t, double v) { out[j] = v; }));
+    *handled = true;
+    last_path_ = 2;
     return BBFMM_OK;
 }
 

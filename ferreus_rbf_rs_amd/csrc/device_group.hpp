@@ -18,8 +18,9 @@
 // No collective is supplied by the caller and no second process exists.  Parts may share a device ("0,0,0": logical
 // parts, the one-GPU rehearsal of the N-device path; peer copies degenerate to device copies).  Arbitrary targets (values,
 // gradients, Leaves mode) with the weights of set_weights are sharded by target rows: every part completes its own
-// multipoles from its device's copy of the staged weights and evaluates a contiguous share.  What remains (few targets,
-// other weights than set_weights', target subsets) is served by part 0 alone after it has completed its multipoles.
+// multipoles from its device's copy of the staged weights and evaluates a contiguous share.  Row subsets (matvec_partial) are
+// dealt to the parts that own the rows.  What remains (few targets, other weights than set_weights') is served by part 0
+// alone after it has completed its multipoles.
 #pragma once
 #include <memory>
 #include <string>
@@ -74,6 +75,16 @@ class DeviceGroup {
                          bool *handled);
     // set_local_coefficients on every part (Leaves mode over the group); *handled = false: other weights than set_weights'
     int set_local_coefficients_all(const double *w, int64_t rows, int k, int64_t ldw, bool *handled);
+    // matvec_partial (rbf.rs:119-133) over the group: the rows `idx` are dealt to the parts that own them (the split is cached
+    // by index set), every part runs its share of the upward pass, the exchange, and the restricted downward + leaf pass of
+    // ITS rows of the set.  result: N + basis_size values, zero except the rows of idx (rbf.rs:1346, 1366-1376).
+    int fast_matvec_subset(const double *w, int64_t rows, int64_t basis_size, const int64_t *idx, int64_t n_idx, const double *poly,
+                           int64_t ldp, double nugget, double *result);
+    // the unchanged caller's form of it: set_weights(w), then evaluate(w, select_mat_rows(source_points, idx)) -- targets that
+    // are rows of the sources (found bit for bit by the primary's table), one rhs, the weights of set_weights.
+    // *handled = false: not such a call.
+    int evaluate_rows_of_sources(const double *w, int64_t rows, int k, int64_t ldw, const double *x, int64_t m, int64_t ldx, double *out,
+                                 bool *handled);
     // Before a call that part 0 serves alone.  same_weights: the call brings the weights of set_weights (or none).
     int prepare_primary(bool same_weights);
     // the primary has been given other weights / another product behind the group's back: nothing staged is valid any more
@@ -106,7 +117,7 @@ class DeviceGroup {
     int stage(const double *w, int64_t rows, int k, int64_t ldw);
     // upward pass of every part + the exchange, from the weights at d_w (leading dimension ld) on the primary's device and
     // from the owners' staged copies elsewhere (d_w == nullptr: staged copies everywhere)
-    int run_upward(int k, const double *d_w_primary, int64_t ld_primary);
+    int run_upward(int k, const double *d_w_primary, int64_t ld_primary, bool near_field = true);
     template <class F> int finish_to_host(int k, F &&consume);
     template <class F> int for_parts(F &&fn);
     void free_buffers();
@@ -127,6 +138,17 @@ class DeviceGroup {
     bool all_locals_ = false;       // every part holds the whole-tree local expansions of the staged weights (Leaves mode)
     int64_t shard_min_rows_ = 16384; // targets per part below which a call is not worth sharding (BBFMM_GROUP_SHARD_MIN)
     int complete_all(int k);
+    struct SubsetSplit { // an index set dealt to the parts that own its rows
+        uint64_t key = 0, last_use = 0;
+        std::vector<int64_t> idx;                  // the set itself (a hash hit is confirmed by comparing it)
+        std::vector<std::vector<int64_t>> rows;    // per part: its rows of the set ...
+        std::vector<std::vector<int64_t>> where;   // ... and their positions in idx
+        std::vector<int64_t> offset;               // per part: first value of its block in the pinned buffer
+    };
+    std::vector<std::unique_ptr<SubsetSplit>> splits_;
+    uint64_t split_clock_ = 0, last_rows_miss_ = 0;
+    int subset_split(const int64_t *idx, int64_t n_idx, SubsetSplit **out);
+    template <class F> int subset_product(SubsetSplit *sp, bool upward_pending, F &&consume);
     bool threads_ = true;
     int last_path_ = 0;
 };

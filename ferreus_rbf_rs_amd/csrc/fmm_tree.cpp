@@ -1306,7 +1306,7 @@ int64_t FmmTree::partition_coarse_count() const {
 
 // First half of the partitioned matvec: set_weights restricted to this rank's share of the upward pass
 // (bbfmm.rs:383-401, 666-772 split by subtree), partial coarse multipoles packed rhs-major into d_coarse.
-int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse, hipStream_t comm_stream) {
+int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse, hipStream_t comm_stream, bool near_field) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     if (!have_part_) return fail(BBFMM_BAD_ARGUMENT, "bbfmm_set_partition (world > 1) must be called first");
     const int64_t N = tree_.n_points, C = tree_.n_cells();
@@ -1337,8 +1337,38 @@ int FmmTree::matvec_partition_upward(const double *d_w, int64_t ldw, int k, doub
         HIPCHK(hipEventRecord(ev_pack_, stream_));
         HIPCHK(hipStreamWaitEvent(comm_stream, ev_pack_, 0));
     }
-    CHK(leaf_pass_near(part_targets_, k, false, stream_, 1));
-    part_pending_k_ = k;
+    if (near_field) CHK(leaf_pass_near(part_targets_, k, false, stream_, 1));
+    part_pending_k_ = near_field ? k : -k; // (negative: upward done, the owned targets' near field not queued)
+    return BBFMM_OK;
+}
+
+int FmmTree::partition_subset_finish(const double *d_coarse, const int64_t *idx, int64_t n_idx, double *h_out, hipStream_t comm_stream) {
+    if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
+    if (!have_part_ || (part_pending_k_ != 1 && part_pending_k_ != -1)) return fail(BBFMM_BAD_ARGUMENT, "bbfmm_matvec_partition_upward (one rhs) must be called first");
+    if (n_idx < 0 || (n_idx > 0 && (!idx || !h_out))) return fail(BBFMM_BAD_ARGUMENT, "bad partial product arguments");
+    const int64_t C = tree_.n_cells();
+    const int64_t cnt = partition_coarse_count();
+    if (cnt > 0 && !d_coarse) return fail(BBFMM_BAD_ARGUMENT, "bad partitioned matvec arguments");
+    part_pending_k_ = 0;
+    SubsetPlan *sp = nullptr;
+    if (n_idx > 0) CHK(subset_plan(idx, n_idx, &sp)); // (before anything is queued: a bad index leaves the handle as it was)
+    if (comm_stream) {
+        HIPCHK(hipEventRecord(ev_comm_, comm_stream));
+        HIPCHK(hipStreamWaitEvent(stream_, ev_comm_, 0));
+    }
+    phase_begin();
+    if (cnt > 0)
+        HIPCHK(hipMemcpyAsync(d_M_.p, d_coarse, static_cast<size_t>(cnt) * sizeof(double), hipMemcpyDeviceToDevice, stream_));
+    phase_end(kPhM2M);
+    (void)C;
+    if (n_idx == 0) return BBFMM_OK;
+    CHK(downward(1, &sp->dp));
+    CHK(leaf_pass(sp->ts, 1, false));
+    phase_begin();
+    launch_scatter_output(sp->ts.out.p, n_idx, 1, sp->ts.perm.p, d_out_.p, n_idx, 0, stream_);
+    HIPCHK(hipMemcpyAsync(h_out, d_out_.p, static_cast<size_t>(n_idx) * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    phase_end(kPhScatter);
+    HIPCHK(hipGetLastError());
     return BBFMM_OK;
 }
 

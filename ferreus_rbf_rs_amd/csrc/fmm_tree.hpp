@@ -171,7 +171,13 @@ class FmmTree {
     // comm_stream (may be null): the stream the caller runs the all-reduce on.  It is made to wait for the packed
     // multipoles only, so that the collective overlaps the near field queued behind the pack; finish makes the handle's
     // stream wait for it.  Null: the caller orders the collective after the handle's stream itself.
-    int matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse, hipStream_t comm_stream);
+    // near_field = false: the near field of the owned targets is not queued (a device group's partial product evaluates a
+    // subset of them: partition_subset_finish)
+    int matvec_partition_upward(const double *d_w, int64_t ldw, int k, double *d_coarse, hipStream_t comm_stream, bool near_field = true);
+    // A partition's share of a partial matvec (rbf.rs:119-133) behind matvec_partition_upward and the exchange: the
+    // restricted downward pass and the leaf pass of the rows `idx` (rows this part owns; plan cached by index set), the
+    // n_idx values in the order of idx copied to h_out (pinned) asynchronously on the handle's stream.  One rhs.
+    int partition_subset_finish(const double *d_coarse, const int64_t *idx, int64_t n_idx, double *h_out, hipStream_t comm_stream);
     int matvec_partition_finish(const double *d_coarse, double *d_out, int64_t ldo, bool sync, hipStream_t comm_stream);
     // the same, but the owned potentials stay in the tree's sorted order: k rows of d_seg (ld >= the owned count), the
     // block a rank sends to the all-gather; partition_scatter then writes gathered blocks of parts [first, first + n)

@@ -136,8 +136,10 @@ int bbfmm_create(const double *pts, int64_t n, int32_t d, int64_t ld, int32_t in
  * device callers, to the first device).  No caller-supplied collective, no second process.  Arbitrary targets (values,
  * gradients, Leaves mode after bbfmm_set_local_coefficients) with the weights of bbfmm_set_weights are SHARDED by target rows
  * when there are at least 16384 per part (BBFMM_GROUP_SHARD_MIN): every part completes its own multipoles from its
- * device's copy of the weights and evaluates a contiguous share of the rows (bbfmm_last_evaluate_at_sources: 3).  Everything
- * else (few targets, other weights than set_weights', row subsets) is served by the first device alone, with unchanged results.
+ * device's copy of the weights and evaluates a contiguous share of the rows (bbfmm_last_evaluate_at_sources: 3).  Row subsets
+ * (bbfmm_fast_matrix_vector_product with target_indices; the unchanged caller's evaluate at rows of the sources from the second
+ * sighting of a set on) are dealt to the parts that own the rows.  Everything else (few targets, other weights than
+ * set_weights') is served by the first device alone, with unchanged results.
  *   devices    n_devices HIP device ids; the first one holds the handle's own tree (introspection, bbfmm_stream,
  *              device-resident vectors).  An id may repeat: logical parts on one device -- the one-GPU rehearsal of the
  *              N-device path (peer copies become device copies).  One entry: a plain handle on that device.

@@ -77,22 +77,46 @@ def test_two_rhs_and_a_second_evaluate_behind_one_set_weights(case):
     assert relerr(y, one.evaluate(w, pts)) < 1e-12
 
 
-def test_matvec_partial_row_sets_and_other_targets_are_served_by_the_first_device(case):
+def test_matvec_partial_row_sets_go_to_the_parts_that_own_them_and_what_remains_to_the_first_device(case):
     rng, pts, kp, one, ref = case
     n = len(pts)
-    g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0])
+    g = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0, 0])
     w = np.asfortranarray(rng.standard_normal((n, 1)))
-    # matvec_partial (rbf.rs:119-133), patched and unchanged caller
+    # matvec_partial (rbf.rs:119-133), patched caller: the rows of the set dealt to the parts that own them, nugget and
+    # polynomial tail on the host; an unsorted set with a repeated row; the empty set
     idx = np.sort(rng.choice(n, n // 7, replace=False))
-    yp = g.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx)
-    yp1 = one.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx)
-    assert relerr(yp, yp1) < 1e-12 and np.count_nonzero(yp) <= len(idx)
+    poly = np.asfortranarray(np.hstack([np.ones((n, 1)), pts]))
+    w4 = np.concatenate([w[:, 0], rng.standard_normal(4)])
+    yp = g.fast_matrix_vector_product(w4, basis_size=4, target_indices=idx, polynomial_matrix=poly, nugget=0.5)
+    yp1 = one.fast_matrix_vector_product(w4, basis_size=4, target_indices=idx, polynomial_matrix=poly, nugget=0.5)
+    assert g.last_evaluate_path() == 2 and relerr(yp, yp1) < 1e-12 and np.count_nonzero(yp) <= len(idx)
+    ref.set_weights(w)
+    assert relerr(yp[idx], ref.evaluate(w, pts[idx])[:, 0] + 0.5 * w[idx, 0] + poly[idx] @ w4[n:]) < TOL
+    assert relerr(g.fast_matrix_vector_product(w4, basis_size=4, target_indices=idx, polynomial_matrix=poly, nugget=0.5), yp) < 1e-12
+    idx2 = rng.permutation(idx)[: n // 30]
+    idx2[5] = idx2[9]
+    yq = g.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx2)
+    assert relerr(yq, one.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx2)) < 1e-12
+    assert not g.fast_matrix_vector_product(w[:, 0].copy(), target_indices=np.zeros(0, dtype=np.int64)).any()
+    with pytest.raises(ValueError, match="out of range"):
+        g.fast_matrix_vector_product(w[:, 0].copy(), target_indices=np.array([0, n]))
+    # the unchanged caller of it: set_weights + evaluate at rows of the sources -- recognised, partitioned from the second
+    # sighting of the set on (the first one is served by the first device, as on one device)
     g.set_weights(w)
-    ys = g.evaluate(w, pts[idx])
-    assert g.last_evaluate_at_sources() in (0, 2)
+    assert relerr(g.evaluate(w, pts[idx]), yp1[idx, None] - 0.5 * w[idx] - (poly[idx] @ w4[n:])[:, None]) < 1e-11
+    assert g.last_evaluate_path() == 2                           # (a set the patched call has shown before)
+    idx3 = np.sort(rng.choice(n, n // 9, replace=False))          # a set never seen
+    g.set_weights(w)
+    ys = g.evaluate(w, pts[idx3])
+    assert g.last_evaluate_path() == 0
+    g.set_weights(w)
+    ys2 = g.evaluate(w, pts[idx3])
+    assert g.last_evaluate_path() == 2
     one.set_weights(w)
-    assert relerr(ys, one.evaluate(w, pts[idx])) < 1e-12
-    assert relerr(ys[:, 0], yp[idx]) < 1e-12
+    y_one = one.evaluate(w, pts[idx3])
+    assert relerr(ys, y_one) < 1e-12 and relerr(ys2, y_one) < 1e-12
+    ys3 = g.evaluate(w, pts[idx3])                               # behind the same set_weights: the upward pass is run again
+    assert g.last_evaluate_path() == 2 and relerr(ys3, y_one) < 1e-12
     # the group's own path still works afterwards
     y = g.evaluate(w, pts)
     assert g.last_evaluate_at_sources() == 1
