@@ -2,7 +2,8 @@
 """Round-3 fuzz on the GPU box: random clouds / orders / kernels / right-hand sides, each checked three ways against
 the default handle's device matvec -- (1) a handle with a small M2L budget (batches, target-class groups, rhs chunks),
 (2) a W-way partition run rank by rank through the split upward pass (the sum of the partial coarse multipoles stands in
-for the all-reduce), (3) a BBFMM_FLAG_DETERMINISTIC handle, twice, bit for bit -- at 1e-12 of max |y|.
+for the all-reduce), (3) a BBFMM_FLAG_DETERMINISTIC handle, twice, bit for bit, (4) -- round 6 -- ONE handle over W logical parts on the device
+(device-resident vectors and the unchanged caller's host-buffer sequence) -- at 1e-12 of max |y|.
 
   python tests/checks/round3_fuzz.py [cases] [seed]      -> JSON lines, last line = summary"""
 import json, os, sys
@@ -93,7 +94,19 @@ for case in range(cases):
     dt.matvec_device(w.data_ptr(), n, K, o2.data_ptr(), n, True)
     res["err_deterministic"] = float((o1 - ref).abs().max()) / scale
     res["deterministic_bitwise"] = bool(torch.equal(o1, o2))
-    ok = res["err_budget"] < 1e-12 and res["err_partition"] < 1e-12 and res["err_deterministic"] < 1e-12 and res["deterministic_bitwise"]
+    # (4) round 6: ONE handle over `world` logical parts on the device (bbfmm_create_on_devices), device-resident and host buffers
+    gt = mk(devices=[0] * world)
+    og = torch.zeros_like(w)
+    gt.matvec_device(w.data_ptr(), n, K, og.data_ptr(), n, True)
+    res["err_group_device"] = float((og - ref).abs().max()) / scale
+    wh = np.asfortranarray(w.cpu().numpy().T)
+    gt.set_weights(wh)
+    yh = gt.evaluate(wh, pts)
+    res["err_group_host"] = float(np.abs(yh.T - ref.cpu().numpy()).max()) / scale
+    res["group_path"] = int(gt.last_evaluate_path())
+    del gt
+    ok = (res["err_budget"] < 1e-12 and res["err_partition"] < 1e-12 and res["err_deterministic"] < 1e-12 and res["deterministic_bitwise"]
+          and res["err_group_device"] < 1e-12 and res["err_group_host"] < 1e-12 and res["group_path"] == 1)
     res["ok"] = bool(ok)
     fails += 0 if ok else 1
     print(json.dumps(res), flush=True)
