@@ -301,3 +301,35 @@ def test_arbitrary_targets_are_sharded_over_the_parts(case, monkeypatch):
     g.set_weights(w)
     one.set_weights(w)
     assert relerr(g.evaluate(w2, x), one.evaluate(w2, x)) < 1e-12 and g.last_evaluate_path() == 0
+
+
+@pytest.mark.parametrize("n", [2, 300, 5000])
+def test_tiny_clouds_on_a_group(n):
+    """Fewer leaves than parts, trees of depth 0 or 1 (nothing to exchange), parts that own no row at all."""
+    rng = np.random.default_rng(n)
+    pts = rng.random((n, 3))
+    kp = F.KernelParams(F.FmmKernelType.LinearRbf)
+    one = F.FmmTree(pts, 4, kp, True, True)
+    g = F.FmmTree(pts, 4, kp, True, True, devices=[0, 0, 0, 0])
+    w = np.asfortranarray(rng.standard_normal((n, 1)))
+    g.set_weights(w)
+    one.set_weights(w)
+    y, y1 = g.evaluate(w, pts), one.evaluate(w, pts)
+    assert relerr(y, y1) < 1e-12
+    assert relerr(g.fast_matrix_vector_product(w[:, 0].copy()), one.fast_matrix_vector_product(w[:, 0].copy())) < 1e-12
+    idx = np.arange(0, n, 2)
+    assert relerr(g.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx),
+                  one.fast_matrix_vector_product(w[:, 0].copy(), target_indices=idx)) < 1e-12
+
+
+def test_extension_flags_on_a_group(case):
+    """The labelled extensions (shared-basis M2L, small W leaves summed directly) keep working behind a group handle."""
+    rng, pts, kp, one, ref = case
+    n = len(pts)
+    w = np.asfortranarray(rng.standard_normal((n, 1)))
+    for kw in ({"m2l_shared_basis": True}, {"direct_small_w_leaves": True}):
+        a = F.FmmTree(pts, 7, kp, True, True, **kw)
+        b = F.FmmTree(pts, 7, kp, True, True, devices=[0, 0, 0], **kw)
+        a.set_weights(w)
+        b.set_weights(w)
+        assert relerr(b.evaluate(w, pts), a.evaluate(w, pts)) < 1e-12, kw
