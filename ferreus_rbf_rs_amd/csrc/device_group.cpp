@@ -82,6 +82,15 @@ int DeviceGroup::part_fail(const Part &p, int rc) {
     return rc;
 }
 
+namespace {
+// FmmTree::group_weights_resident_ for the length of one call (cleared again whatever way the call ends)
+struct ResidentWeights {
+    bool &flag;
+    explicit ResidentWeights(bool &f) : flag(f) { flag = true; }
+    ~ResidentWeights() { flag = false; }
+};
+} // namespace
+
 template <class F> int DeviceGroup::for_parts(F &&fn) {
     const int G = n_parts();
     std::vector<int> rcs(static_cast<size_t>(G), BBFMM_OK);
@@ -727,10 +736,9 @@ int DeviceGroup::evaluate_sharded(const double *w, int64_t rows, int k, int64_t 
     const int rc = for_parts([&](int g) -> int {
         FmmTree &t = *parts_[static_cast<size_t>(g)].t;
         const int64_t r0 = m * g / G, r1 = m * (g + 1) / G;
-        t.group_weights_resident_ = true;
+        const ResidentWeights resident(t.group_weights_resident_);
         prc[static_cast<size_t>(g)] = t.evaluate(w, rows, k, ldw, x + r0, r1 - r0, ldx, out + r0, ldo, grad ? grad + r0 : nullptr, ldg, with_grads,
                                                  leaves_only, &bad[static_cast<size_t>(g)]);
-        t.group_weights_resident_ = false;
         return BBFMM_OK; // (the parts' verdicts are combined below: the first offending row of the whole call wins)
     });
     if (rc != BBFMM_OK) return rc;
@@ -753,10 +761,8 @@ int DeviceGroup::set_local_coefficients_all(const double *w, int64_t rows, int k
     CHK(complete_all(k));
     const int rc = for_parts([&](int g) -> int {
         FmmTree &t = *parts_[static_cast<size_t>(g)].t;
-        t.group_weights_resident_ = true;
-        const int prc = t.set_local_coefficients(w, rows, k, ldw);
-        t.group_weights_resident_ = false;
-        return prc;
+        const ResidentWeights resident(t.group_weights_resident_);
+        return t.set_local_coefficients(w, rows, k, ldw);
     });
     if (rc != BBFMM_OK) return rc;
     all_locals_ = true;
