@@ -61,6 +61,12 @@ EXTRA_CONFIGS = [
     # oracle is the dense sum: 32 rows per run)
     {"name": "config4_gaussian_ext_10M_8rhs", "points": 10_000_000, "kernel": "GaussianExt", "order": 7, "nrhs": 8,
      "base_range": 0.1, "total_sill": 0.1},
+    # TUNING, never the headline: the headline workload with the reference's OWN knob FmmParams.max_points_per_cell
+    # (ferreus_rbf/src/config.rs:216, default 256) at 512 -- a depth-5 tree with 305-point leaves instead of depth 6 with 38:
+    # eight times less M2L, eight times more near field, which the whole-leaf kernels of round 6 run at 0.84 of the FMA rate.
+    # The same arithmetic, the same accuracy (dense rows), a setting any ferreus_rbf user can make (Params.fmm_params).
+    {"name": "tuning_max_points_per_cell_512_linear_10M", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 1,
+     "base_range": 1.0, "total_sill": 1.0, "max_points_per_cell": 512},
     # EXTENSION, never the headline: the headline workload with BBFMM_FLAG_M2L_SHARED_BASIS, so that the figure the README
     # quotes for it is measured by the driver's own run
     {"name": "extension_shared_basis_linear_10M", "points": 10_000_000, "kernel": "LinearRbf", "order": 7, "nrhs": 1,
@@ -594,8 +600,11 @@ def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None, valu_
     pts = np.random.default_rng(42).random((N, 3))
     t0 = time.time()
     if tree is None:
+        par = None
+        if cfg.get("max_points_per_cell"):   # the reference's defaults (bbfmm.rs:96-103) with another leaf limit
+            par = F.FmmParams(cfg["max_points_per_cell"], F.M2LCompressionType.ACA, 10.0 ** -cfg["order"], 1024)
         tree = F.FmmTree(pts, cfg["order"], F.KernelParams(F.KernelType[cfg["kernel"]], base_range=cfg["base_range"],
-                                                           total_sill=cfg["total_sill"]), True, True,
+                                                           total_sill=cfg["total_sill"]), True, True, params=par,
                          m2l_shared_basis=bool(cfg.get("m2l_shared_basis")),
                          direct_small_w_leaves=bool(cfg.get("direct_small_w_leaves")))
     t_build = time.time() - t0
@@ -623,6 +632,9 @@ def run_config(torch, dist, F, dev, cfg, world, rank, exchange, tree=None, valu_
                           valu_lane_rate)
     err = dense_rows_err(torch, dev, cfg["kernel"], cfg["base_range"], cfg["total_sill"], pts, w, out)
     ext = {}
+    if cfg.get("max_points_per_cell"):
+        ext = {"tuning": "FmmParams.max_points_per_cell = %d (the reference's own parameter, config.rs:216; its default is 256): "
+                         "never the headline" % cfg["max_points_per_cell"]}
     if cfg.get("direct_small_w_leaves"):
         ext = {"extension": "BBFMM_FLAG_DIRECT_SMALL_W_LEAVES (W-list leaves with no more points than nodes summed directly: "
                             "exact where the reference's M2P / P2L approximate)"}
@@ -1089,7 +1101,7 @@ def main():
         ordered = sorted(todo, key=lambda c: (c["points"], c["kernel"], c["order"]) != (N, args.kernel, args.order))
         for cfg in ordered:
             reuse = tree if (cfg["points"], cfg["kernel"], cfg["order"]) == (N, args.kernel, args.order) and \
-                not cfg["name"].startswith("extension_") else None
+                not cfg["name"].startswith(("extension_", "tuning_")) else None
             if reuse is None and tree is not None:
                 del tree, w, out, stream
                 tree = w = out = stream = None

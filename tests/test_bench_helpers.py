@@ -56,9 +56,11 @@ def test_extra_configs_name_baseline_json_configs():
     Every flagged configuration says what it is by its name."""
     flagged = lambda c: bool(c.get("m2l_shared_basis") or c.get("direct_small_w_leaves"))
     names = [c["name"] for c in bench.EXTRA_CONFIGS + bench.EXTENSION_CONFIGS + [bench.CONFIG5]]
-    assert len(names) == len(set(names)) == 10
-    assert len(bench.EXTRA_CONFIGS) == 6 and not flagged(bench.CONFIG5)
+    assert len(names) == len(set(names)) == 11
+    assert len(bench.EXTRA_CONFIGS) == 7 and not flagged(bench.CONFIG5)
     assert [c["name"] for c in bench.EXTRA_CONFIGS if flagged(c)] == ["extension_shared_basis_linear_10M"]
+    # round 6: ONE tuning entry -- the reference's own FmmParams.max_points_per_cell at 512 on the headline workload -- named as such
+    assert [c["name"] for c in bench.EXTRA_CONFIGS if c.get("max_points_per_cell")] == ["tuning_max_points_per_cell_512_linear_10M"]
     assert all(flagged(c) and c["name"].startswith("extension_") for c in bench.EXTENSION_CONFIGS)
     assert (bench.CONFIG5["points"], bench.CONFIG5["kernel"]) == (40_000_000, "Spheroidal3Rbf")
     for c in bench.EXTRA_CONFIGS + bench.EXTENSION_CONFIGS + [bench.CONFIG5]:
