@@ -1087,7 +1087,7 @@ __global__ __launch_bounds__(64 * SYM_WAVES) void p2p_sym_kernel(KernelSpec ks, 
 // at 5M Spheroidal3 points against 12.4 for the chunk kernel); column sums collect in the tile's LDS accumulator over
 // all of the leaf's rows and leave with one atomic per source and (leaf, tile).
 // One pass: NR rows (sorted sources g0 .. g0 + NR, wave-uniform) against the tile.  ALLCOLS: every column takes its column
-// sum (the nodes of W cells); otherwise only the two-sided ones (cidx >= 0).  The rows' sums over this tile are reduced
+// sum (the nodes of W cells); otherwise only the two-sided ones (cidx >= 0) are flushed by the caller.  The rows' sums over this tile are reduced
 // across the wave and added to out[row0 + r] at once (rows outside [win_lo, win_hi) are dropped: a partition's window) --
 // the accumulators do not outlive the pass, so the kernel holds NR of them whatever the size of the leaf.
 template <int KID, int NR, bool ALLCOLS>
@@ -1110,16 +1110,40 @@ __device__ inline void sym3_pass(const KernelSpec &ks, SymTile<1> &tile, int fil
             racc[r] += v * wj;
             csum += v * tw[r];
         }
-        if (ALLCOLS || tile.cidx[j] >= 0) unsafeAtomicAdd(&tile.col[0][j], csum);
+        // (one-sided columns -- cidx < 0: the leaf itself, another part's points -- collect their sums too and are skipped
+        // when the tile is flushed: cheaper than reading cidx and masking the add in every iteration)
+        unsafeAtomicAdd(&tile.col[0][j], csum);
     }
-    double mine = 0.0;
+    if constexpr (NR >= 4) {
+        // eight (padded) row sums across the wave by halving: lanes l and l ^ 32 split the rows between them and exchange
+        // the halves they give up (four exchanges), then l ^ 16 (two), then l ^ 8 (one) -- every lane is left with ONE row,
+        // (l >> 3) & 7, summed over eight lanes -- and three plain steps finish it: 10 exchanges where NR separate
+        // reductions took 6 NR (a pass of eight rows: 48), 8 % of a LinearRbf pass.
+        const bool b5 = (lane & 32) != 0, b4 = (lane & 16) != 0, b3 = (lane & 8) != 0;
+        double u[4], t2[2];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const double sres = wave_sum(racc[r]);
-        if (lane == r) mine = sres;
+        for (int i = 0; i < 4; ++i) {
+            const double a = racc[i], b = i + 4 < NR ? racc[i + 4 < NR ? i + 4 : 0] : 0.0;
+            u[i] = (b5 ? b : a) + __shfl_xor(b5 ? a : b, 32, 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) t2[i] = (b4 ? u[i + 2] : u[i]) + __shfl_xor(b4 ? u[i] : u[i + 2], 16, 64);
+        double tot = (b3 ? t2[1] : t2[0]) + __shfl_xor(b3 ? t2[0] : t2[1], 8, 64);
+        tot += __shfl_xor(tot, 4, 64);
+        tot += __shfl_xor(tot, 2, 64);
+        tot += __shfl_xor(tot, 1, 64);
+        const int r = (lane >> 3) & 7, o = row0 + r;
+        if ((lane & 7) == 0 && r < NR && o >= win_lo && o < win_hi) unsafeAtomicAdd(&out[o], tot);
+    } else {
+        double mine = 0.0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const double sres = wave_sum(racc[r]);
+            if (lane == r) mine = sres;
+        }
+        const int o = row0 + lane;
+        if (lane < NR && o >= win_lo && o < win_hi) unsafeAtomicAdd(&out[o], mine);
     }
-    const int o = row0 + lane;
-    if (lane < NR && o >= win_lo && o < win_hi) unsafeAtomicAdd(&out[o], mine);
 }
 
 // A wave's nr rows in passes of at most MAXR rows, all of sz or sz + 1 rows (equal passes: a pass of one or two rows costs
@@ -2391,7 +2415,11 @@ void launch_wx_sym(const KernelSpec &ks, const ChebRef &ch, int n_jobs, const in
                        lengths, make_xyz(src_xyz), w_sorted + static_cast<int64_t>(k0) * ldw, ldw, kb,                 \
                        M + static_cast<int64_t>(k0) * ld_ml, L + static_cast<int64_t>(k0) * ld_ml, ld_ml,               \
                        out_sorted + static_cast<int64_t>(k0) * ldo, ldo, out_off, out_n)
-            if (kb == 1 && n_leaf_jobs > 0) // one rhs: whole leaves (the same rows and W cells as the chunk jobs)
+            if (kb == 1 && n_leaf_jobs > 0 && p2p_sym3_max_rows_per_pass() == 8) // one rhs: whole leaves (the same rows and W cells as the chunk jobs)
+                hipLaunchKernelGGL((wx_sym3_kernel<ID, 8>), dim3(n_leaf_jobs), dim3(64 * SYM_WAVES), 0, s, ks, ljobs, ch.dev, centers, lengths,
+                                   make_xyz(src_xyz), w_sorted + static_cast<int64_t>(k0) * ldw, M + static_cast<int64_t>(k0) * ld_ml,
+                                   L + static_cast<int64_t>(k0) * ld_ml, out_sorted + static_cast<int64_t>(k0) * ldo, out_off, out_n);
+            else if (kb == 1 && n_leaf_jobs > 0)
                 hipLaunchKernelGGL((wx_sym3_kernel<ID, 6>), dim3(n_leaf_jobs), dim3(64 * SYM_WAVES), 0, s, ks, ljobs, ch.dev, centers, lengths,
                                    make_xyz(src_xyz), w_sorted + static_cast<int64_t>(k0) * ldw, M + static_cast<int64_t>(k0) * ld_ml,
                                    L + static_cast<int64_t>(k0) * ld_ml, out_sorted + static_cast<int64_t>(k0) * ldo, out_off, out_n);

@@ -41,7 +41,7 @@ for c in ('FETCH_SIZE', 'WRITE_SIZE', 'MfmaUtil', 'MfmaFlopsF64', 'VALUBusy', 'V
 mean = lambda v: sum(v) / len(v) if v else None
 phase = {'m2l_gemm_k4<11, 1, 1>': 'M2L_stage1', 'm2l_gemm_k4<22, 2, 1>': 'M2L_stage2', 'm2l_gemm_k4<11, 2, 1>': 'M2L_stage2', 'p2p_sym_kernel<0, 1>': 'P2P',
          'p2p_sym2_kernel<0, 1>': 'P2P', 'p2p_kernel<0, false, 1>': 'P2P', 'wx_sym_kernel<0, 1>': 'P2L',
-         'p2p_sym3_kernel<0, 8>': 'P2P', 'p2p_sym3_kernel<0, 6>': 'P2P', 'wx_sym3_kernel<0, 6>': 'P2L'}   # round 6: the whole-leaf kernels of a one-rhs pass
+         'p2p_sym3_kernel<0, 8>': 'P2P', 'p2p_sym3_kernel<0, 6>': 'P2P', 'wx_sym3_kernel<0, 6>': 'P2L', 'wx_sym3_kernel<0, 8>': 'P2L'}   # round 6: the whole-leaf kernels of a one-rhs pass
 per_bytes, per_kernel, lines = {}, {}, []
 for k, v in sorted(agg.items()):
     fb = 2 * mean(v.get('FETCH_SIZE')) * 1024 if v.get('FETCH_SIZE') else None
