@@ -130,6 +130,8 @@ def _synthetic_detail(world=1):
         cfgs[c["name"]] = {"workload": "x" * 80, "ms_per_step": 14.312587000313215, "roofline": r, "phase_ms_per_step": ms,
                            "dense_rows_rel_err": 9.955587767114334e-07,
                            "phase_roofline": bench.phase_roofline(S, c["points"], c["nrhs"], 7, c["kernel"], ms, 3.1e13)}
+        if c.get("note"):
+            cfgs[c["name"]]["note"] = c["note"]
     solve = {"ddm_params": {}, "levels": 4, "setup_s": 2.612345678, "solve_s": 3.1923456, "iterations": 5, "converged": True,
              "stagnated": False, "residual_history": [6.12e-5, 9.97e-6, 2.69e-6, 1.11e-6, 6.96e-7], "max_fit_error_on_sample": 4e-6}
     cfgs["config3_solve_tps_10M_fgmres_schwarz"] = {"workload": "y" * 100, "for_points": solve,
@@ -195,7 +197,9 @@ def test_the_stdout_line_stays_under_4_kb_and_round_trips(world, tmp_path, monke
         elif name.startswith("config3_solve"):
             assert c["for_points"]["iterations"] == 5 and c["reference_defaults"]["stagnated"] is True
         else:
-            assert set(c) == {"ms_per_step", "dense_rows_rel_err", "roofline"} and set(c["roofline"]) == {"kernel", "bound", "frac"}
+            assert set(c) - {"note"} == {"ms_per_step", "dense_rows_rel_err", "roofline"} and set(c["roofline"]) == {"kernel", "bound", "frac"}
+    # the narrow Gaussian's 1e-2 against its dense rows is the method's error -- said next to the number
+    assert "METHOD" in line["configs"]["config4_gaussian_ext_10M_8rhs"]["note"]
     # the full record went to the side file, untouched
     with open(tmp_path / "bench_detail.json") as f:
         full = json.load(f)
