@@ -2375,6 +2375,18 @@ int p2p_sym_wave_rows() {
     return rows;
 }
 
+// A launch of the wave kernel with fewer jobs than this leaves the chip to a handful of waves per SIMD, each walking its
+// whole leaf alone: such trees give every leaf to a workgroup instead (eight waves share its rows).  Measured on MI355X,
+// uniform points, near field per matvec, wave kernel -> workgroup kernels: 512 leaves (20k / 36k points) 0.055 -> 0.018 /
+// 0.130 -> 0.035 ms, 4,096 leaves (150k / 200k / 300k) 0.134 -> 0.083 / 0.131 -> 0.112 / 0.288 -> 0.203 ms; 32,768 leaves
+// (1.6M / 2M) 0.71 -> 0.89 / 1.11 -> 1.23 ms the other way.  Default 48 jobs per CU; BBFMM_P2P_SYM_WAVE_MIN=<jobs> overrides.
+static int device_cu_count();
+int64_t p2p_sym_wave_min_jobs() {
+    const char *e = std::getenv("BBFMM_P2P_SYM_WAVE_MIN"); // read per plan (a handle's job lists are built once): the tests
+    if (e && *e) return std::max<int64_t>(0, std::atoll(e)); // run small trees through either kind of job in one process
+    return int64_t(48) * device_cu_count();
+}
+
 int p2p_sym_rows_per_job() { return SYM_WAVES * SYM_TR; }
 // Whole-leaf jobs of the one-rhs workgroup kernel: rows per job (BBFMM_P2P_SYM_LEAF=<rows>; 0: no such jobs, the chunk
 // jobs serve one rhs too).  A job of R rows gives each of the eight waves R / 8 of them.

@@ -168,6 +168,7 @@ void launch_p2p_sym(const KernelSpec &ks, int n_jobs, const int32_t *tgt_begin, 
 int p2p_sym_rows_per_job();
 int p2p_sym3_rows_per_job(); // 0: no whole-leaf jobs (BBFMM_P2P_SYM_LEAF=0)
 int p2p_sym_wave_rows(); // 0: no wave jobs (BBFMM_P2P_SYM_WAVE=0)
+int64_t p2p_sym_wave_min_jobs(); // fewer wave-sized leaves than this in a job list: none of them goes to the wave kernel
 int wx_sym_rows_per_job();
 int wx_sym3_rows_per_job(); // 0: no whole-leaf jobs (BBFMM_WX_SYM_LEAF=0)
 // M2P + P2L in one pass for targets = all sources (X = W^T; K rhs in passes of kSymMaxRhs: rhs k at w_sorted + k * ldw,

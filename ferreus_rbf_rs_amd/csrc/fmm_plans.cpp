@@ -56,8 +56,14 @@ int FmmTree::build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells
     // wave-per-job kernel (no barriers, columns in registers: faster where a leaf's work is small); bigger leaves go
     // in chunks of at most p2p_sym_rows_per_job() rows to the workgroup-per-job kernel, whose per-job overhead is
     // spread over eight waves (faster there).
-    const int64_t max_rows = p2p_sym_rows_per_job(), wave_rows = p2p_sym_wave_rows(), leaf_rows = p2p_sym3_rows_per_job();
+    const int64_t max_rows = p2p_sym_rows_per_job(), leaf_rows = p2p_sym3_rows_per_job();
     const int64_t nj_cells = static_cast<int64_t>(job_cells.size());
+    int64_t wave_rows = p2p_sym_wave_rows();
+    if (wave_rows > 0) { // a small tree (or a thin part of one): too few wave jobs to fill the chip -- workgroups take every leaf
+        int64_t n_wave = 0;
+        for (const int32_t c : job_cells) n_wave += (t.pt_end[c] - t.pt_begin[c]) <= wave_rows;
+        if (n_wave < p2p_sym_wave_min_jobs()) wave_rows = 0;
+    }
     // per chunk of leaves into local buffers (threads), concatenated in order
     constexpr int64_t kChunkS = 2048;
     const int64_t nch = (nj_cells + kChunkS - 1) / kChunkS;

@@ -51,13 +51,18 @@ for case in range(cases):
     par = F.FmmParams(leaf, 2, 10.0 ** -order, 1024)
     os.environ.pop("BBFMM_M2L_CBUF_MB", None)
     mk = lambda **kw: F.FmmTree(pts, order, kp, adaptive, sparse, params=par, **kw)
+    # small leaves: one wave each in the reference handle and the library's size rule (workgroup jobs in trees this small) in
+    # the handles checked against it, or the other way round (the variable is read when a handle builds its job lists)
+    os.environ["BBFMM_P2P_SYM_WAVE_MIN"] = "0" if case % 2 == 0 else ""
     ref_t = mk()
+    os.environ["BBFMM_P2P_SYM_WAVE_MIN"] = "" if case % 2 == 0 else "0"
     st = ref_t.stats()
     w = torch.from_numpy(rng.standard_normal((K, n))).cuda()
     ref = torch.zeros_like(w)
     ref_t.matvec_device(w.data_ptr(), n, K, ref.data_ptr(), n, True)
     scale = float(ref.abs().max())
-    res = {"case": case, "cloud": kind, "d": d, "adaptive": adaptive, "sparse": sparse, "n": n, "order": order, "kernel": kid, "K": K, "leaf": leaf, "depth": st.depth, "n_w": st.n_w}
+    res = {"case": case, "cloud": kind, "d": d, "adaptive": adaptive, "sparse": sparse, "n": n, "order": order, "kernel": kid, "K": K, "leaf": leaf, "depth": st.depth, "n_w": st.n_w,
+           "reference_handle_small_leaves": "wave jobs" if case % 2 == 0 else "size rule"}
     # (1) small budget
     if st.m2l_slots_bytes_per_rhs > 0:
         os.environ["BBFMM_M2L_CBUF_MB"] = "%.6f" % (frac * st.m2l_slots_bytes_per_rhs / 1048576.0)

@@ -11,6 +11,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu")
+    # The library gives the leaves of a SMALL tree to its workgroup kernels (fewer than 48 wave-sized leaves per CU cannot fill
+    # the chip one wave per leaf: device.hip p2p_sym_wave_min_jobs); the test clouds are all small, so without this the
+    # wave-per-leaf kernel that production sizes run (10M points: 261k leaves) would only be seen by the full-size tests.
+    # The suite therefore keeps small trees on the wave kernel; the size rule itself is covered where a test deletes the
+    # variable (test_gpu_configs.py: both job kinds against the oracle) and in test_gpu_switches.py (child processes
+    # start without any BBFMM_ variable).
+    os.environ.setdefault("BBFMM_P2P_SYM_WAVE_MIN", "0")
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -254,13 +254,20 @@ def test_independent_operators_on_a_mixed_level_tree(kid, order, br, sill, tol):
 @pytest.mark.parametrize("kid,d,mpc,nrhs", [(0, 3, 256, 1), (1, 3, 256, 2), (3, 3, 20, 1), (7, 3, 256, 3), (2, 2, 256, 1),
                                            (0, 1, 64, 1), (0, 3, 256, 5), (0, 3, 40, 8), (3, 3, 256, 8), (1, 3, 64, 11),
                                            (2, 2, 30, 4)])
-def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs):
+@pytest.mark.parametrize("jobs", ["wave_per_small_leaf", "size_rule"])
+def test_symmetric_p2p_equals_the_ordered_pair_loops(kid, d, mpc, nrhs, jobs, monkeypatch):
     """The matvec evaluates every unordered near-field pair once (launch_p2p_sym); `evaluate` at the same points
     goes through the ordered-pair kernel the reference's loops correspond to (bbfmm.rs:1162-1251).  Leaves of up
     to 256 points (several register groups per wave, several source tiles per leaf) and of a few points.  Round 4:
     up to four right-hand sides share one kernel evaluation per unordered pair (kernel instances for 1, 2, 4; three runs
     the 4-slot instance; eleven = 4 + 4 + 3), in the near field and in the fused M2P + P2L."""
     import torch
+    # leaves of at most 64 points: one wave each (what a tree with enough of them gets: conftest.py), or -- the library's own
+    # choice for trees this small -- workgroup jobs like the bigger leaves (BBFMM_P2P_SYM_WAVE_MIN is read when a plan is built)
+    if jobs == "size_rule":
+        monkeypatch.delenv("BBFMM_P2P_SYM_WAVE_MIN", raising=False)
+    else:
+        monkeypatch.setenv("BBFMM_P2P_SYM_WAVE_MIN", "0")
     rng = np.random.default_rng(600 + kid + d)
     n = 150000 if d == 3 else 40000
     pts = clustered_points(rng, n, d)

@@ -28,6 +28,7 @@ SWITCHES = [
     ("near_field_jobs_in_morton_order", {"BBFMM_SYM_JOB_ORDER": "0"}, []),
     ("near_field_no_wave_jobs", {"BBFMM_P2P_SYM_WAVE": "0"}, []),                                       # every leaf in the workgroup kernels
     ("near_field_no_wave_jobs_chunks", {"BBFMM_P2P_SYM_WAVE": "0", "BBFMM_P2P_SYM_LEAF": "0"}, []),
+    ("near_field_wave_jobs_in_a_small_tree", {"BBFMM_P2P_SYM_WAVE_MIN": "0"}, []),   # default: a tree this small has no wave jobs
     ("deterministic", {}, ["deterministic"]),
     ("deterministic_again", {}, ["deterministic"]),
 ]
