@@ -311,7 +311,7 @@ bool DeviceGroup::weights_match_staged(const double *w, int64_t rows, int k, int
 int DeviceGroup::stage(const double *w, int64_t rows, int k, int64_t ldw) {
     (void)rows;
     FmmTree &P = *parts_[0].t;
-    staged_k_ = 0;
+    staged_k_ = dev_staged_k_ = 0;
     all_complete_ = all_locals_ = false;
     // parts that share a device read its owner's copy: the new weights wait until the last product's parts have read the old
     for (size_t g = 0; g < parts_.size(); ++g) {
@@ -342,7 +342,7 @@ int DeviceGroup::stage(const double *w, int64_t rows, int k, int64_t ldw) {
         GHIP(hipEventRecord(p.ev_w, p.t->stream_));
     }
     P.bind_device();
-    staged_k_ = k;
+    staged_k_ = dev_staged_k_ = k;
     return BBFMM_OK;
 }
 
@@ -652,10 +652,23 @@ int DeviceGroup::matvec_device(const double *d_w, int64_t ldw, int k, double *d_
     if (!d_w || !d_out || k < 1 || ldw < N || ldo < N) return fail(BBFMM_BAD_ARGUMENT, "bad device matvec arguments");
     last_path_ = 0;
     CHK(ensure_capacity(k, true));
-    staged_k_ = 0; // the owners' staging buffers are overwritten with the caller's device weights
+    staged_k_ = dev_staged_k_ = 0; // the owners' staging buffers are overwritten with the caller's device weights
     all_complete_ = all_locals_ = false;
     P.bind_device();
     GHIP(hipEventRecord(ev_in_, P.stream_));
+    // The primary keeps a copy as well (its parts read the caller's buffer itself): the partitioned upward pass leaves it with
+    // the partial sums of its own subtree, and a later call that it serves alone -- evaluate at other targets without another
+    // set_weights, as after bbfmm_matvec_device on a plain handle -- completes its multipoles from this copy.
+    {
+        const int rc = P.ensure_w_in(k);
+        if (rc != BBFMM_OK) return part_fail(parts_[0], rc);
+    }
+    for (size_t h = 1; h < parts_.size(); ++h) // (parts sharing the primary's device may still be reading the old copy)
+        if (parts_[h].owner == 0) GHIP(hipStreamWaitEvent(P.stream_, parts_[h].ev_up, 0));
+    for (int j = 0; j < k; ++j)
+        GHIP(hipMemcpyAsync(P.d_w_in_.p + static_cast<size_t>(j) * N, d_w + static_cast<size_t>(j) * ldw, static_cast<size_t>(N) * sizeof(double),
+                            hipMemcpyDeviceToDevice, P.stream_));
+    GHIP(hipEventRecord(parts_[0].ev_w, P.stream_));
     for (int g = 1; g < G; ++g) {
         Part &p = parts_[static_cast<size_t>(g)];
         if (p.owner != g) continue;
@@ -674,6 +687,7 @@ int DeviceGroup::matvec_device(const double *d_w, int64_t ldw, int k, double *d_
     }
     P.bind_device();
     CHK(run_upward(k, d_w, ldw));
+    dev_staged_k_ = k;
     const int64_t m_max = m_max_;
     int rc = for_parts([&](int g) -> int {
         Part &p = parts_[static_cast<size_t>(g)];
@@ -773,16 +787,16 @@ int DeviceGroup::set_local_coefficients_all(const double *w, int64_t rows, int k
 int DeviceGroup::prepare_primary(bool same_weights) {
     FmmTree &P = *parts_[0].t;
     last_path_ = 0;
-    if (!primary_complete_ && staged_k_ > 0) {
+    if (!primary_complete_ && dev_staged_k_ > 0) { // (after set_weights: the staged weights; after matvec_device: its device copy)
         P.bind_device();
-        const int rc = P.complete_upward_from_staged(staged_k_);
+        const int rc = P.complete_upward_from_staged(dev_staged_k_);
         if (rc != BBFMM_OK) return part_fail(parts_[0], rc);
-        P.pin_w_k_ = staged_k_; // the pinned buffer holds exactly the weights the sorted copy was gathered from
+        P.pin_w_k_ = staged_k_; // the pinned buffer holds exactly the weights the sorted copy was gathered from (0: it does not)
         primary_complete_ = true;
         pending_k_ = 0;
     }
     if (!same_weights) { // the primary is about to stage others (the reference's mixture: old multipoles, new near field)
-        staged_k_ = 0;
+        staged_k_ = dev_staged_k_ = 0;
         all_complete_ = all_locals_ = false;
     }
     return BBFMM_OK;

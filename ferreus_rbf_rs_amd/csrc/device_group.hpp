@@ -88,7 +88,7 @@ class DeviceGroup {
     // Before a call that part 0 serves alone.  same_weights: the call brings the weights of set_weights (or none).
     int prepare_primary(bool same_weights);
     // the primary has been given other weights / another product behind the group's back: nothing staged is valid any more
-    void primary_state_changed() { staged_k_ = 0; pending_k_ = 0; primary_complete_ = true; all_complete_ = all_locals_ = false; }
+    void primary_state_changed() { staged_k_ = dev_staged_k_ = 0; pending_k_ = 0; primary_complete_ = true; all_complete_ = all_locals_ = false; }
     bool weights_match_staged(const double *w, int64_t rows, int k, int64_t ldw) const;
     int last_path() const { return last_path_; } // 1: the last evaluate ran partitioned over the group, 0: on the primary
     void set_profiling(bool on);
@@ -132,6 +132,8 @@ class DeviceGroup {
     double *d_all_ = nullptr;       // primary's device: gathered blocks of a device-resident product
     hipEvent_t ev_in_ = nullptr;
     int staged_k_ = 0;              // the pinned buffer of the primary and every owner's d_w_in_ hold the weights of set_weights
+    int dev_staged_k_ = 0;          // every owner's d_w_in_ (the primary's included) holds the weights of the last product: set_weights',
+                                    // or the device-resident ones of matvec_device (which the pinned buffer does not hold)
     int pending_k_ = 0;             // upward + exchange queued for them, not consumed yet
     bool primary_complete_ = false; // the primary holds the complete multipoles of the staged weights
     bool all_complete_ = false;     // every part does

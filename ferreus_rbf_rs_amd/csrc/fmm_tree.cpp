@@ -858,6 +858,7 @@ int FmmTree::upward(int k, const DownwardPlan *dp) {
     const HostTree &t = tree_;
     const int64_t C = t.n_cells();
     const bool part = dp && dp->restrict_upward;
+    multipoles_partial_ = part; // (a partition's share: nothing but the partitioned downward pass may read M until a whole upward pass has run)
     // reset_multipole_coefficients (bbfmm.rs:619-624): M is zero-initialised once; P2M and M2M assign
     // every leaf with sources and every parent, the other entries are never written.  A partition computes
     // only its share (see DownwardPlan): the coarse prefix is zeroed first because the coarse leaves other ranks
@@ -1068,10 +1069,16 @@ int FmmTree::set_weights(const double *w, int64_t rows, int k, int64_t ldw) {
     return BBFMM_OK;
 }
 
+// After bbfmm_matvec_partition_upward the multipoles of this handle are its own subtree's share (+ the coarse prefix): a call of
+// the evaluator behind it would read them as if they were whole.
+static const char kPartialMultipoles[] =
+    "the multipoles are one partition's share (bbfmm_matvec_partition_upward ran last): bbfmm_set_weights must be called first";
+
 int FmmTree::set_local_coefficients(const double *w, int64_t rows, int k, int64_t ldw) {
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     if (nrhs_ == 0) return fail(BBFMM_BAD_ARGUMENT, "set_weights must be called first");
+    if (multipoles_partial_) return fail(BBFMM_BAD_ARGUMENT, kPartialMultipoles);
     if (k != nrhs_) return fail(BBFMM_BAD_ARGUMENT, "weights must have the column count given to set_weights");
     CHK(put_weights(w, rows, k, ldw));
     CHK(downward(k));
@@ -1086,6 +1093,7 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
     if (host_only_) return fail(BBFMM_DEVICE_ERROR, "handle was created with BBFMM_FLAG_HOST_ONLY");
     part_pending_k_ = 0; // M, the sorted weights or the partition's outputs are rewritten: a half-done partitioned matvec is void
     if (nrhs_ == 0) return fail(BBFMM_BAD_ARGUMENT, "set_weights must be called first");
+    if (multipoles_partial_) return fail(BBFMM_BAD_ARGUMENT, kPartialMultipoles);
     if (k != nrhs_) return fail(BBFMM_BAD_ARGUMENT, "weights must have the column count given to set_weights");
     if (m < 0 || (m > 0 && (!x || !out || ldx < m || ldo < m))) return fail(BBFMM_BAD_ARGUMENT, "bad target/output arrays");
     if (with_grads && m > 0 && (!grad || ldg < m)) return fail(BBFMM_BAD_ARGUMENT, "bad gradient array");

@@ -331,6 +331,7 @@ class FmmTree {
     int build_downward_plan(const std::vector<int32_t> &target_leaves, DownwardPlan *dp, bool restrict_upward = false,
                             int64_t own_b = 0, int64_t own_e = 0);
     int part_pending_k_ = 0; // rhs count of a matvec_partition_upward that still waits for its finish
+    bool multipoles_partial_ = false; // the last upward pass was a partition's share: the evaluator's entry points refuse to read M
     void free_downward_plan(DownwardPlan *dp);
     int subset_plan(const int64_t *idx, int64_t n_idx, SubsetPlan **out);
     uint64_t subset_key(const int64_t *idx, int64_t n_idx) const;

@@ -305,7 +305,10 @@ int bbfmm_partition_rows(const bbfmm_handle *h, int64_t *rows_out);
  * for the packed multipoles only and queues the near field (P2P) of the owned targets behind the pack on the handle's own
  * stream, so that the collective runs beside it; _finish makes the handle's stream wait for comm_stream before it reads
  * d_coarse.  With NULL the caller orders the collective after the handle's stream itself (everything serial).
- * bbfmm_matvec_device on a partitioned handle still works on its own (it then runs the whole upward pass). */
+ * bbfmm_matvec_device on a partitioned handle still works on its own (it then runs the whole upward pass).  After
+ * _upward the handle's multipoles are this rank's share: bbfmm_evaluate* and bbfmm_set_local_coefficients return
+ * BBFMM_BAD_ARGUMENT ("one partition's share") until bbfmm_set_weights or bbfmm_matvec_device has run a whole upward pass
+ * (a device-group handle completes its first part's multipoles by itself). */
 int64_t bbfmm_partition_coarse_count(const bbfmm_handle *h);
 int bbfmm_matvec_partition_upward(bbfmm_handle *h, const double *d_w, int64_t ldw, int32_t k, double *d_coarse, void *comm_stream);
 int bbfmm_matvec_partition_finish(bbfmm_handle *h, const double *d_coarse, double *d_out, int64_t ldo, int32_t sync, void *comm_stream);

@@ -386,3 +386,32 @@ def test_eighty_million_points_depth_seven_tree():
     yd = -(torch.sqrt(r2) * w[0]).sum(1)
     got = y[0][torch.from_numpy(idx).cuda()]
     assert float((got - yd).abs().max() / yd.abs().max()) < 1e-6
+
+
+def test_the_evaluator_refuses_a_partition_s_share_of_the_multipoles():
+    """After bbfmm_matvec_partition_upward a handle's multipoles are its own subtree's share (+ the coarse prefix): evaluate and
+    set_local_coefficients say so instead of reading them as if they were whole; set_weights makes them whole again.  (A device
+    group completes its first part's multipoles by itself: test_gpu_device_group.py.)"""
+    import torch
+    rng = np.random.default_rng(77)
+    pts = rng.random((60000, 3))
+    n = len(pts)
+    t = F.FmmTree(pts, 5, F.KernelParams(F.KernelType(0)), True, True)
+    w = rng.standard_normal((n, 1))
+    dw = torch.from_numpy(np.ascontiguousarray(w.T)).cuda()
+    x = rng.random((50, 3))
+    t.set_weights(w)
+    y0 = t.evaluate(w, x)
+    t.set_partition(0, 2)
+    c = torch.zeros((1, max(t.partition_coarse_count(), 1)), dtype=torch.float64, device="cuda")
+    t.matvec_partition_upward(dw.data_ptr(), n, 1, c.data_ptr())
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="partition's share"):
+        t.evaluate(w, x)
+    with pytest.raises(ValueError, match="partition's share"):
+        t.set_local_coefficients(w)
+    t.set_partition(0, 1)
+    with pytest.raises(ValueError, match="partition's share"):
+        t.evaluate(w, x)
+    t.set_weights(w)
+    assert relerr(t.evaluate(w, x), y0) < 1e-13

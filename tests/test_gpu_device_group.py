@@ -159,6 +159,21 @@ def test_device_resident_vectors_on_a_group(case):
         g.matvec_device(w.data_ptr(), n, k, out.data_ptr(), n, sync=True)
         one.matvec_device(w.data_ptr(), n, k, out1.data_ptr(), n, sync=True)
         assert relerr(out.cpu().numpy(), out1.cpu().numpy()) < 1e-12
+    # A call the first device serves alone right behind a device-resident product, with no set_weights in between (what a
+    # plain handle allows: bbfmm_matvec_device leaves the multipoles of its weights behind).  The partitioned upward pass left
+    # the first device with the partial sums of its own subtree: it completes them from its copy of the device weights.
+    w1 = torch.from_numpy(np.ascontiguousarray(rng.standard_normal((1, n)))).cuda()
+    o1, o2 = torch.zeros((1, n), dtype=torch.float64, device="cuda"), torch.zeros((1, n), dtype=torch.float64, device="cuda")
+    g.matvec_device(w1.data_ptr(), n, 1, o1.data_ptr(), n, sync=True)
+    one.matvec_device(w1.data_ptr(), n, 1, o2.data_ptr(), n, sync=True)
+    x = pts[rng.choice(n, 300, replace=False)] * 0.999 + 0.0005 * rng.random((300, pts.shape[1]))
+    w1h = np.asfortranarray(w1.cpu().numpy().T)
+    assert g.last_evaluate_path() == 1
+    y_g, y_1 = g.evaluate(w1h, x), one.evaluate(w1h, x)
+    assert g.last_evaluate_path() == 0 and relerr(y_g, y_1) < 1e-12
+    # and the product after that is whole again
+    g.matvec_device(w1.data_ptr(), n, 1, o1.data_ptr(), n, sync=True)
+    assert relerr(o1.cpu().numpy(), o2.cpu().numpy()) < 1e-12
     # a host-buffer product right behind the device-resident one (the staged weights were replaced)
     wh = np.asfortranarray(rng.standard_normal((n, 1)))
     g.set_weights(wh)
