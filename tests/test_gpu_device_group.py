@@ -348,3 +348,17 @@ def test_extension_flags_on_a_group(case):
         a.set_weights(w)
         b.set_weights(w)
         assert relerr(b.evaluate(w, pts), a.evaluate(w, pts)) < 1e-12, kw
+
+
+@pytest.mark.timeout(900)
+def test_random_call_sequences_on_a_group_equal_the_plain_handle():
+    """tests/checks/group_sequence_fuzz.py in small: random sequences of the evaluator's calls (set_weights, evaluate at the
+    sources / few / many targets / rows of the sources, other weights than set_weights', gradients, Leaves mode, the matvec
+    entry points on host and device vectors) on a group of 2-5 logical parts and on a plain handle -- the same values at 1e-11
+    or the same refusal (and the same offending row) after every call.  What a group keeps between calls must never show."""
+    env = {k: v for k, v in os.environ.items() if not k.startswith("BBFMM_")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "checks", "group_sequence_fuzz.py"), "10", "5", "14"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    lines = p.stdout.decode().strip().splitlines()
+    assert p.returncode == 0, "\n".join(l for l in lines if '"ok": false' in l)[:3000] + p.stderr.decode()[-1500:]
+    assert '"failures": 0' in lines[-1]
