@@ -422,3 +422,21 @@ def test_degenerate_clouds(name):
     # the matvec entry point (unordered near field, fused adaptive lists) on the same cloud
     y = t.fast_matrix_vector_product(w[:, 0].copy())
     assert relerr(y, r.evaluate(w, pts)[:, 0]) < TOL
+
+
+@pytest.mark.timeout(900)
+def test_random_call_sequences_equal_the_oracle_call_by_call():
+    """tests/checks/handle_sequence_fuzz.py in small: random sequences of the evaluator's calls on a handle and on the oracle's
+    restatement of the reference's FmmTree -- the state one call leaves to the next (the multipoles of set_weights under another
+    call's weights, stored local expansions, right-hand-side counts, row subsets) gives the same values at 1e-11, or the same
+    refusal with the same offending row, after every call."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("BBFMM_")}
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "checks", "handle_sequence_fuzz.py"), "8", "17", "12"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=800)
+    lines = p.stdout.decode().strip().splitlines()
+    assert p.returncode == 0, "\n".join(l for l in lines if '"ok": false' in l)[:3000] + p.stderr.decode()[-1500:]
+    assert '"failures": 0' in lines[-1]
