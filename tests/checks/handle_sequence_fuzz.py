@@ -46,17 +46,22 @@ def run(f):
 
 fails = 0
 for s in range(n_seq):
-    d = 3 if rng.integers(0, 4) else 2
-    n = int(rng.integers(3000, 12000))
+    d = [3, 3, 3, 2, 2, 1][int(rng.integers(0, 6))]
+    n = int(rng.integers(3000, 12000)) if d > 1 else int(rng.integers(500, 3000))
+    # the solver's tree (adaptive, sparse, extents from the data: rbf.rs:459-467) most of the time; the evaluator's otherwise
+    # (rbf.rs:594-631: explicit extents, not sparse) and regular trees
+    adaptive, sparse = bool(rng.integers(0, 4) > 0), bool(rng.integers(0, 3) > 0)
+    extents = None if rng.integers(0, 3) else [-0.25] * d + [1.5] * d
     pts = np.vstack([rng.random((n // 2, d)), np.clip(rng.normal(size=(n - n // 2, d)) * 0.06 + 0.4, 0.0, 0.999)])
     pts = np.unique(pts, axis=0)
     n = len(pts)
     kid = [0, 1, 2, 3, 7][int(rng.integers(0, 5))]            # 7: a kernel without gradients in the reference
     order = int(rng.integers(3, 7))
-    leaf = int(rng.integers(20, 120))
+    leaf = int(rng.integers(20, 120)) if adaptive else int(rng.integers(60, 200))
     params = (leaf, O.COMPRESSION_ACA, 10.0 ** -order, 1024)
-    t = F.FmmTree(pts, order, F.KernelParams(F.KernelType(kid), base_range=0.3, total_sill=0.2), True, True, params=F.FmmParams(*params))
-    r = O.FmmTree(pts, order, kid, True, True, None, O.FmmParams(*params), base_range=0.3, total_sill=0.2)
+    t = F.FmmTree(pts, order, F.KernelParams(F.KernelType(kid), base_range=0.3, total_sill=0.2), adaptive, sparse, extents=extents,
+                  params=F.FmmParams(*params))
+    r = O.FmmTree(pts, order, kid, adaptive, sparse, extents, O.FmmParams(*params), base_range=0.3, total_sill=0.2)
     inject_product_operators(t, r)
     pool_w = {k: [rng.standard_normal((n, k)) for _ in range(2)] for k in (1, 2, 3)}
     x_few = rng.random((int(rng.integers(1, 60)), d)) * 0.98 + 0.01
@@ -143,7 +148,8 @@ for s in range(n_seq):
         log.append(entry)
         if bad:
             break
-    res = {"sequence": s, "d": d, "n": n, "kernel": kid, "order": order, "leaf": leaf,
+    res = {"sequence": s, "d": d, "n": n, "kernel": kid, "order": order, "leaf": leaf, "adaptive": adaptive, "sparse": sparse,
+           "extents": extents is not None,
            "calls": [e["op"] + ("!" if e["refused"] else "") + ("" if e["compared"] else "~") for e in log],
            "max_err": max([e.get("err", 0.0) for e in log] or [0.0]), "ok": bad is None}
     if bad:
