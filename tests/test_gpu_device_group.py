@@ -318,9 +318,12 @@ def test_arbitrary_targets_are_sharded_over_the_parts(case, monkeypatch):
     assert relerr(g.evaluate(w2, x), one.evaluate(w2, x)) < 1e-12 and g.last_evaluate_path() == 0
 
 
+@pytest.mark.parametrize("jobs", ["wave_per_small_leaf", "size_rule"])
 @pytest.mark.parametrize("n", [2, 300, 5000])
-def test_tiny_clouds_on_a_group(n):
+def test_tiny_clouds_on_a_group(n, jobs, monkeypatch):
     """Fewer leaves than parts, trees of depth 0 or 1 (nothing to exchange), parts that own no row at all."""
+    if jobs == "size_rule":   # (the library's own choice for trees this small: every leaf a workgroup job)
+        monkeypatch.delenv("BBFMM_P2P_SYM_WAVE_MIN", raising=False)
     rng = np.random.default_rng(n)
     pts = rng.random((n, 3))
     kp = F.KernelParams(F.FmmKernelType.LinearRbf)
