@@ -2631,11 +2631,15 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
         const char *e = std::getenv("BBFMM_M2L_S2_ZSPLIT");
         return e && std::atoi(e) == 1 ? 1 : 2;
     }();
-    // Few tiles (a small tree, a thin slice of a partition): also split the contraction, so that about two
-    // workgroups per CU exist and none walks more than a few dozen steps alone.  The parts add to L (zeroed by the
-    // caller before every downward pass) with f64 atomics; launches that fill the chip keep plain stores.
+    // Few tiles (a small tree, a thin slice of a partition): also split the contraction, so that no workgroup walks a
+    // tile's chain of ~290 dependent steps alone.  The parts add to L (zeroed by the caller before every downward pass) with
+    // f64 atomics; launches that fill the chip keep plain stores.
     // Stage 2 per matvec: 50k points 0.50 -> 0.11 ms (the whole matvec 0.79 -> 0.39 ms), 200k 0.52 -> 0.43, 1M 0.95 -> 0.78;
     // from 3M points on the launch fills the chip and nothing changes.  BBFMM_M2L_S2_KSPLIT=<n> overrides (1: off).
+    // Round 6: the number of parts from what was measured instead of a power of two -- a CU works its workgroups off one after
+    // the other (two resident ones share its matrix pipe), a part costs a fixed 4-5 % of a whole chain plus its share of it,
+    // so the launch takes ceil(workgroups * parts / CUs) * (0.05 + 1 / parts) chains: 585 cells (32 workgroups) 16 -> 8 parts,
+    // 0.105 -> 0.085 ms; 4,681 cells (158 workgroups) 4 -> 3 parts, 0.419 -> 0.368 ms (5 parts: 0.462, 8: 0.411, 2: 0.511).
     static const int ks_env = [] {
         const char *e = std::getenv("BBFMM_M2L_S2_KSPLIT");
         const int v = e ? std::atoi(e) : 0;
@@ -2646,7 +2650,16 @@ void launch_m2l_stage2(const M2lClass *classes, const M2lTileDesc *tiles, const 
         const int n_cu = device_cu_count();
         const int64_t wgs = static_cast<int64_t>(n_tiles) * z * K;
         ksplit = 1;
-        while (ksplit < 16 && wgs * ksplit * 2 <= static_cast<int64_t>(kM2lS2KsplitFill) * n_cu) ksplit *= 2;
+        if (wgs * 2 <= static_cast<int64_t>(kM2lS2KsplitFill) * n_cu) { // (launches of at most two workgroups per CU, as before)
+            double best = 1e300;
+            for (int ks = 1; ks <= 16; ++ks) {
+                const double cost = std::ceil(static_cast<double>(wgs * ks) / n_cu) * (0.05 + 1.0 / ks);
+                if (cost < best - 1e-12) {
+                    best = cost;
+                    ksplit = ks;
+                }
+            }
+        }
     }
     m2l_dispatch_chunks<2>(n_pad / 16, classes, tiles, n_tiles, n_pad, z, K, C, cbuf, cbuf_len, L, 0, qlist, ksplit > 1 ? ksplit : 0, tile_idx, s);
 }
