@@ -994,6 +994,22 @@ int FmmTree::downward_tail(int k, const DownwardPlan *dp, const TargetSet *wx) {
 }
 
 // leaf_pass (bbfmm.rs:1089-1159) into ts.out / ts.grad (sorted order)
+// m x ncols values (column after column on the device) to the caller's host array with leading dimension ld: one copy when the
+// columns are adjacent there too, one per column otherwise.  NOT hipMemcpy2DAsync: on ROCm 7.2 a per-call device buffer that
+// was the source of a 2-D copy to pageable host memory and is freed right behind it (hipFree returns success) never goes
+// back to the device -- with it the buffers the last kernels read; 4 MB per handle that had evaluated 80k targets, without
+// bound (found with scripts/group_lifecycle_check.py; the same copy as a 1-D one leaves nothing behind).
+hipError_t FmmTree::columns_to_host(double *dst, int64_t ld, const double *d_src, int64_t m, int ncols) {
+    if (m <= 0 || ncols <= 0) return hipSuccess;
+    if (ld == m) return hipMemcpyAsync(dst, d_src, static_cast<size_t>(m) * ncols * sizeof(double), hipMemcpyDeviceToHost, stream_);
+    for (int j = 0; j < ncols; ++j) {
+        const hipError_t e = hipMemcpyAsync(dst + static_cast<size_t>(j) * ld, d_src + static_cast<size_t>(j) * m,
+                                            static_cast<size_t>(m) * sizeof(double), hipMemcpyDeviceToHost, stream_);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
 int FmmTree::leaf_pass(const TargetSet &ts, int k, bool with_grads) {
     CHK(leaf_pass_near(ts, k, with_grads, stream_, 3));
     return leaf_pass_far(ts, k, with_grads);
@@ -1233,17 +1249,14 @@ int FmmTree::evaluate(const double *w, int64_t rows, int k, int64_t ldw, const d
             phase_begin();
             launch_scatter_output(ts.out.p, m, k, ts.perm.p, o_dev.p, m, 0, stream_);
             phase_end(kPhScatter);
-            hipError_t e = hipMemcpy2DAsync(out, ldo * sizeof(double), o_dev.p, m * sizeof(double), m * sizeof(double), k,
-                                            hipMemcpyDeviceToHost, stream_);
+            hipError_t e = columns_to_host(out, ldo, o_dev.p, m, k);
             if (e != hipSuccess) rc = hip_fail(e, "copy values to host");
         }
         if (rc == BBFMM_OK && with_grads) {
             rc = talloc(&g_dev, static_cast<size_t>(k) * d_ * m);
             if (rc == BBFMM_OK) {
                 launch_scatter_output(ts.grad.p, m, k * d_, ts.perm.p, g_dev.p, m, 0, stream_);
-                hipError_t e = hipMemcpy2DAsync(grad, ldg * sizeof(double), g_dev.p, m * sizeof(double),
-                                                m * sizeof(double), static_cast<size_t>(k) * d_, hipMemcpyDeviceToHost,
-                                                stream_);
+                hipError_t e = columns_to_host(grad, ldg, g_dev.p, m, k * d_);
                 if (e != hipSuccess) rc = hip_fail(e, "copy gradients to host");
             }
         }

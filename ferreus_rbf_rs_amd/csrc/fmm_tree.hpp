@@ -264,6 +264,7 @@ class FmmTree {
     int build_source_target_set();
     int build_sym_runs(TargetSet *ts, const std::vector<int32_t> &job_cells, int64_t pb, int64_t pe, const std::vector<uint8_t> *part_active = nullptr);
     void free_target_set(TargetSet *ts);
+    hipError_t columns_to_host(double *dst, int64_t ld, const double *d_src, int64_t m, int ncols);
     int upload_weights(const double *w, int64_t rows, int k, int64_t ldw);
     void phase_begin();
     void phase_end(int ph);
