@@ -27,6 +27,8 @@ for r in range(rounds):
     z = g.evaluate(w, x)                        # sharded over the parts
     g.set_local_coefficients(w)
     u = g.evaluate_leaves(w, x)
+    ug = g.evaluate_leaves_with_gradients(w, x[:30000])
+    zg = g.evaluate_with_gradients(w, x[:30000])   # (few enough targets for the first device alone on a group)
     v = g.fast_matrix_vector_product(w[:, 0].copy(), target_indices=np.arange(0, n, 3))
     dw = torch.from_numpy(np.ascontiguousarray(w.T)).cuda()
     out = torch.zeros_like(dw)
